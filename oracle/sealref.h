@@ -1,0 +1,191 @@
+/*
+ * oracle/sealref.h -- CPU restatement of the Gemini-SEAL hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle: a plain-C restatement of the reference's algorithms for the
+ * RNS-NTT / BEHZ multiply / hybrid key-switch / modulus-switch path. It is NOT part of the
+ * product. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Parity status: PINNED by (a) the known-answer values held by the reference's own unit tests
+ * (native/tests/seal/util/{ntt,rns,polyarithsmallmod,uintarithsmallmod,galois}.cpp) and
+ * (b) FNV-1a-64 digests captured from the compiled reference by the survey stage
+ * (SURVEY.md Appendix A.5 / B.3 / B.5), committed under tests/golden/.
+ * The reference itself is unbuildable under this round's rules (needs a cmake-generated
+ * config.h and a source patch), so there is no oracle/_ref.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/native/src/seal/).
+ */
+#ifndef SEALREF_H
+#define SEALREF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- word arithmetic (util/uintarith.h, util/uintarithsmallmod.h) ---- */
+typedef struct
+{
+    uint64_t value;
+    uint64_t cr[3]; /* floor(2^128/value) low, high; 2^128 mod value  (modulus.cpp:85-98) */
+    int bit_count;
+} ref_modulus;
+
+int ref_modulus_init(ref_modulus *m, uint64_t value);
+uint64_t ref_barrett_reduce_128(uint64_t lo, uint64_t hi, const ref_modulus *m);
+uint64_t ref_barrett_reduce_63(uint64_t x, const ref_modulus *m);
+uint64_t ref_multiply_uint_mod(uint64_t a, uint64_t b, const ref_modulus *m);
+uint64_t ref_multiply_add_uint_mod(uint64_t a, uint64_t b, uint64_t c, const ref_modulus *m);
+uint64_t ref_dot_product_mod(const uint64_t *a, const uint64_t *b, size_t count, const ref_modulus *m);
+uint64_t ref_exponentiate_uint_mod(uint64_t a, uint64_t e, const ref_modulus *m);
+int ref_try_invert_uint_mod(uint64_t value, uint64_t modulus, uint64_t *result);
+uint64_t ref_shoupify(uint64_t x, uint64_t p);
+
+/* ---- number theory (util/numth.cpp, modulus.cpp) ---- */
+int ref_is_prime(uint64_t value);
+int ref_get_primes(size_t ntt_size, int bit_size, size_t count, uint64_t *out);
+int ref_coeff_modulus_create(size_t n, const int *bit_sizes, size_t count, uint64_t *out);
+int ref_try_minimal_primitive_root(uint64_t degree, const ref_modulus *m, uint64_t *root);
+
+/* ---- NTT (util/ntt.cpp, util/ntt.h) ---- */
+typedef struct
+{
+    int logn;
+    size_t n;
+    ref_modulus mod;
+    uint64_t root;
+    uint64_t inv_degree, scaled_inv_degree, reduce_precomp;
+    uint64_t *root_powers, *scaled_root_powers, *inv_root_powers, *scaled_inv_root_powers;
+} ref_ntt_tables;
+
+int ref_ntt_tables_init(ref_ntt_tables *t, int logn, uint64_t modulus);
+void ref_ntt_tables_free(ref_ntt_tables *t);
+/* mode: 0 = PARITY (reference's uncorrected lazy butterflies), 1 = STRICT (Harvey-corrected) */
+void ref_ntt_forward_lazy(uint64_t *x, const ref_ntt_tables *t, int strict);
+void ref_ntt_forward(uint64_t *x, const ref_ntt_tables *t, int strict);
+void ref_ntt_inverse_lazy(uint64_t *x, const ref_ntt_tables *t);
+void ref_ntt_inverse(uint64_t *x, const ref_ntt_tables *t);
+
+/* ---- coefficient-wise polynomial arithmetic (util/polyarithsmallmod.{h,cpp}) ---- */
+void ref_dyadic_product_coeffmod(const uint64_t *a, const uint64_t *b, size_t n, const ref_modulus *m, uint64_t *r);
+void ref_multiply_poly_scalar_coeffmod(const uint64_t *a, size_t n, uint64_t scalar, const ref_modulus *m, uint64_t *r);
+void ref_add_poly_coeffmod(const uint64_t *a, const uint64_t *b, size_t n, const ref_modulus *m, uint64_t *r);
+void ref_sub_poly_coeffmod(const uint64_t *a, const uint64_t *b, size_t n, const ref_modulus *m, uint64_t *r);
+void ref_negate_poly_coeffmod(const uint64_t *a, size_t n, const ref_modulus *m, uint64_t *r);
+void ref_modulo_poly_coeffs_63(const uint64_t *a, size_t n, const ref_modulus *m, uint64_t *r);
+
+/* ---- BaseConverter (util/rns.cpp:452-523) ---- */
+typedef struct
+{
+    size_t isize, osize;
+    ref_modulus *ibase, *obase;
+    uint64_t *inv_punct; /* [isize]  (q^_i)^{-1} mod q_i */
+    uint64_t *matrix;    /* [osize][isize]  q^_i mod p_j */
+} ref_base_converter;
+
+int ref_base_converter_init(ref_base_converter *bc, const uint64_t *ibase, size_t isize, const uint64_t *obase,
+                            size_t osize);
+void ref_base_converter_free(ref_base_converter *bc);
+void ref_fast_convert(const ref_base_converter *bc, const uint64_t *in, uint64_t *out);
+void ref_fast_convert_array(const ref_base_converter *bc, const uint64_t *in, size_t count, uint64_t *out);
+
+/* ---- RNSTool (util/rns.cpp:539-1068) ---- */
+typedef struct
+{
+    size_t n;
+    int logn;
+    size_t q_size, B_size, Bsk_size;
+    ref_modulus *q;         /* [q_size] */
+    ref_modulus *Bsk;       /* [Bsk_size]  B..., m_sk last */
+    ref_modulus m_tilde;    /* 2^32 */
+    ref_modulus m_sk, gamma, t;
+    ref_ntt_tables *Bsk_ntt; /* [Bsk_size] */
+    ref_base_converter q_to_Bsk, q_to_m_tilde, B_to_q, B_to_m_sk;
+    uint64_t *prod_B_mod_q;       /* [q_size] */
+    uint64_t *inv_prod_q_mod_Bsk; /* [Bsk_size] */
+    uint64_t inv_prod_B_mod_m_sk;
+    uint64_t *inv_m_tilde_mod_Bsk; /* [Bsk_size] */
+    uint64_t inv_prod_q_mod_m_tilde;
+    uint64_t *prod_q_mod_Bsk;    /* [Bsk_size] */
+    uint64_t *inv_q_last_mod_q;  /* [q_size-1] */
+} ref_rns_tool;
+
+int ref_rns_tool_init(ref_rns_tool *rt, size_t n, const uint64_t *q, size_t q_size, uint64_t t);
+void ref_rns_tool_free(ref_rns_tool *rt);
+void ref_fastbconv_m_tilde(const ref_rns_tool *rt, const uint64_t *in, uint64_t *out);
+void ref_sm_mrq(const ref_rns_tool *rt, const uint64_t *in, uint64_t *out);
+void ref_fast_floor(const ref_rns_tool *rt, const uint64_t *in, uint64_t *out);
+void ref_fastbconv_sk(const ref_rns_tool *rt, const uint64_t *in, uint64_t *out);
+void ref_divide_and_round_q_last_inplace(const ref_rns_tool *rt, uint64_t *in);
+void ref_divide_and_round_q_last_ntt_inplace(const ref_rns_tool *rt, uint64_t *in, const ref_ntt_tables *q_tables,
+                                             int strict);
+
+/* ---- Galois (util/galois.cpp) ---- */
+uint32_t ref_galois_elt_from_step(size_t n, int step, int *ok);
+void ref_galois_table_ntt(int logn, uint32_t galois_elt, uint32_t *table);
+void ref_apply_galois(const uint64_t *in, int logn, uint32_t galois_elt, const ref_modulus *m, uint64_t *out);
+void ref_apply_galois_ntt(const uint64_t *in, int logn, uint32_t galois_elt, uint64_t *out);
+
+/* ---- hybrid key-switch helpers (multi_special_primes.cpp) ---- */
+void ref_modup_rns(const uint64_t *src_poly, uint64_t *dst_poly, size_t n, size_t n_ct_rns, size_t n_sp_rns,
+                   size_t src_bundle_index, const ref_modulus *key_mod, size_t n_key_mod);
+void ref_rescale_special_rns_inplace(uint64_t *poly, int is_ckks, size_t n, size_t n_ct_rns, size_t n_sp_rns,
+                                     const ref_modulus *key_mod, size_t n_key_mod, const ref_ntt_tables *key_tables,
+                                     int strict);
+
+/* ---- context + Evaluator-level drivers (context.cpp, evaluator.cpp) ---- */
+#define REF_SCHEME_BFV 1
+#define REF_SCHEME_CKKS 2
+#define REF_MODE_PARITY 0
+#define REF_MODE_STRICT 1
+
+typedef struct
+{
+    int scheme;
+    int logn;
+    size_t n;
+    size_t n_key;     /* number of key-level primes */
+    size_t nsp;       /* n_special_primes */
+    size_t k_first;   /* n_key - nsp */
+    uint64_t t;       /* plain modulus (BFV), 0 for CKKS */
+    int mode;
+    ref_modulus *key_mod;       /* [n_key] */
+    ref_ntt_tables *key_tables; /* [n_key] */
+    ref_rns_tool **rns_tools;   /* [n_key+1], indexed by k (lazily built) */
+} ref_context;
+
+int ref_context_init(ref_context *c, int scheme, int logn, const uint64_t *key_moduli, size_t n_key, size_t nsp,
+                     uint64_t t, int mode);
+void ref_context_free(ref_context *c);
+const ref_rns_tool *ref_context_rns_tool(ref_context *c, size_t k);
+
+/* ciphertext layouts: size x k x N row-major uint64 (ciphertext.h:359-368) */
+/* evaluator.cpp:274-445; out has (sa+sb-1) polys of k rows */
+int ref_bfv_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                     uint64_t *out);
+/* evaluator.cpp:447-527 */
+int ref_ckks_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                      uint64_t *out);
+/* evaluator.cpp:2259-2368; ct = 2 polys (k rows) updated in place; target = k rows;
+   key = digits x 2 x n_key x N (K1 layout, keygenerator.cpp:325-369) */
+int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key);
+/* evaluator.cpp:772-827; ct has `size` polys, keys[i] is the key for RelinKeys::get_index(i+2) */
+int ref_relinearize(ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *const *keys);
+/* evaluator.cpp:829-892 (BFV mod_switch_to_next / CKKS rescale_to_next); out has `size` polys of k-1 rows */
+int ref_mod_switch_scale_to_next(ref_context *c, size_t k, const uint64_t *ct, size_t size, uint64_t *out);
+/* evaluator.cpp:894-957 (CKKS mod_switch_to_next) */
+int ref_mod_switch_drop_to_next(ref_context *c, size_t k, const uint64_t *ct, size_t size, uint64_t *out);
+/* evaluator.cpp:1841-1943; ct = 2 polys in place */
+int ref_apply_galois_inplace(ref_context *c, size_t k, uint64_t *ct, uint32_t galois_elt, const uint64_t *key);
+
+/* ---- synthetic data helpers shared by tests ---- */
+uint64_t ref_splitmix64(uint64_t *state);
+uint64_t ref_fnv1a64(const uint64_t *words, size_t count);
+void ref_fill_rows(uint64_t *dst, size_t rows, size_t n, const uint64_t *moduli, uint64_t *state);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

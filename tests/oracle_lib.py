@@ -1,0 +1,264 @@
+"""ctypes loader for the CPU oracle (oracle/libsealref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg. The product (gemini-seal_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+u64 = C.c_uint64
+u64p = C.POINTER(C.c_uint64)
+szt = C.c_size_t
+
+
+class Modulus(C.Structure):
+    _fields_ = [("value", u64), ("cr", u64 * 3), ("bit_count", C.c_int)]
+
+
+class NttTables(C.Structure):
+    _fields_ = [
+        ("logn", C.c_int),
+        ("n", szt),
+        ("mod", Modulus),
+        ("root", u64),
+        ("inv_degree", u64),
+        ("scaled_inv_degree", u64),
+        ("reduce_precomp", u64),
+        ("root_powers", u64p),
+        ("scaled_root_powers", u64p),
+        ("inv_root_powers", u64p),
+        ("scaled_inv_root_powers", u64p),
+    ]
+
+
+class BaseConverter(C.Structure):
+    _fields_ = [
+        ("isize", szt),
+        ("osize", szt),
+        ("ibase", C.POINTER(Modulus)),
+        ("obase", C.POINTER(Modulus)),
+        ("inv_punct", u64p),
+        ("matrix", u64p),
+    ]
+
+
+class RnsTool(C.Structure):
+    _fields_ = [
+        ("n", szt),
+        ("logn", C.c_int),
+        ("q_size", szt),
+        ("B_size", szt),
+        ("Bsk_size", szt),
+        ("q", C.POINTER(Modulus)),
+        ("Bsk", C.POINTER(Modulus)),
+        ("m_tilde", Modulus),
+        ("m_sk", Modulus),
+        ("gamma", Modulus),
+        ("t", Modulus),
+        ("Bsk_ntt", C.POINTER(NttTables)),
+        ("q_to_Bsk", BaseConverter),
+        ("q_to_m_tilde", BaseConverter),
+        ("B_to_q", BaseConverter),
+        ("B_to_m_sk", BaseConverter),
+        ("prod_B_mod_q", u64p),
+        ("inv_prod_q_mod_Bsk", u64p),
+        ("inv_prod_B_mod_m_sk", u64),
+        ("inv_m_tilde_mod_Bsk", u64p),
+        ("inv_prod_q_mod_m_tilde", u64),
+        ("prod_q_mod_Bsk", u64p),
+        ("inv_q_last_mod_q", u64p),
+    ]
+
+
+class Context(C.Structure):
+    _fields_ = [
+        ("scheme", C.c_int),
+        ("logn", C.c_int),
+        ("n", szt),
+        ("n_key", szt),
+        ("nsp", szt),
+        ("k_first", szt),
+        ("t", u64),
+        ("mode", C.c_int),
+        ("key_mod", C.POINTER(Modulus)),
+        ("key_tables", C.POINTER(NttTables)),
+        ("rns_tools", C.POINTER(C.POINTER(RnsTool))),
+    ]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ORACLE_DIR, "libsealref.so")
+    src = os.path.join(ORACLE_DIR, "sealref.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build()
+    L = C.CDLL(path)
+    L.ref_splitmix64.restype = u64
+    L.ref_fnv1a64.restype = u64
+    L.ref_barrett_reduce_128.restype = u64
+    L.ref_barrett_reduce_128.argtypes = [u64, u64, C.POINTER(Modulus)]
+    L.ref_barrett_reduce_63.restype = u64
+    L.ref_barrett_reduce_63.argtypes = [u64, C.POINTER(Modulus)]
+    L.ref_multiply_uint_mod.restype = u64
+    L.ref_multiply_uint_mod.argtypes = [u64, u64, C.POINTER(Modulus)]
+    L.ref_multiply_add_uint_mod.restype = u64
+    L.ref_multiply_add_uint_mod.argtypes = [u64, u64, u64, C.POINTER(Modulus)]
+    L.ref_dot_product_mod.restype = u64
+    L.ref_dot_product_mod.argtypes = [C.c_void_p, C.c_void_p, szt, C.POINTER(Modulus)]
+    L.ref_exponentiate_uint_mod.restype = u64
+    L.ref_exponentiate_uint_mod.argtypes = [u64, u64, C.POINTER(Modulus)]
+    L.ref_shoupify.restype = u64
+    L.ref_shoupify.argtypes = [u64, u64]
+    L.ref_modulus_init.argtypes = [C.POINTER(Modulus), u64]
+    L.ref_try_invert_uint_mod.argtypes = [u64, u64, u64p]
+    L.ref_is_prime.argtypes = [u64]
+    L.ref_get_primes.argtypes = [szt, C.c_int, szt, C.c_void_p]
+    L.ref_coeff_modulus_create.argtypes = [szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_ntt_tables_init.argtypes = [C.POINTER(NttTables), C.c_int, u64]
+    L.ref_ntt_tables_free.argtypes = [C.POINTER(NttTables)]
+    for f in ("ref_ntt_forward_lazy", "ref_ntt_forward"):
+        getattr(L, f).argtypes = [C.c_void_p, C.POINTER(NttTables), C.c_int]
+        getattr(L, f).restype = None
+    for f in ("ref_ntt_inverse_lazy", "ref_ntt_inverse"):
+        getattr(L, f).argtypes = [C.c_void_p, C.POINTER(NttTables)]
+        getattr(L, f).restype = None
+    L.ref_dyadic_product_coeffmod.argtypes = [C.c_void_p, C.c_void_p, szt, C.POINTER(Modulus), C.c_void_p]
+    L.ref_multiply_poly_scalar_coeffmod.argtypes = [C.c_void_p, szt, u64, C.POINTER(Modulus), C.c_void_p]
+    L.ref_add_poly_coeffmod.argtypes = [C.c_void_p, C.c_void_p, szt, C.POINTER(Modulus), C.c_void_p]
+    L.ref_sub_poly_coeffmod.argtypes = [C.c_void_p, C.c_void_p, szt, C.POINTER(Modulus), C.c_void_p]
+    L.ref_negate_poly_coeffmod.argtypes = [C.c_void_p, szt, C.POINTER(Modulus), C.c_void_p]
+    L.ref_modulo_poly_coeffs_63.argtypes = [C.c_void_p, szt, C.POINTER(Modulus), C.c_void_p]
+    L.ref_base_converter_init.argtypes = [C.POINTER(BaseConverter), C.c_void_p, szt, C.c_void_p, szt]
+    L.ref_base_converter_free.argtypes = [C.POINTER(BaseConverter)]
+    L.ref_fast_convert.argtypes = [C.POINTER(BaseConverter), C.c_void_p, C.c_void_p]
+    L.ref_fast_convert_array.argtypes = [C.POINTER(BaseConverter), C.c_void_p, szt, C.c_void_p]
+    L.ref_rns_tool_init.argtypes = [C.POINTER(RnsTool), szt, C.c_void_p, szt, u64]
+    L.ref_rns_tool_free.argtypes = [C.POINTER(RnsTool)]
+    for f in ("ref_fastbconv_m_tilde", "ref_sm_mrq", "ref_fast_floor", "ref_fastbconv_sk"):
+        getattr(L, f).argtypes = [C.POINTER(RnsTool), C.c_void_p, C.c_void_p]
+        getattr(L, f).restype = None
+    L.ref_divide_and_round_q_last_inplace.argtypes = [C.POINTER(RnsTool), C.c_void_p]
+    L.ref_divide_and_round_q_last_ntt_inplace.argtypes = [C.POINTER(RnsTool), C.c_void_p, C.POINTER(NttTables), C.c_int]
+    L.ref_galois_elt_from_step.restype = C.c_uint32
+    L.ref_galois_elt_from_step.argtypes = [szt, C.c_int, C.POINTER(C.c_int)]
+    L.ref_galois_table_ntt.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
+    L.ref_apply_galois.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(Modulus), C.c_void_p]
+    L.ref_apply_galois_ntt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    L.ref_modup_rns.argtypes = [C.c_void_p, C.c_void_p, szt, szt, szt, szt, C.POINTER(Modulus), szt]
+    L.ref_rescale_special_rns_inplace.argtypes = [C.c_void_p, C.c_int, szt, szt, szt, C.POINTER(Modulus), szt,
+                                                  C.POINTER(NttTables), C.c_int]
+    L.ref_context_init.argtypes = [C.POINTER(Context), C.c_int, C.c_int, C.c_void_p, szt, szt, u64, C.c_int]
+    L.ref_context_free.argtypes = [C.POINTER(Context)]
+    L.ref_context_rns_tool.restype = C.POINTER(RnsTool)
+    L.ref_context_rns_tool.argtypes = [C.POINTER(Context), szt]
+    L.ref_bfv_multiply.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_ckks_multiply.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_switch_key_inplace.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_relinearize.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.POINTER(C.c_void_p)]
+    L.ref_mod_switch_scale_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_mod_switch_drop_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_apply_galois_inplace.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
+    L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
+    L.ref_splitmix64.argtypes = [u64p]
+    _LIB = L
+    return L
+
+
+def ptr(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def modulus(value):
+    m = Modulus()
+    rc = lib().ref_modulus_init(C.byref(m), value)
+    assert rc == 0, value
+    return m
+
+
+def get_primes(n, bits, count):
+    out = np.zeros(count, dtype=np.uint64)
+    assert lib().ref_get_primes(n, bits, count, ptr(out)) == 0
+    return [int(x) for x in out]
+
+
+def coeff_modulus_create(n, bit_sizes):
+    bs = np.array(bit_sizes, dtype=np.int32)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    assert lib().ref_coeff_modulus_create(n, bs.ctypes.data_as(C.c_void_p), len(bit_sizes), ptr(out)) == 0
+    return [int(x) for x in out]
+
+
+class Tables:
+    def __init__(self, logn, p):
+        self.t = NttTables()
+        assert lib().ref_ntt_tables_init(C.byref(self.t), logn, p) == 0, (logn, p)
+        self.logn, self.n, self.p = logn, 1 << logn, p
+
+    def arr(self, name):
+        return np.ctypeslib.as_array(getattr(self.t, name), shape=(self.n,)).copy()
+
+    def __del__(self):
+        try:
+            lib().ref_ntt_tables_free(C.byref(self.t))
+        except Exception:
+            pass
+
+
+class SplitMix:
+    def __init__(self, seed):
+        self.state = u64(seed)
+
+    def set(self, seed):
+        self.state = u64(seed)
+
+    def fill(self, rows, n, moduli):
+        out = np.empty((rows, n), dtype=np.uint64)
+        mods = np.array(moduli, dtype=np.uint64)
+        assert len(mods) == rows
+        lib().ref_fill_rows(ptr(out), rows, n, ptr(mods), C.byref(self.state))
+        return out
+
+
+def fnv(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return int(lib().ref_fnv1a64(ptr(a), a.size))
+
+
+class RefContext:
+    def __init__(self, scheme, logn, key_moduli, nsp=1, t=0, mode=0):
+        self.c = Context()
+        km = np.array(key_moduli, dtype=np.uint64)
+        rc = lib().ref_context_init(C.byref(self.c), scheme, logn, ptr(km), len(km), nsp, t, mode)
+        assert rc == 0
+        self.scheme, self.logn, self.n = scheme, logn, 1 << logn
+        self.key_moduli = [int(x) for x in key_moduli]
+        self.n_key, self.nsp, self.k_first, self.t = len(km), nsp, len(km) - nsp, t
+
+    def rns_tool(self, k):
+        r = lib().ref_context_rns_tool(C.byref(self.c), k)
+        assert r
+        return r
+
+    def tables(self, i):
+        return C.byref(self.c.key_tables[i])
+
+    def __del__(self):
+        try:
+            lib().ref_context_free(C.byref(self.c))
+        except Exception:
+            pass
