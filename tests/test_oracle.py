@@ -1,0 +1,337 @@
+"""The CPU oracle against (a) the reference's own known-answer tests and (b) the digests the
+survey stage captured from the compiled reference. CPU only. This is what pins the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+DIG = json.load(open(os.path.join(HERE, "golden", "survey_digests.json")))
+L = O.lib()
+
+
+def h(a):
+    return "%016x" % O.fnv(a)
+
+
+def arr(x):
+    return np.array(x, dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- reference KATs
+def test_kat_ntt_root_powers():
+    k = KAT["ntt_root_powers"]
+    for case in k["cases"]:
+        t = O.Tables(case["logn"], k["p"])
+        assert [int(x) for x in t.arr("root_powers")] == case["root_powers"]
+        # The reference test also expects inv_root_powers[1] == root_powers[1]^{-1}; that line is stale
+        # in this fork, whose table is re-ordered and has n^{-1} merged in (ntt.cpp:84-98).
+
+
+def test_kat_ntt_forward_n2():
+    k = KAT["ntt_forward"]
+    t = O.Tables(k["logn"], k["p"])
+    for case in k["cases"]:
+        x = arr(case["in"])
+        L.ref_ntt_forward(O.ptr(x), C.byref(t.t), 0)
+        assert [int(v) for v in x] == case["out"]
+
+
+def test_kat_ntt_roundtrip_n8():
+    k = KAT["ntt_roundtrip"]
+    t = O.Tables(k["logn"], k["p"])
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        x = rng.integers(0, 2**32, size=8, dtype=np.uint64)
+        y = x.copy()
+        L.ref_ntt_forward(O.ptr(y), C.byref(t.t), 0)
+        L.ref_ntt_inverse(O.ptr(y), C.byref(t.t))
+        assert np.array_equal(x, y)
+    z = np.zeros(8, dtype=np.uint64)
+    L.ref_ntt_inverse(O.ptr(z), C.byref(t.t))
+    assert not z.any()
+
+
+def test_kat_barrett_and_mulmod():
+    for c in KAT["barrett_reduce_128"]["cases"]:
+        m = O.modulus(c["mod"])
+        assert L.ref_barrett_reduce_128(c["lo"], c["hi"], C.byref(m)) == c["out"]
+    for c in KAT["multiply_uint_mod"]["cases"]:
+        m = O.modulus(c["mod"])
+        assert L.ref_multiply_uint_mod(c["a"], c["b"], C.byref(m)) == c["out"]
+    for c in KAT["multiply_uint_mod"]["exponentiate"]:
+        m = O.modulus(c["mod"])
+        assert L.ref_exponentiate_uint_mod(c["a"], c["e"], C.byref(m)) == c["out"]
+
+
+def test_kat_dot_product_mod():
+    k = KAT["dot_product_mod"]
+    m = O.modulus(k["small"]["mod"])
+    a = np.full(64, k["small"]["a"], dtype=np.uint64)
+    b = np.full(64, k["small"]["b"], dtype=np.uint64)
+    for cnt in k["small"]["counts"]:
+        assert L.ref_dot_product_mod(O.ptr(a), O.ptr(b), cnt, C.byref(m)) == (6 * cnt) % 5
+    p = O.get_primes(1024, 61, 1)[0]
+    m = O.modulus(p)
+    a = np.full(64, p - 1, dtype=np.uint64)
+    for cnt in k["large"]["counts"]:
+        assert L.ref_dot_product_mod(O.ptr(a), O.ptr(a), cnt, C.byref(m)) == cnt
+
+
+def test_kat_polyarith():
+    for c in KAT["multiply_poly_scalar_coeffmod"]["cases"]:
+        m = O.modulus(c["mod"])
+        x = arr(c["in"])
+        L.ref_multiply_poly_scalar_coeffmod(O.ptr(x), len(x), c["scalar"], C.byref(m), O.ptr(x))
+        assert [int(v) for v in x] == c["out"]
+    for c in KAT["dyadic_product_coeffmod"]["cases"]:
+        m = O.modulus(c["mod"])
+        a, b = arr(c["a"]), arr(c["b"])
+        r = np.zeros_like(a)
+        L.ref_dyadic_product_coeffmod(O.ptr(a), O.ptr(b), len(a), C.byref(m), O.ptr(r))
+        assert [int(v) for v in r] == c["out"]
+
+
+def test_kat_galois():
+    k = KAT["galois"]
+    x = arr(k["in"])
+    m = O.modulus(k["mod"])
+    o = np.zeros_like(x)
+    L.ref_apply_galois(O.ptr(x), k["logn"], k["elt"], C.byref(m), O.ptr(o))
+    assert [int(v) for v in o] == k["apply_galois"]
+    L.ref_apply_galois_ntt(O.ptr(x), k["logn"], k["elt"], O.ptr(o))
+    assert [int(v) for v in o] == k["apply_galois_ntt"]
+    for elt, idx in k["index_from_elt"]:
+        assert (elt - 1) >> 1 == idx
+
+
+def test_kat_base_converter():
+    k = KAT["base_converter"]
+    for grp in k["convert"]:
+        bc = O.BaseConverter()
+        ib, ob = arr(grp["ibase"]), arr(grp["obase"])
+        assert L.ref_base_converter_init(C.byref(bc), O.ptr(ib), len(ib), O.ptr(ob), len(ob)) == 0
+        for cin, cout in grp["cases"]:
+            x = arr(cin)
+            o = np.zeros(len(ob), dtype=np.uint64)
+            L.ref_fast_convert(C.byref(bc), O.ptr(x), O.ptr(o))
+            assert [int(v) for v in o] == cout
+        L.ref_base_converter_free(C.byref(bc))
+    for grp in k["convert_array"]:
+        bc = O.BaseConverter()
+        ib, ob = arr(grp["ibase"]), arr(grp["obase"])
+        assert L.ref_base_converter_init(C.byref(bc), O.ptr(ib), len(ib), O.ptr(ob), len(ob)) == 0
+        x = arr(grp["in"])
+        o = np.zeros(len(ob) * grp["count"], dtype=np.uint64)
+        L.ref_fast_convert_array(C.byref(bc), O.ptr(x), grp["count"], O.ptr(o))
+        assert [int(v) for v in o] == grp["out"]
+        L.ref_base_converter_free(C.byref(bc))
+
+
+def _tool(q):
+    rt = O.RnsTool()
+    qa = arr(q)
+    assert L.ref_rns_tool_init(C.byref(rt), 2, O.ptr(qa), len(q), 0) == 0
+    bsk = [int(rt.Bsk[i].value) for i in range(rt.Bsk_size)]
+    return rt, bsk
+
+
+def test_kat_rns_tool():
+    k = KAT["rns_tool"]
+    mt = 1 << 32
+    for c in k["fastbconv_m_tilde"]:
+        rt, bsk = _tool(c["q"])
+        x = arr(c["in"])
+        o = np.zeros(2 * (len(bsk) + 1), dtype=np.uint64)
+        zero = np.zeros_like(x)
+        L.ref_fastbconv_m_tilde(C.byref(rt), O.ptr(zero), O.ptr(o))
+        assert not o.any()
+        L.ref_fastbconv_m_tilde(C.byref(rt), O.ptr(x), O.ptr(o))
+        bases = bsk + [mt]
+        if c["expect_expr"] == "q3":
+            t1, t2 = mt % 3, (2 * mt) % 3
+            exp = sum(([t1 % b, t2 % b] for b in bases), [])
+        else:
+            t = ((2 * mt) % 3) * 5 + ((4 * mt) % 5) * 3
+            exp = sum(([t % b, t % b] for b in bases), [])
+        assert [int(v) for v in o] == exp
+        L.ref_rns_tool_free(C.byref(rt))
+    for c in k["sm_mrq"]:
+        rt, bsk = _tool(c["q"])
+        nb = len(bsk)
+        if "in_expr" in c:
+            x = [mt, 2 * mt] * nb + [0, 0]
+        elif "in_const" in c:
+            x = [c["in_const"]] * (2 * nb + 2)
+        elif "in_pair" in c:
+            x = c["in_pair"] * (nb + 1)
+        else:
+            x = [2 * mt + c["in_pair_plus_2mt"][0], 2 * mt + c["in_pair_plus_2mt"][1]] * (nb + 1)
+        x = arr(x)
+        o = np.zeros(2 * nb, dtype=np.uint64)
+        L.ref_sm_mrq(C.byref(rt), O.ptr(x), O.ptr(o))
+        assert [int(v) for v in o] == c["out"]
+        L.ref_rns_tool_free(C.byref(rt))
+    for c in k["fast_floor"]:
+        rt, bsk = _tool(c["q"])
+        nb = len(bsk)
+        x = arr(c["in_pair"] * (len(c["q"]) + nb))
+        o = np.zeros(2 * nb, dtype=np.uint64)
+        L.ref_fast_floor(C.byref(rt), O.ptr(x), O.ptr(o))
+        got = [int(v) for v in o]
+        if c["exact"]:
+            assert got == c["out"]
+        else:
+            assert all(abs(g - e) <= 1 for g, e in zip(got, c["out"]))
+        L.ref_rns_tool_free(C.byref(rt))
+    for c in k["fastbconv_sk"]:
+        rt, bsk = _tool(c["q"])
+        x = arr(c["in_pair"] * len(bsk))
+        o = np.zeros(2 * len(c["q"]), dtype=np.uint64)
+        L.ref_fastbconv_sk(C.byref(rt), O.ptr(x), O.ptr(o))
+        assert [int(v) for v in o] == c["out"]
+        L.ref_rns_tool_free(C.byref(rt))
+    for c in k["divide_and_round_q_last_inplace"]:
+        rt, _ = _tool(c["q"])
+        x = arr(c["in"])
+        L.ref_divide_and_round_q_last_inplace(C.byref(rt), O.ptr(x))
+        got = [int(v) for v in x[: len(c["out"])]]
+        if c["exact"]:
+            assert got == c["out"]
+        else:
+            mods = sum(([q, q] for q in c["q"][:-1]), [])
+            assert all((m + e - g) % m <= 1 for g, e, m in zip(got, c["out"], mods))
+        L.ref_rns_tool_free(C.byref(rt))
+
+
+# ---------------------------------------------------------------- survey digests (compiled reference)
+@pytest.mark.parametrize("row", DIG["table_kats"], ids=lambda r: "logn%d_p%d" % (r["logn"], r["p"]))
+def test_digest_tables(row):
+    t = O.Tables(row["logn"], row["p"])
+    assert t.t.root == row["psi"]
+    assert int(t.arr("root_powers")[1]) == row["root_powers_1"]
+    irp = t.arr("inv_root_powers")
+    assert int(irp[1]) == row["inv_root_powers_1"] and int(irp[-1]) == row["inv_root_powers_last"]
+
+
+def test_digest_prime_lists():
+    for row in DIG["prime_lists"]:
+        assert O.coeff_modulus_create(1 << row["logn"], row["bits"]) == row["primes"]
+    for row in DIG["aux_primes_60"]:
+        assert O.get_primes(1 << row["logn"], 60, row["count"]) == row["primes"]
+    for row in DIG["galois_elts"]:
+        n = 1 << row["logn"]
+        assert L.ref_galois_elt_from_step(n, 1, None) == row["step1"]
+        assert L.ref_galois_elt_from_step(n, 0, None) == row["step0"]
+        assert L.ref_galois_elt_from_step(n, -1, None) == row["stepm1"]
+
+
+@pytest.mark.parametrize("row", DIG["ntt_digests"], ids=lambda r: "logn%d_k%d" % (r["logn"], len(r["bits"])))
+def test_digest_ntt(row):
+    logn, k = row["logn"], len(row["bits"])
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, row["bits"])
+    x = O.SplitMix(0x5EA1 + 1000 * logn + k).fill(k, n, mods)
+    assert h(x) == row["input"]
+    tabs = [O.Tables(logn, p) for p in mods]
+    f, lz, iv = x.copy(), x.copy(), x.copy()
+    dy = np.empty_like(x)
+    for i in range(k):
+        L.ref_ntt_forward(O.ptr(f[i]), C.byref(tabs[i].t), 0)
+        L.ref_ntt_forward_lazy(O.ptr(lz[i]), C.byref(tabs[i].t), 0)
+        L.ref_ntt_inverse(O.ptr(iv[i]), C.byref(tabs[i].t))
+        m = O.modulus(mods[i])
+        L.ref_dyadic_product_coeffmod(O.ptr(f[i]), O.ptr(f[i]), n, C.byref(m), O.ptr(dy[i]))
+    assert h(f) == row["fwd"] and h(lz) == row["fwd_lazy"] and h(dy) == row["dyadic_sq"] and h(iv) == row["inv"]
+    if "fwd_first" in row:
+        assert int(f[0, 0]) == row["fwd_first"] and int(f[-1, -1]) == row["fwd_last"]
+    back = f.copy()
+    for i in range(k):
+        L.ref_ntt_inverse(O.ptr(back[i]), C.byref(tabs[i].t))
+    assert np.array_equal(back, x)
+    # STRICT (Harvey-corrected) forward coincides with PARITY on <=59-bit primes
+    st = x.copy()
+    for i in range(k):
+        L.ref_ntt_forward(O.ptr(st[i]), C.byref(tabs[i].t), 1)
+    assert np.array_equal(st, f)
+
+
+UD = DIG["unit_digests"]
+
+
+@pytest.mark.parametrize("ci", range(len(UD["columns"])), ids=[c["name"] for c in UD["columns"]])
+def test_digest_unit_functions(ci):
+    col = UD["columns"][ci]
+    logn, nsp = col["logn"], col["nsp"]
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, col["bits"])
+    ctx = O.RefContext(1, logn, kmods, nsp=nsp, t=col["t"])
+    k = ctx.k_first
+    rt = ctx.rns_tool(k)
+    bsk = [int(rt.contents.Bsk[i].value) for i in range(rt.contents.Bsk_size)]
+    nb, q, nk = len(bsk), kmods[:k], len(kmods)
+    sm = O.SplitMix(0)
+    res = {}
+    sm.set(0xF00D0001)
+    x = sm.fill(k, n, q)
+    out = np.zeros((nb + 1, n), dtype=np.uint64)
+    L.ref_fastbconv_m_tilde(rt, O.ptr(x), O.ptr(out))
+    res["fastbconv_m_tilde"] = h(out)
+    sm.set(0xF00D0002)
+    x = sm.fill(nb + 1, n, bsk + [1 << 32])
+    out = np.zeros((nb, n), dtype=np.uint64)
+    L.ref_sm_mrq(rt, O.ptr(x), O.ptr(out))
+    res["sm_mrq"] = h(out)
+    sm.set(0xF00D0003)
+    x = sm.fill(k + nb, n, q + bsk)
+    out = np.zeros((nb, n), dtype=np.uint64)
+    L.ref_fast_floor(rt, O.ptr(x), O.ptr(out))
+    res["fast_floor"] = h(out)
+    sm.set(0xF00D0004)
+    x = sm.fill(nb, n, bsk)
+    out = np.zeros((k, n), dtype=np.uint64)
+    L.ref_fastbconv_sk(rt, O.ptr(x), O.ptr(out))
+    res["fastbconv_sk"] = h(out)
+    sm.set(0xF00D0005)
+    x = sm.fill(k, n, q)
+    L.ref_divide_and_round_q_last_inplace(rt, O.ptr(x))
+    res["divide_and_round_q_last_inplace"] = h(x[: k - 1])
+    sm.set(0xF00D0006)
+    x = sm.fill(k, n, q)
+    L.ref_divide_and_round_q_last_ntt_inplace(rt, O.ptr(x), ctx.c.key_tables, 0)
+    res["divide_and_round_q_last_ntt_inplace"] = h(x[: k - 1])
+    sm.set(0xF00D0007)
+    x = sm.fill(1, n, q[:1])
+    o1, o2 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    m0 = O.modulus(q[0])
+    L.ref_apply_galois(O.ptr(x), logn, 5, C.byref(m0), O.ptr(o1))
+    L.ref_apply_galois_ntt(O.ptr(x), logn, 5, O.ptr(o2))
+    res["apply_galois"], res["apply_galois_ntt"] = h(o1), h(o2)
+    for key, b in (("modup_rns_first", 0), ("modup_rns_last", col["modup_last_bundle"])):
+        ext = np.zeros((k + nsp, n), dtype=np.uint64)
+        sm.set(0xF00D0008 + b)
+        r0 = b * nsp
+        r1 = min(r0 + nsp, k)
+        ext[r0:r1] = sm.fill(r1 - r0, n, kmods[r0:r1])
+        L.ref_modup_rns(O.ptr(ext[r0:]), O.ptr(ext), n, k, nsp, b, ctx.c.key_mod, nk)
+        res[key] = h(ext)
+    for key, isck in (("rescale_special_ckks", 1), ("rescale_special_bfv", 0)):
+        sm.set(0xF00D0010 + isck)
+        ext = sm.fill(k + nsp, n, kmods[:k] + kmods[nk - nsp:])
+        L.ref_rescale_special_rns_inplace(O.ptr(ext), isck, n, k, nsp, ctx.c.key_mod, nk, ctx.c.key_tables, 0)
+        res[key] = h(ext[:k])
+    for key, val in res.items():
+        assert val == UD[key][ci], key
+
+
+@pytest.mark.parametrize("row", DIG["end_to_end"], ids=lambda r: "cfg%d" % r["cfg"])
+def test_digest_end_to_end(row):
+    import synth
+
+    got = synth.run_reference_chain(row)
+    assert got == row["digests"]
