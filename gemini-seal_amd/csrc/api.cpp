@@ -1,0 +1,813 @@
+// api.cpp -- the C ABI of include/sealhip.h. Conventions follow the reference's C export layer
+// (native/src/seal/c/defines.h:34-58, c/evaluator.cpp:39-47): null checks -> E_POINTER, C++ exceptions
+// mapped to HRESULTs (invalid_argument -> E_INVALIDARG, logic_error -> COR_E_INVALIDOPERATION,
+// everything else -> E_UNEXPECTED), nothing thrown across the boundary.
+#include "../../include/sealhip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "engine.hpp"
+
+using namespace sealhip;
+
+struct sealhip_context
+{
+    std::unique_ptr<Engine> engine;
+};
+struct sealhip_kswitch_key
+{
+    KSwitchKey key;
+};
+
+namespace
+{
+    thread_local std::string g_last_error;
+
+    long fail(long code, const std::string &msg)
+    {
+        g_last_error = msg;
+        return code;
+    }
+
+    template <class F>
+    long guarded(F &&body)
+    {
+        try
+        {
+            body();
+            return SEALHIP_S_OK;
+        }
+        catch (const HipError &err)
+        {
+            return fail(err.code == hipErrorOutOfMemory ? SEALHIP_E_OUTOFMEMORY : SEALHIP_E_UNEXPECTED, err.what());
+        }
+        catch (const std::invalid_argument &err)
+        {
+            return fail(SEALHIP_E_INVALIDARG, err.what());
+        }
+        catch (const std::out_of_range &err)
+        {
+            return fail(SEALHIP_E_INVALIDARG, err.what());
+        }
+        catch (const std::logic_error &err)
+        {
+            return fail(SEALHIP_COR_E_INVALIDOPERATION, err.what());
+        }
+        catch (const std::bad_alloc &)
+        {
+            return fail(SEALHIP_E_OUTOFMEMORY, "out of host memory");
+        }
+        catch (const std::exception &err)
+        {
+            return fail(SEALHIP_E_UNEXPECTED, err.what());
+        }
+        catch (...)
+        {
+            return fail(SEALHIP_E_UNEXPECTED, "unknown error");
+        }
+    }
+
+#define REQUIRE_PTR(p)                                             \
+    do                                                             \
+    {                                                              \
+        if (!(p))                                                  \
+            return fail(SEALHIP_E_POINTER, #p " is null");         \
+    } while (0)
+
+    Engine &device_engine(sealhip_context *ctx)
+    {
+        Engine &e = *ctx->engine;
+        if (e.device < 0)
+            throw std::logic_error("host-only context: there is no CPU fallback, create the context on a HIP device");
+        SEALHIP_CHECK(hipSetDevice(e.device));
+        return e;
+    }
+
+    void check_level(const Engine &e, uint32_t k)
+    {
+        if (k < 1 || static_cast<int>(k) > e.n_key)
+            throw std::invalid_argument("level k out of range");
+    }
+
+    void check_launch(hipError_t err, const char *what)
+    {
+        if (err != hipSuccess)
+            throw HipError(err, (std::string(what) + ": " + hipGetErrorString(err)).c_str());
+    }
+
+    void ntt_entry(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base, bool inverse,
+                   int flags)
+    {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (base == SEALHIP_BASE_BSK || base == SEALHIP_BASE_KEY)
+            (void)e.level(static_cast<int>(k));
+        const RowMap map = e.map_for(static_cast<int>(k), base);
+        check_launch(launch_ntt(e, reinterpret_cast<u64 *>(data), count * map.rows, map, inverse, flags), "ntt");
+    }
+
+    void poly_entry(sealhip_context *ctx, PolyOp op, const uint64_t *a, const uint64_t *b, uint64_t scalar,
+                    uint64_t *r, size_t count, uint32_t k, uint32_t base)
+    {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        const RowMap map = e.map_for(static_cast<int>(k), base);
+        check_launch(launch_poly_op(e, op, reinterpret_cast<const u64 *>(a), reinterpret_cast<const u64 *>(b), scalar,
+                                    reinterpret_cast<u64 *>(r), count * map.rows, map),
+                     "poly op");
+    }
+
+    LevelTools &bfv_level(Engine &e, uint32_t k)
+    {
+        check_level(e, k);
+        if (e.scheme != 1)
+            throw std::logic_error("unsupported operation for scheme type");
+        return e.level(static_cast<int>(k));
+    }
+} // namespace
+
+extern "C" {
+
+const char *sealhip_last_error_string(void)
+{
+    return g_last_error.c_str();
+}
+
+long sealhip_num_devices(int32_t *count)
+{
+    REQUIRE_PTR(count);
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    *count = err == hipSuccess ? n : 0;
+    return SEALHIP_S_OK;
+}
+
+long sealhip_context_create(const sealhip_params *params, sealhip_context **out)
+{
+    REQUIRE_PTR(params);
+    REQUIRE_PTR(out);
+    REQUIRE_PTR(params->key_moduli);
+    *out = nullptr;
+    return guarded([&] {
+        if (params->mode != SEALHIP_MODE_PARITY && params->mode != SEALHIP_MODE_STRICT)
+            throw std::invalid_argument("unknown mode");
+        if (params->device >= 0)
+        {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || params->device >= n)
+                throw HipError(hipErrorNoDevice, "no such HIP device (the engine has no CPU fallback)");
+        }
+        auto ctx = std::make_unique<sealhip_context>();
+        ctx->engine = make_engine(static_cast<int>(params->scheme), static_cast<int>(params->log_n),
+                                  reinterpret_cast<const u64 *>(params->key_moduli),
+                                  static_cast<int>(params->n_key_moduli), static_cast<int>(params->n_special_primes),
+                                  params->plain_modulus, params->mode == SEALHIP_MODE_STRICT, params->device);
+        *out = ctx.release();
+    });
+}
+
+long sealhip_context_destroy(sealhip_context *ctx)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] { delete ctx; });
+}
+
+long sealhip_context_first_level(const sealhip_context *ctx, uint32_t *k_first)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(k_first);
+    *k_first = static_cast<uint32_t>(ctx->engine->k_first);
+    return SEALHIP_S_OK;
+}
+
+long sealhip_context_bsk_size(sealhip_context *ctx, uint32_t k, uint32_t *bsk_size)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(bsk_size);
+    return guarded([&] {
+        Engine &e = *ctx->engine;
+        check_level(e, k);
+        if (e.scheme != 1)
+            throw std::logic_error("base Bsk exists only for BFV");
+        *bsk_size = static_cast<uint32_t>(e.level_host(static_cast<int>(k)).map_bsk.rows);
+    });
+}
+
+long sealhip_set_stream(sealhip_context *ctx, void *hip_stream)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        if (hip_stream)
+        {
+            if (e.own_stream)
+                SEALHIP_CHECK(hipStreamDestroy(e.stream));
+            e.stream = static_cast<hipStream_t>(hip_stream);
+            e.own_stream = false;
+        }
+        else if (!e.own_stream)
+        {
+            SEALHIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+            e.own_stream = true;
+        }
+    });
+}
+
+long sealhip_synchronize(sealhip_context *ctx)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+    });
+}
+
+long sealhip_malloc(sealhip_context *ctx, size_t bytes, void **dptr)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(dptr);
+    return guarded([&] {
+        device_engine(ctx);
+        SEALHIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1));
+    });
+}
+
+long sealhip_free(sealhip_context *ctx, void *dptr)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipFree(dptr));
+    });
+}
+
+long sealhip_memcpy_h2d(sealhip_context *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(dst_dev);
+    REQUIRE_PTR(src_host);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+    });
+}
+
+long sealhip_memcpy_d2h(sealhip_context *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(dst_host);
+    REQUIRE_PTR(src_dev);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+    });
+}
+
+long sealhip_profile_enable(sealhip_context *ctx, int32_t enable)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        e.prof_on = enable != 0;
+    });
+}
+
+long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(json);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        struct Agg
+        {
+            std::size_t launches = 0;
+            double ms = 0, units = 0;
+        };
+        std::map<std::string, Agg> agg;
+        for (ProfRecord &r : e.prof)
+        {
+            float ms = 0;
+            if (r.start && r.stop && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess)
+            {
+                Agg &a = agg[r.tag];
+                a.launches++;
+                a.ms += ms;
+                a.units += r.units;
+            }
+            if (r.start)
+                (void)hipEventDestroy(r.start);
+            if (r.stop)
+                (void)hipEventDestroy(r.stop);
+        }
+        e.prof.clear();
+        std::string out = "{";
+        bool first = true;
+        for (auto &kv : agg)
+        {
+            char buf[256];
+            std::snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %zu, \"ms\": %.6f, \"units\": %.0f}",
+                          first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.units);
+            out += buf;
+            first = false;
+        }
+        out += "}";
+        if (out.size() + 1 > capacity)
+            throw std::invalid_argument("capacity too small");
+        std::memcpy(json, out.c_str(), out.size() + 1);
+    });
+}
+
+long sealhip_debug_ntt_table(sealhip_context *ctx, uint32_t prime_index, uint32_t kind, uint64_t *out_host,
+                             size_t capacity)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(out_host);
+    return guarded([&] {
+        Engine &e = *ctx->engine;
+        if (static_cast<int>(prime_index) >= e.n_primes() || kind > 3)
+            throw std::invalid_argument("table index out of range");
+        if (capacity < e.n)
+            throw std::invalid_argument("capacity too small");
+        const HostNttTables &tb = e.tables[prime_index];
+        if (tb.fwd.empty())
+            throw std::invalid_argument("this prime has no NTT tables");
+        const std::vector<u64> v = tb.reference_table(static_cast<int>(kind));
+        std::memcpy(out_host, v.data(), v.size() * sizeof(u64));
+    });
+}
+
+long sealhip_debug_rns_constants(sealhip_context *ctx, uint32_t k, uint32_t which, uint64_t *out_host,
+                                 size_t capacity, size_t *written)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(out_host);
+    REQUIRE_PTR(written);
+    return guarded([&] {
+        Engine &e = *ctx->engine;
+        check_level(e, k);
+        const HostRnsTool &r = *e.level_host(static_cast<int>(k)).host_rns;
+        std::vector<u64> v;
+        switch (which)
+        {
+        case 0: v = r.Bsk; break;
+        case 1: v = r.inv_prod_q_mod_Bsk; break;
+        case 2: v = r.prod_q_mod_Bsk; break;
+        case 3: v = r.inv_m_tilde_mod_Bsk; break;
+        case 4: v = r.prod_B_mod_q; break;
+        case 5: v = r.inv_q_last_mod_q; break;
+        case 6: v = { r.inv_prod_q_mod_m_tilde, r.inv_prod_B_mod_m_sk, r.m_sk, r.gamma }; break;
+        case 7: v = r.q_to_Bsk.matrix; break;
+        case 8: v = r.B_to_q.matrix; break;
+        case 9: v = r.q_to_Bsk.inv_punct; break;
+        case 10: v = r.B_to_q.inv_punct; break;
+        case 11: v = r.q_to_m_tilde.matrix; break;
+        case 12: v = r.B_to_m_sk.matrix; break;
+        default: throw std::invalid_argument("unknown constant selector");
+        }
+        if (capacity < v.size())
+            throw std::invalid_argument("capacity too small");
+        std::memcpy(out_host, v.data(), v.size() * sizeof(u64));
+        *written = v.size();
+    });
+}
+
+/* ---------------------------------------------------------------- NTT */
+long sealhip_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] { ntt_entry(ctx, data, count, k, base, false, 0); });
+}
+long sealhip_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] { ntt_entry(ctx, data, count, k, base, false, kNttCanonical); });
+}
+long sealhip_inverse_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
+                                                uint32_t base)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] { ntt_entry(ctx, data, count, k, base, true, 0); });
+}
+long sealhip_inverse_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
+                                           uint32_t base)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] { ntt_entry(ctx, data, count, k, base, true, kNttCanonical); });
+}
+
+/* ---------------------------------------------------------------- coefficient-wise */
+long sealhip_dyadic_product_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count,
+                                     uint32_t k, uint32_t base, uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(b);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Dyadic, a, b, 0, result, count, k, base); });
+}
+long sealhip_multiply_poly_scalar_coeffmod(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k,
+                                           uint32_t base, uint64_t scalar, uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Scalar, a, a, scalar, result, count, k, base); });
+}
+long sealhip_add_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count, uint32_t k,
+                               uint32_t base, uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(b);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Add, a, b, 0, result, count, k, base); });
+}
+long sealhip_sub_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count, uint32_t k,
+                               uint32_t base, uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(b);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Sub, a, b, 0, result, count, k, base); });
+}
+long sealhip_negate_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k, uint32_t base,
+                                  uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Negate, a, a, 0, result, count, k, base); });
+}
+
+/* ---------------------------------------------------------------- RNSTool */
+long sealhip_fastbconv_m_tilde(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        LevelTools &lt = bfv_level(e, k);
+        check_launch(launch_fastbconv_m_tilde(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in), k * e.n,
+                                              reinterpret_cast<u64 *>(out), (lt.h_rns.nB + 1) * e.n, count),
+                     "fastbconv_m_tilde");
+    });
+}
+long sealhip_sm_mrq(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        LevelTools &lt = bfv_level(e, k);
+        check_launch(launch_sm_mrq(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in), (lt.h_rns.nB + 1) * e.n,
+                                   reinterpret_cast<u64 *>(out), lt.h_rns.nB * e.n, count),
+                     "sm_mrq");
+    });
+}
+long sealhip_fast_floor(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        LevelTools &lt = bfv_level(e, k);
+        check_launch(launch_fast_floor(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in),
+                                       (k + lt.h_rns.nB) * e.n, reinterpret_cast<u64 *>(out), lt.h_rns.nB * e.n, count,
+                                       0),
+                     "fast_floor");
+    });
+}
+long sealhip_fastbconv_sk(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        LevelTools &lt = bfv_level(e, k);
+        check_launch(launch_fastbconv_sk(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in), lt.h_rns.nB * e.n,
+                                         reinterpret_cast<u64 *>(out), k * e.n, count),
+                     "fastbconv_sk");
+    });
+}
+long sealhip_divide_and_round_q_last_inplace(sealhip_context *ctx, uint32_t k, uint64_t *data, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (k < 2)
+            throw std::invalid_argument("divide_and_round_q_last needs at least two primes");
+        LevelTools &lt = e.level(static_cast<int>(k));
+        u64 *p = reinterpret_cast<u64 *>(data);
+        check_launch(launch_divround_bfv(e, lt.d_rns, lt.h_rns, p, k * e.n, p, k * e.n, count, static_cast<int>(k)),
+                     "divide_and_round_q_last");
+    });
+}
+long sealhip_divide_and_round_q_last_ntt_inplace(sealhip_context *ctx, uint32_t k, uint64_t *data, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(data);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_divround_ntt_inplace(e, static_cast<int>(k), reinterpret_cast<u64 *>(data), count);
+    });
+}
+
+/* ---------------------------------------------------------------- Galois */
+long sealhip_galois_elt_from_step(const sealhip_context *ctx, int32_t step, uint32_t *galois_elt)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(galois_elt);
+    return guarded([&] {
+        // galois.cpp:49-91, generator 5 (util/galois.h:169)
+        const uint32_t n = static_cast<uint32_t>(ctx->engine->n);
+        const uint64_t m = static_cast<uint64_t>(n) * 2;
+        if (step == 0)
+        {
+            *galois_elt = static_cast<uint32_t>(m - 1);
+            return;
+        }
+        const bool negative = step < 0;
+        const uint32_t pos = static_cast<uint32_t>(negative ? -static_cast<int64_t>(step) : step);
+        if (pos >= (n >> 1))
+            throw std::invalid_argument("step count too large");
+        uint32_t s = negative ? (n >> 1) - pos : pos;
+        uint64_t elt = 1;
+        while (s--)
+            elt = (elt * 5) & (m - 1);
+        *galois_elt = static_cast<uint32_t>(elt);
+    });
+}
+
+static long galois_entry(sealhip_context *ctx, const uint64_t *in, size_t count, uint32_t k, uint32_t galois_elt,
+                         uint64_t *out, bool ntt_form)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (in == out)
+            throw std::invalid_argument("result cannot point to the same value as operand"); // galois.cpp:156-159
+        if (!(galois_elt & 1) || galois_elt >= 2 * e.n)
+            throw std::invalid_argument("Galois element is not valid");
+        const RowMap map = e.map_for(static_cast<int>(k), SEALHIP_BASE_Q);
+        const uint32_t *table = ntt_form ? e.galois_table(galois_elt) : nullptr;
+        check_launch(launch_galois(e, reinterpret_cast<const u64 *>(in), reinterpret_cast<u64 *>(out), count * k, map,
+                                   galois_elt, table),
+                     "apply_galois");
+    });
+}
+long sealhip_apply_galois(sealhip_context *ctx, const uint64_t *in, size_t count, uint32_t k, uint32_t galois_elt,
+                          uint64_t *out)
+{
+    return galois_entry(ctx, in, count, k, galois_elt, out, false);
+}
+long sealhip_apply_galois_ntt(sealhip_context *ctx, const uint64_t *in, size_t count, uint32_t k, uint32_t galois_elt,
+                              uint64_t *out)
+{
+    return galois_entry(ctx, in, count, k, galois_elt, out, true);
+}
+
+/* ---------------------------------------------------------------- key switch */
+long sealhip_kswitch_key_load(sealhip_context *ctx, const uint64_t *key, uint32_t n_digits, int32_t from_host,
+                              sealhip_kswitch_key **out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(key);
+    REQUIRE_PTR(out);
+    *out = nullptr;
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        const uint32_t max_digits = static_cast<uint32_t>((e.k_first + e.nsp - 1) / e.nsp); // keygenerator.cpp:334-336
+        if (n_digits == 0 || n_digits > max_digits)
+            throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        auto k = std::make_unique<sealhip_kswitch_key>();
+        k->key.n_digits = n_digits;
+        k->key.words = static_cast<std::size_t>(n_digits) * 2 * e.n_key * e.n;
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&k->key.d_data), k->key.words * sizeof(u64)));
+        hipError_t err = hipMemcpyAsync(k->key.d_data, key, k->key.words * sizeof(u64),
+                                        from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e.stream);
+        if (err == hipSuccess)
+            err = hipStreamSynchronize(e.stream);
+        if (err != hipSuccess)
+        {
+            (void)hipFree(k->key.d_data);
+            throw HipError(err, hipGetErrorString(err));
+        }
+        *out = k.release();
+    });
+}
+long sealhip_kswitch_key_destroy(sealhip_context *ctx, sealhip_kswitch_key *key)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(key);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipFree(key->key.d_data));
+        delete key;
+    });
+}
+long sealhip_modup_rns(sealhip_context *ctx, uint32_t k, uint32_t src_bundle_index, uint64_t *ext, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ext);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_modup(e, static_cast<int>(k), static_cast<int>(src_bundle_index), reinterpret_cast<u64 *>(ext), count);
+    });
+}
+long sealhip_rescale_special_rns_inplace(sealhip_context *ctx, uint32_t k, uint64_t *poly, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(poly);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_rescale_special_inplace(e, static_cast<int>(k), reinterpret_cast<u64 *>(poly), count);
+    });
+}
+long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, const uint64_t *target, size_t count,
+                                const sealhip_kswitch_key *key)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(target);
+    REQUIRE_PTR(key);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        op_switch_key(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), 2 * poly,
+                      reinterpret_cast<const u64 *>(target), poly, count, key->key);
+    });
+}
+
+/* ---------------------------------------------------------------- Evaluator level */
+long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a,
+                                const uint64_t *b, uint32_t size_b, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(b);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        // SEAL_CIPHERTEXT_SIZE_MIN/MAX (util/defines.h:56-57)
+        if (size_a < 2 || size_b < 2 || size_a + size_b - 1 > 16)
+            throw std::invalid_argument("encrypted1 or encrypted2 is not valid for encryption parameters");
+        if (out == a || out == b)
+            throw std::invalid_argument("out must not alias an operand");
+        if (e.scheme == 1)
+            op_bfv_multiply(e, static_cast<int>(k), reinterpret_cast<const u64 *>(a), static_cast<int>(size_a),
+                            reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), count,
+                            reinterpret_cast<u64 *>(out));
+        else
+            op_ckks_multiply(e, static_cast<int>(k), reinterpret_cast<const u64 *>(a), static_cast<int>(size_a),
+                             reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), count,
+                             reinterpret_cast<u64 *>(out));
+    });
+}
+
+long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, size_t count,
+                              uint64_t *out)
+{
+    // bfv_square / ckks_square (evaluator.cpp:560-770) compute the same canonical residues as
+    // multiply(a, a): 2*c0*c1 mod p == c0*c1 + c1*c0 mod p.
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size_a < 2 || 2 * size_a - 1 > 16)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (out == a)
+            throw std::invalid_argument("out must not alias the operand");
+        const u64 *pa = reinterpret_cast<const u64 *>(a);
+        if (e.scheme == 1)
+            op_bfv_multiply(e, static_cast<int>(k), pa, static_cast<int>(size_a), pa, static_cast<int>(size_a), count,
+                            reinterpret_cast<u64 *>(out));
+        else
+            op_ckks_multiply(e, static_cast<int>(k), pa, static_cast<int>(size_a), pa, static_cast<int>(size_a), count,
+                             reinterpret_cast<u64 *>(out));
+    });
+}
+
+long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                   const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 2 || size > 16)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (size == 2)
+            return; // evaluator.cpp:798-802
+        if (!relin_keys || n_relin_keys < size - 2)
+            throw std::invalid_argument("not enough relinearization keys"); // :793-796
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        u64 *p = reinterpret_cast<u64 *>(ct);
+        // :811-815 -- the target stays the LAST polynomial for every step, exactly like the reference
+        for (uint32_t I = 0; I + 2 < size; I++)
+        {
+            const uint32_t key_power = size - 1 - I;
+            const sealhip_kswitch_key *key = relin_keys[key_power - 2];
+            if (!key)
+                throw std::invalid_argument("not enough relinearization keys");
+            op_switch_key(e, static_cast<int>(k), p, size * poly, p + (size - 1) * poly, size * poly, count, key->key);
+        }
+    });
+}
+
+long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                          size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (k < 2)
+            throw std::invalid_argument("end of modulus switching chain reached");
+        const u64 *in = reinterpret_cast<const u64 *>(ct);
+        u64 *o = reinterpret_cast<u64 *>(out);
+        if (e.scheme == 1)
+            op_mod_switch_scale(e, static_cast<int>(k), in, static_cast<int>(size), count, o);
+        else
+            // mod_switch_drop_to_next (evaluator.cpp:894-957): keep the first k-1 rows of every polynomial
+            check_launch(launch_copy_rows(e, in, static_cast<std::size_t>(k) * e.n, o,
+                                          static_cast<std::size_t>(k - 1) * e.n, count * size, static_cast<int>(k - 1)),
+                         "mod_switch_drop");
+    });
+}
+
+long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                       size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (e.scheme != 2)
+            throw std::invalid_argument("unsupported operation for scheme type"); // evaluator.cpp:1108-1109
+        op_mod_switch_scale(e, static_cast<int>(k), reinterpret_cast<const u64 *>(ct), static_cast<int>(size), count,
+                            reinterpret_cast<u64 *>(out));
+    });
+}
+
+long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *ct, size_t count,
+                                    uint32_t galois_elt, const sealhip_kswitch_key *galois_key)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(galois_key);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_apply_galois(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), count, galois_elt, galois_key->key);
+    });
+}
+
+long sealhip_evaluator_transform_to_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    return guarded([&] { ntt_entry(ctx, ct, count * size, k, SEALHIP_BASE_Q, false, kNttCanonical); });
+}
+
+long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    return guarded([&] { ntt_entry(ctx, ct, count * size, k, SEALHIP_BASE_Q, true, kNttCanonical); });
+}
+
+} // extern "C"

@@ -1,0 +1,422 @@
+// engine.cpp -- context construction: regenerates every table/constant the hot path needs
+// (what SEALContext / ContextData / RNSTool / NTTTables hold in the reference:
+// native/src/seal/context.cpp:455-540, util/rns.cpp:539-729, util/ntt.cpp:37-99) and uploads it.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace sealhip
+{
+    namespace
+    {
+        template <class T>
+        T *upload(Engine &e, std::vector<void *> &owned, const T *host, std::size_t count)
+        {
+            T *dev = nullptr;
+            SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(T) * (count ? count : 1)));
+            owned.push_back(dev);
+            if (count)
+                SEALHIP_CHECK(hipMemcpy(dev, host, sizeof(T) * count, hipMemcpyHostToDevice));
+            (void)e;
+            return dev;
+        }
+
+        RowMap make_map(const std::vector<unsigned short> &ids)
+        {
+            RowMap m{};
+            if (ids.size() > static_cast<std::size_t>(kMaxRows))
+                throw std::invalid_argument("too many rows per polynomial");
+            m.rows = static_cast<int>(ids.size());
+            for (std::size_t i = 0; i < ids.size(); i++)
+                m.prime[i] = ids[i];
+            return m;
+        }
+    } // namespace
+
+    std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
+                                        bool strict, int device)
+    {
+        if (scheme != 1 && scheme != 2)
+            throw std::invalid_argument("unsupported scheme"); // evaluator.cpp:262-263
+        if (logn < 3 || logn > 16)
+            // SEAL_POLY_MOD_DEGREE_MAX = 65536 (util/defines.h:53); the fork's inverse NTT is only defined for
+            // N >= 8 (ntt.cpp:352-402)
+            throw std::invalid_argument("poly_modulus_degree is invalid");
+        if (n_key < 2 || n_key > kMaxModuli || nsp < 1 || n_key <= nsp)
+            throw std::invalid_argument("coeff_modulus / n_special_primes invalid"); // context.cpp:527-530
+        if (scheme == 1 && t < 2)
+            throw std::invalid_argument("plain_modulus is invalid");
+        auto e = std::make_unique<Engine>();
+        e->scheme = scheme;
+        e->logn = logn;
+        e->n = std::size_t(1) << logn;
+        e->n_key = n_key;
+        e->nsp = nsp;
+        e->k_first = n_key - nsp;
+        e->t = scheme == 1 ? t : 0;
+        e->mode_strict = strict;
+        e->device = device;
+        e->key_moduli.assign(key_moduli, key_moduli + n_key);
+        for (int i = 0; i < n_key; i++)
+        {
+            HostModulus check(e->key_moduli[i]); // range check
+            (void)check;
+            for (int j = 0; j < i; j++)
+                if (e->key_moduli[i] == e->key_moduli[j])
+                    throw std::invalid_argument("coeff_modulus primes must be distinct");
+        }
+        // auxiliary 60-bit primes for BEHZ (rns.cpp:587): m_sk, gamma, B_0, B_1, ...
+        if (scheme == 1)
+            e->aux_primes = get_primes(e->n, 60, static_cast<std::size_t>(n_key) + 3);
+        const int n_primes = n_key + static_cast<int>(e->aux_primes.size());
+        e->tables.resize(n_primes);
+        for (int i = 0; i < n_primes; i++)
+        {
+            const u64 p = i < n_key ? e->key_moduli[i] : e->aux_primes[i - n_key];
+            if (i == n_key + 1)
+            {
+                // gamma is never transformed; keep only its modulus
+                e->tables[i].logn = logn;
+                e->tables[i].p = p;
+                continue;
+            }
+            e->tables[i].build(logn, p);
+        }
+        if (device < 0)
+            return e;
+
+        SEALHIP_CHECK(hipSetDevice(device));
+        SEALHIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+        SEALHIP_CHECK(ntt_init_kernels());
+        std::vector<PrimeDev> pd(n_primes);
+        for (int i = 0; i < n_primes; i++)
+        {
+            const HostNttTables &tb = e->tables[i];
+            HostModulus m(tb.p);
+            PrimeDev &d = pd[i];
+            d.p = tb.p;
+            d.two_p = tb.p << 1;
+            d.rdp = tb.rdp ? tb.rdp : shoup(1, tb.p);
+            d.cr0 = m.cr0;
+            d.cr1 = m.cr1;
+            d.inv_n = tb.inv_n;
+            d.inv_n_shoup = tb.inv_n_shoup;
+            d.inv_n_w = tb.inv_n_w;
+            d.inv_n_w_shoup = tb.inv_n_w_shoup;
+            d.fwd = tb.fwd.empty() ? nullptr : upload<u64>(*e, e->owned, tb.fwd.data(), tb.fwd.size());
+            d.inv = tb.inv.empty() ? nullptr : upload<u64>(*e, e->owned, tb.inv.data(), tb.inv.size());
+        }
+        e->d_primes = upload<PrimeDev>(*e, e->owned, pd.data(), pd.size());
+        return e;
+    }
+
+    void Engine::prof_begin(const char *tag, double units) const
+    {
+        ProfRecord r{ tag, nullptr, nullptr, units };
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
+            return;
+        (void)hipEventRecord(r.start, stream);
+        prof.push_back(r);
+    }
+
+    void Engine::prof_end() const
+    {
+        if (!prof.empty() && prof.back().stop)
+            (void)hipEventRecord(prof.back().stop, stream);
+    }
+
+    Engine::~Engine()
+    {
+        if (device < 0)
+            return;
+        (void)hipSetDevice(device);
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        for (auto &kv : levels)
+            for (void *p : kv.second->owned)
+                (void)hipFree(p);
+        for (auto &kv : galois_tables)
+            (void)hipFree(kv.second);
+        for (void *p : owned)
+            (void)hipFree(p);
+        if (ws)
+            (void)hipFree(ws);
+        if (own_stream && stream)
+            (void)hipStreamDestroy(stream);
+    }
+
+    LevelTools &Engine::level_host(int k)
+    {
+        if (k < 1 || k > n_key)
+            throw std::invalid_argument("level k out of range");
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = levels.find(k);
+        if (it != levels.end())
+            return *it->second;
+        auto lt = std::make_unique<LevelTools>();
+        std::vector<u64> q(key_moduli.begin(), key_moduli.begin() + k);
+        lt->host_rns = std::make_unique<HostRnsTool>();
+        if (scheme == 1)
+            lt->host_rns->build(n, q, t, aux_primes);
+        else
+        {
+            // CKKS: only inv_q_last_mod_q is used on the path (rns.cpp:719-728)
+            lt->host_rns->n = n;
+            lt->host_rns->q = q;
+            lt->host_rns->inv_q_last_mod_q.assign(k - 1, 0);
+            for (int i = 0; i + 1 < k; i++)
+                if (!invmod(q[k - 1], q[i], lt->host_rns->inv_q_last_mod_q[i]))
+                    throw std::logic_error("invalid rns bases");
+        }
+        // row maps
+        std::vector<unsigned short> ids_q, ids_bsk, ids_key, ids_qbsk;
+        for (int i = 0; i < k; i++)
+            ids_q.push_back(static_cast<unsigned short>(i));
+        ids_key = ids_q;
+        if (k <= k_first)
+            for (int j = 0; j < nsp; j++)
+                ids_key.push_back(static_cast<unsigned short>(k_first + j));
+        if (scheme == 1)
+        {
+            const std::size_t B = lt->host_rns->B_size;
+            for (std::size_t j = 0; j < B; j++)
+                ids_bsk.push_back(static_cast<unsigned short>(n_key + 2 + j));
+            ids_bsk.push_back(static_cast<unsigned short>(n_key)); // m_sk last (rns.cpp:600)
+        }
+        ids_qbsk = ids_q;
+        ids_qbsk.insert(ids_qbsk.end(), ids_bsk.begin(), ids_bsk.end());
+        lt->map_q = make_map(ids_q);
+        lt->map_bsk = make_map(ids_bsk);
+        lt->map_key = make_map(ids_key);
+        lt->map_qbsk = make_map(ids_qbsk);
+        auto &ref = *lt;
+        levels.emplace(k, std::move(lt));
+        return ref;
+    }
+
+    LevelTools &Engine::level(int k)
+    {
+        LevelTools &lt = level_host(k);
+        if (device < 0)
+            throw std::logic_error("host-only context: no device");
+        std::lock_guard<std::mutex> lock(mu);
+        if (lt.d_rns)
+            return lt;
+        SEALHIP_CHECK(hipSetDevice(device));
+        const HostRnsTool &hr = *lt.host_rns;
+        RnsDev rd{};
+        rd.k = k;
+        rd.t = t;
+        for (int i = 0; i < k; i++)
+            rd.q_prime[i] = static_cast<unsigned short>(i);
+        for (int i = 0; i + 1 < k; i++)
+            rd.inv_q_last_mod_q[i] = hr.inv_q_last_mod_q[i];
+        if (scheme == 1)
+        {
+            const int nB = static_cast<int>(hr.Bsk.size()), B = static_cast<int>(hr.B_size);
+            rd.nB = nB;
+            rd.B = B;
+            for (int i = 0; i < k; i++)
+            {
+                rd.q_inv[i] = hr.q_to_Bsk.inv_punct[i];
+                rd.q_mt_inv[i] = mulmod(hr.m_tilde % hr.q[i], hr.q_to_Bsk.inv_punct[i], hr.q[i]);
+                rd.q_to_mt[i] = hr.q_to_m_tilde.matrix[i];
+                rd.prod_B_mod_q[i] = hr.prod_B_mod_q[i];
+            }
+            rd.q_to_Bsk = upload<u64>(*this, lt.owned, hr.q_to_Bsk.matrix.data(), hr.q_to_Bsk.matrix.size());
+            rd.inv_prod_q_mod_mt = hr.inv_prod_q_mod_m_tilde;
+            for (int j = 0; j < nB; j++)
+            {
+                rd.prod_q_mod_Bsk[j] = hr.prod_q_mod_Bsk[j];
+                rd.inv_prod_q_mod_Bsk[j] = hr.inv_prod_q_mod_Bsk[j];
+                rd.inv_mt_mod_Bsk[j] = hr.inv_m_tilde_mod_Bsk[j];
+                rd.bsk_prime[j] = lt.map_bsk.prime[j];
+            }
+            for (int i = 0; i < B; i++)
+            {
+                rd.B_inv[i] = hr.B_to_q.inv_punct[i];
+                rd.B_to_msk[i] = hr.B_to_m_sk.matrix[i];
+            }
+            rd.B_to_q = upload<u64>(*this, lt.owned, hr.B_to_q.matrix.data(), hr.B_to_q.matrix.size());
+            rd.inv_prod_B_mod_msk = hr.inv_prod_B_mod_m_sk;
+        }
+        lt.h_rns = rd;
+        lt.d_rns = upload<RnsDev>(*this, lt.owned, &rd, 1);
+
+        // ---- key-switch constants (only for ciphertext levels) ----
+        if (k <= k_first)
+        {
+            KsDev kd{};
+            kd.k = k;
+            kd.nsp = nsp;
+            kd.nd = (k + nsp - 1) / nsp;
+            kd.n_all = k_first;
+            kd.n_total = n_key;
+            kd.is_ckks = scheme == 2;
+            kd.strict = mode_strict;
+            const int rows = k + nsp;
+            for (int r = 0; r < rows; r++)
+                kd.row_prime[r] = static_cast<unsigned short>(r < k ? r : k_first + (r - k));
+            auto prime_of = [&](int r) { return key_moduli[kd.row_prime[r]]; };
+            // mod-up (multi_special_primes.cpp:110-126)
+            const std::size_t blk = static_cast<std::size_t>(2 * nsp + rows * nsp);
+            std::vector<u64> modup(blk * kd.nd, 0);
+            for (int j = 0; j < kd.nd; j++)
+            {
+                const int r0 = j * nsp, r1 = std::min(r0 + nsp, k), bs = r1 - r0;
+                u64 *b = modup.data() + blk * j;
+                for (int a = 0; a < bs; a++)
+                {
+                    const u64 pa = prime_of(r0 + a);
+                    u64 inv_prod = 1 % pa;
+                    for (int c = 0; c < bs; c++)
+                        if (c != a)
+                            inv_prod = mulmod(inv_prod, prime_of(r0 + c) % pa, pa);
+                    u64 inv = 1;
+                    if (bs > 1 && !invmod(inv_prod, pa, inv))
+                        throw std::logic_error("modup: inverse does not exist");
+                    b[a] = inv;
+                    b[nsp + a] = shoup(inv, pa);
+                    for (int r = 0; r < rows; r++)
+                    {
+                        if (r >= r0 && r < r1)
+                            continue;
+                        const u64 pd = prime_of(r);
+                        u64 prod = 1 % pd;
+                        for (int c = 0; c < bs; c++)
+                            if (c != a)
+                                prod = mulmod(prod, prime_of(r0 + c) % pd, pd);
+                        b[2 * nsp + r * nsp + a] = prod;
+                    }
+                }
+            }
+            kd.modup = upload<u64>(*this, lt.owned, modup.data(), modup.size());
+            // mod-down (multi_special_primes.cpp:186-234, :292-299)
+            std::vector<u64> neg_hat(static_cast<std::size_t>(k) * nsp, 0);
+            for (int j = 0; j < nsp; j++)
+            {
+                const u64 pj = key_moduli[k_first + j];
+                u64 prod = 1 % pj;
+                for (int l = 0; l < nsp; l++)
+                    if (l != j)
+                        prod = mulmod(prod, key_moduli[k_first + l] % pj, pj);
+                u64 inv = 1;
+                if (nsp > 1 && !invmod(prod, pj, inv))
+                    throw std::logic_error("moddown: inverse does not exist");
+                kd.inv_hat[j] = inv;
+                kd.inv_hat_shoup[j] = shoup(inv, pj);
+            }
+            for (int i = 0; i < k; i++)
+            {
+                const u64 qi = key_moduli[i];
+                u64 P = 1 % qi;
+                for (int j = 0; j < nsp; j++)
+                {
+                    P = mulmod(P, key_moduli[k_first + j] % qi, qi);
+                    u64 prod = 1 % qi;
+                    for (int l = 0; l < nsp; l++)
+                        if (l != j)
+                            prod = mulmod(prod, key_moduli[k_first + l] % qi, qi);
+                    neg_hat[static_cast<std::size_t>(i) * nsp + j] = prod ? qi - prod : 0;
+                }
+                u64 invP;
+                if (!invmod(P, qi, invP))
+                    throw std::logic_error("moddown: inverse does not exist");
+                kd.invP[i] = invP;
+                kd.invP_shoup[i] = shoup(invP, qi);
+            }
+            kd.neg_hat = upload<u64>(*this, lt.owned, neg_hat.data(), neg_hat.size());
+            lt.h_ks = kd;
+            lt.d_ks = upload<KsDev>(*this, lt.owned, &kd, 1);
+        }
+        return lt;
+    }
+
+    const std::uint32_t *Engine::galois_table(std::uint32_t elt)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = galois_tables.find(elt);
+        if (it != galois_tables.end())
+            return it->second;
+        // generate_table_ntt, galois.cpp:18-47
+        std::vector<std::uint32_t> tab(n);
+        const std::uint32_t nm1 = static_cast<std::uint32_t>(n) - 1;
+        for (std::size_t i = 0; i < n; i++)
+        {
+            const std::uint32_t reversed = reverse_bits(static_cast<std::uint32_t>(n + i), logn + 1);
+            std::uint64_t index_raw = (static_cast<std::uint64_t>(elt) * reversed) >> 1;
+            index_raw &= nm1;
+            tab[i] = reverse_bits(static_cast<std::uint32_t>(index_raw), logn);
+        }
+        SEALHIP_CHECK(hipSetDevice(device));
+        std::uint32_t *dev = nullptr;
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(std::uint32_t) * n));
+        SEALHIP_CHECK(hipMemcpy(dev, tab.data(), sizeof(std::uint32_t) * n, hipMemcpyHostToDevice));
+        galois_tables.emplace(elt, dev);
+        return dev;
+    }
+
+    void Engine::ws_reserve(std::size_t bytes)
+    {
+        if (bytes <= ws_bytes)
+            return;
+        SEALHIP_CHECK(hipSetDevice(device));
+        if (ws)
+        {
+            SEALHIP_CHECK(hipStreamSynchronize(stream));
+            SEALHIP_CHECK(hipFree(ws));
+            ws = nullptr;
+            ws_bytes = 0;
+        }
+        SEALHIP_CHECK(hipMalloc(&ws, bytes));
+        ws_bytes = bytes;
+    }
+
+    u64 *Engine::ws_alloc(std::size_t words)
+    {
+        const std::size_t bytes = (words * sizeof(u64) + 255) & ~static_cast<std::size_t>(255);
+        if (ws_used + bytes > ws_bytes)
+            throw std::logic_error("internal: workspace overflow");
+        u64 *p = reinterpret_cast<u64 *>(static_cast<char *>(ws) + ws_used);
+        ws_used += bytes;
+        return p;
+    }
+
+    int Engine::rows_for(int k, unsigned base)
+    {
+        LevelTools &lt = level_host(k);
+        switch (base)
+        {
+        case 0:
+            return lt.map_q.rows;
+        case 1:
+            return lt.map_bsk.rows;
+        case 2:
+            return lt.map_key.rows;
+        default:
+            throw std::invalid_argument("unknown base");
+        }
+    }
+
+    RowMap Engine::map_for(int k, unsigned base)
+    {
+        LevelTools &lt = level_host(k);
+        switch (base)
+        {
+        case 0:
+            return lt.map_q;
+        case 1:
+            if (scheme != 1)
+                throw std::invalid_argument("base Bsk exists only for BFV");
+            return lt.map_bsk;
+        case 2:
+            if (k > k_first)
+                throw std::invalid_argument("key base needs a ciphertext level");
+            return lt.map_key;
+        default:
+            throw std::invalid_argument("unknown base");
+        }
+    }
+} // namespace sealhip

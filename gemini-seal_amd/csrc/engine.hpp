@@ -1,0 +1,268 @@
+// engine.hpp -- internal interfaces of the sealhip engine (context, device tables, kernel launchers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "devmath.hpp"
+#include "hostmath.hpp"
+
+namespace sealhip
+{
+    constexpr int kMaxRows = 136;          // rows of one "polynomial" a launch can describe
+    constexpr int kMaxModuli = 64;         // SEAL_COEFF_MOD_COUNT_MAX (util/defines.h:48)
+    constexpr unsigned short kSkipRow = 0xFFFF;
+
+    // Which prime each row of a polynomial uses (index into Engine::d_primes); kSkipRow = leave untouched.
+    struct RowMap
+    {
+        int rows;
+        unsigned short prime[kMaxRows];
+    };
+
+    constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
+    constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
+
+    struct NttRound
+    {
+        int beta, wlo, whi;
+    };
+    struct NttPass
+    {
+        int logn, t, c, b_lo, flags, nrounds;
+        NttRound rounds[4];
+    };
+    struct NttPlan
+    {
+        int logn, npass, flags;
+        bool serial;
+        NttPass pass[2];
+    };
+    NttPlan plan_ntt(int logn, bool inverse, int flags);
+
+    // ---- device-resident constants of one BFV level (RNSTool, rns.cpp:539-729) ----
+    struct RnsDev
+    {
+        int k, nB, B;               // |q|, |Bsk|, |B|
+        u64 t;                      // plain modulus
+        // q -> Bsk U {m_tilde}
+        u64 q_mt_inv[kMaxModuli];   // m_tilde * (q^_i)^{-1} mod q_i   (fused multiply_poly_scalar + inv_punctured)
+        u64 q_inv[kMaxModuli];      // (q^_i)^{-1} mod q_i
+        const u64 *q_to_Bsk;        // [nB][k]
+        u64 q_to_mt[kMaxModuli];    // [k] mod 2^32
+        u64 inv_prod_q_mod_mt;      // mod 2^32
+        // per Bsk prime
+        u64 prod_q_mod_Bsk[kMaxModuli + 2], inv_prod_q_mod_Bsk[kMaxModuli + 2], inv_mt_mod_Bsk[kMaxModuli + 2];
+        // B -> q, B -> m_sk
+        u64 B_inv[kMaxModuli + 1];  // (B^_i)^{-1} mod B_i
+        const u64 *B_to_q;          // [k][B]
+        u64 B_to_msk[kMaxModuli + 1];
+        u64 inv_prod_B_mod_msk;
+        u64 prod_B_mod_q[kMaxModuli];
+        u64 inv_q_last_mod_q[kMaxModuli];
+        unsigned short q_prime[kMaxModuli];       // prime ids of q rows
+        unsigned short bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
+    };
+
+    // ---- device-resident constants of the hybrid key switch at level k (multi_special_primes.cpp) ----
+    struct KsDev
+    {
+        int k, nsp, nd, n_all, n_total; // ct primes, special primes, digits at this level, first-level k, key primes
+        int is_ckks, strict;
+        unsigned short row_prime[kMaxModuli]; // prime id of ext row r (r < k: r; r >= k: n_all + r - k)
+        // mod-up: for bundle j, element a (source row j*nsp+a): inv_punch and its shoup; punch[dst row][a]
+        const u64 *modup; // layout: [nd][ (2*nsp) + rows*nsp ] see engine.cpp
+        // mod-down
+        u64 inv_hat[kMaxModuli], inv_hat_shoup[kMaxModuli]; // [nsp]  p^_j^{-1} mod p_j
+        const u64 *neg_hat;                                  // [k][nsp]  -p^_j mod q_i
+        u64 invP[kMaxModuli], invP_shoup[kMaxModuli];        // [k]  P^{-1} mod q_i
+    };
+
+    struct LevelTools
+    {
+        std::unique_ptr<HostRnsTool> host_rns; // BFV + CKKS (CKKS only uses inv_q_last_mod_q)
+        RnsDev *d_rns = nullptr;
+        KsDev *d_ks = nullptr;
+        KsDev h_ks{};
+        RnsDev h_rns{};
+        std::vector<void *> owned; // device allocations to free
+        RowMap map_q{}, map_bsk{}, map_key{}, map_qbsk{};
+    };
+
+    struct KSwitchKey
+    {
+        u64 *d_data = nullptr;
+        std::uint32_t n_digits = 0;
+        std::size_t words = 0;
+    };
+
+    // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline line).
+    struct ProfRecord
+    {
+        const char *tag;
+        hipEvent_t start, stop;
+        double units; // rows (NTT passes) or lanes processed by the launch
+    };
+
+    struct Engine
+    {
+        // parameters
+        int scheme = 0, logn = 0, n_key = 0, nsp = 0, k_first = 0;
+        std::size_t n = 0;
+        u64 t = 0;
+        bool mode_strict = false;
+        int device = -1; // -1: host-only
+        std::vector<u64> key_moduli, aux_primes;
+        std::vector<HostNttTables> tables; // per prime id
+        // device
+        hipStream_t stream = nullptr;
+        bool own_stream = false;
+        PrimeDev *d_primes = nullptr;
+        std::vector<void *> owned;
+        std::map<int, std::unique_ptr<LevelTools>> levels;
+        std::map<std::uint32_t, std::uint32_t *> galois_tables; // elt -> device table (galois.cpp:18-47)
+        std::mutex mu;
+        // profiler
+        mutable bool prof_on = false;
+        mutable std::vector<ProfRecord> prof;
+        void prof_begin(const char *tag, double units) const;
+        void prof_end() const;
+        // workspace arena (stream-ordered reuse)
+        void *ws = nullptr;
+        std::size_t ws_bytes = 0, ws_used = 0;
+
+        ~Engine();
+        int n_primes() const
+        {
+            return static_cast<int>(tables.size());
+        }
+        LevelTools &level(int k);       // builds host + device constants on first use
+        LevelTools &level_host(int k);  // host constants only
+        const std::uint32_t *galois_table(std::uint32_t elt);
+        void ws_reset()
+        {
+            ws_used = 0;
+        }
+        u64 *ws_alloc(std::size_t words);
+        void ws_reserve(std::size_t bytes);
+        RowMap map_for(int k, unsigned base);
+        int rows_for(int k, unsigned base);
+    };
+
+    struct HipError : std::runtime_error
+    {
+        hipError_t code;
+        HipError(hipError_t c, const char *what) : std::runtime_error(what), code(c)
+        {}
+    };
+#define SEALHIP_CHECK(expr)                                                                          \
+    do                                                                                               \
+    {                                                                                                \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            throw ::sealhip::HipError(_e, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+    } while (0)
+
+    struct ProfScope
+    {
+        const Engine &e;
+        ProfScope(const Engine &eng, const char *tag, double units) : e(eng)
+        {
+            if (e.prof_on)
+                e.prof_begin(tag, units);
+        }
+        ~ProfScope()
+        {
+            if (e.prof_on)
+                e.prof_end();
+        }
+    };
+
+    // ---- launchers (each enqueues on e.stream) ----
+    hipError_t ntt_init_kernels();
+    hipError_t launch_ntt(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, bool inverse, int flags);
+
+    enum class PolyOp
+    {
+        Dyadic,
+        Add,
+        Sub,
+        Negate,
+        Scalar
+    };
+    hipError_t launch_poly_op(const Engine &e, PolyOp op, const u64 *a, const u64 *b, u64 scalar, u64 *r,
+                              std::size_t nrows, const RowMap &map);
+    // out[I] = sum_{i1+i2=I} a[i1] (.) b[i2]  over rows of `map` (evaluator.cpp:376-420 / 493-520)
+    hipError_t launch_tensor_product(const Engine &e, const u64 *a, int sa, std::size_t a_stride, const u64 *b, int sb,
+                                     std::size_t b_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                     const RowMap &map);
+    hipError_t launch_copy_rows(const Engine &e, const u64 *src, std::size_t src_poly_stride, u64 *dst,
+                                std::size_t dst_poly_stride, std::size_t npolys, int rows);
+
+    // RNSTool kernels; item strides are in words
+    hipError_t launch_fastbconv_m_tilde(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                        std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count);
+    hipError_t launch_sm_mrq(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
+                             u64 *out, std::size_t out_stride, std::size_t count);
+    // fused fastbconv_m_tilde + sm_mrq: in k rows -> out |Bsk| rows
+    hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
+                               u64 *out, std::size_t out_stride, std::size_t count);
+    hipError_t launch_fast_floor(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                 std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                 int mul_t);
+    hipError_t launch_fastbconv_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count);
+    // fused (x t) + fast_floor + fastbconv_sk: in (k+|Bsk|) rows -> out k rows
+    hipError_t launch_bfv_floor_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count);
+    hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                   int out_rows);
+    // `last` points at the (inverse-transformed) last row of item 0; items are last_stride words apart
+    hipError_t launch_rescale_pre(const Engine &e, const RnsDev *d, const RnsDev &h, u64 *last,
+                                  std::size_t last_stride, u64 *temp, std::size_t temp_stride, std::size_t count);
+    hipError_t launch_rescale_post(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, const u64 *temp, std::size_t temp_stride, u64 *out,
+                                   std::size_t out_stride, std::size_t count);
+
+    // Galois
+    hipError_t launch_galois(const Engine &e, const u64 *in, u64 *out, std::size_t nrows, const RowMap &map,
+                             std::uint32_t elt, const std::uint32_t *table /* null: coefficient form */);
+
+    // key switch
+    // ext is digit-major: ext + j*ext_digit_stride + item*ext_stride + r*N
+    hipError_t launch_ks_modup(const Engine &e, const KsDev *d, const KsDev &h, const u64 *coeff,
+                               std::size_t coeff_stride, u64 *ext, std::size_t ext_stride,
+                               std::size_t ext_digit_stride, std::size_t count, int only_digit);
+    hipError_t launch_ks_mac(const Engine &e, const KsDev *d, const KsDev &h, const u64 *target,
+                             std::size_t target_stride, const u64 *ext, std::size_t ext_stride,
+                             std::size_t ext_digit_stride, const u64 *key, u64 *prod, std::size_t prod_stride,
+                             std::size_t count);
+    hipError_t launch_ks_moddown_pre(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
+                                     std::size_t prod_stride, u64 *temp, std::size_t temp_stride, std::size_t npolys);
+    hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
+                                      std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
+                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct);
+
+    // ---- composed operations (pipeline.cpp) ----
+    void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
+                       std::size_t count, const KSwitchKey &key);
+    void op_modup(Engine &e, int k, int bundle, u64 *ext, std::size_t count);
+    void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
+    void op_ckks_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
+    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out);
+    void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count);
+    void op_rescale_special_inplace(Engine &e, int k, u64 *poly, std::size_t count);
+    void op_apply_galois(Engine &e, int k, u64 *ct, std::size_t count, std::uint32_t elt, const KSwitchKey &key);
+
+    std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
+                                        bool strict, int device);
+} // namespace sealhip

@@ -1,0 +1,285 @@
+// keyswitch.hip -- column-parallel kernels of the hybrid (multi-special-prime) key switch:
+// modup_rns / modup_to_single_rns (native/src/seal/multi_special_primes.cpp:80-185), the 128-bit
+// inner product against the key (native/src/seal/evaluator.cpp:2315-2357) and
+// rescale_special_rns_inplace (multi_special_primes.cpp:237-304).
+//
+// The reference recomputes the punctured products and inverses on every call
+// (multi_special_primes.cpp:110-126, :244-248, :292-299); here they are context constants (KsDev).
+// The reference also keeps two (k+nsp) x N arrays of 128-bit accumulators in memory across the digit
+// loop; here one lane owns one (row, coefficient) and keeps both accumulators in registers across
+// all digits, streaming the key slices.
+#include "engine.hpp"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr int kThreads = 256;
+
+        // modup constants of digit j: [inv_punch(nsp) | inv_punch_shoup(nsp) | punch[rows][nsp]]
+        __device__ __forceinline__ const u64 *modup_block(const KsDev *d, int j)
+        {
+            const int rows = d->k + d->nsp;
+            return d->modup + static_cast<std::size_t>(j) * (2 * d->nsp + rows * d->nsp);
+        }
+
+        // For every digit j (or only `only_digit`): read the bundle's coefficient-form rows and write every
+        // row outside the bundle of ext[item][j].
+        __global__ __launch_bounds__(kThreads) void ks_modup_kernel(const KsDev *__restrict__ d,
+                                                                    const PrimeDev *__restrict__ primes,
+                                                                    const u64 *__restrict__ coeff,
+                                                                    std::size_t coeff_stride, u64 *__restrict__ ext,
+                                                                    std::size_t ext_stride,
+                                                                    std::size_t ext_digit_stride, std::size_t count,
+                                                                    int logn, int only_digit)
+        {
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t item = i >> logn;
+            if (item >= count)
+                return;
+            const std::size_t c = i & ((static_cast<std::size_t>(1) << logn) - 1);
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const int k = d->k, nsp = d->nsp, rows = k + nsp;
+            const u64 *src = coeff + item * coeff_stride + c;
+            const int j_begin = only_digit >= 0 ? only_digit : 0;
+            const int j_end = only_digit >= 0 ? only_digit + 1 : d->nd;
+            for (int j = j_begin; j < j_end; j++)
+            {
+                const int r0 = j * nsp;
+                const int r1 = r0 + nsp < k ? r0 + nsp : k;
+                const int bs = r1 - r0;
+                u64 *dst = ext + item * ext_stride + static_cast<std::size_t>(j) * ext_digit_stride + c;
+                if (bs == 1)
+                {
+                    // multi_special_primes.cpp:99-108
+                    const u64 x = src[r0 * N];
+                    const u64 psrc = primes[d->row_prime[r0]].p;
+                    for (int r = 0; r < rows; r++)
+                    {
+                        if (r == r0)
+                            continue;
+                        const PrimeDev &D = primes[d->row_prime[r]];
+                        dst[r * N] = psrc <= D.p ? x : barrett_reduce_63(x, D.p, D.cr1);
+                    }
+                    continue;
+                }
+                const u64 *blk = modup_block(d, j);
+                u64 y[kMaxModuli > 8 ? 8 : kMaxModuli]; // bundles wider than 8 fall back to recomputation
+                const bool cached = bs <= 8;
+                if (cached)
+                {
+#pragma unroll
+                    for (int a = 0; a < 8; a++)
+                        if (a < bs)
+                        {
+                            const u64 p = primes[d->row_prime[r0 + a]].p;
+                            y[a] = mulmod_shoup(src[(r0 + a) * N], blk[a], blk[nsp + a], p); // :135-139
+                        }
+                }
+                for (int r = 0; r < rows; r++)
+                {
+                    if (r >= r0 && r < r1)
+                        continue;
+                    const PrimeDev &D = primes[d->row_prime[r]];
+                    const u64 *punch = blk + 2 * nsp + r * nsp;
+                    u64 lo = 0, hi = 0;
+                    if (cached)
+                    {
+#pragma unroll
+                        for (int a = 0; a < 8; a++)
+                            if (a < bs)
+                                mac128(lo, hi, y[a], punch[a]);
+                    }
+                    else
+                    {
+                        for (int a = 0; a < bs; a++)
+                        {
+                            const u64 p = primes[d->row_prime[r0 + a]].p;
+                            mac128(lo, hi, mulmod_shoup(src[(r0 + a) * N], blk[a], blk[nsp + a], p), punch[a]);
+                        }
+                    }
+                    dst[r * N] = barrett_reduce_128(lo, hi, D.p, D.cr0, D.cr1); // :143-146
+                }
+            }
+        }
+
+        // prod[item][l][r][c] = barrett_reduce_128( sum_j ct_j[r][c] * key[j][l][row_prime[r]][c] )
+        // where ct_j = the (NTT-form) target row if r is in bundle j, else ext[j][item][r] (digit-major)
+        // (evaluator.cpp:2315-2349). One lane per (item, row, coefficient).
+        __global__ __launch_bounds__(kThreads) void ks_mac_kernel(const KsDev *__restrict__ d,
+                                                                  const PrimeDev *__restrict__ primes,
+                                                                  const u64 *__restrict__ target,
+                                                                  std::size_t target_stride,
+                                                                  const u64 *__restrict__ ext, std::size_t ext_stride,
+                                                                  std::size_t ext_digit_stride,
+                                                                  const u64 *__restrict__ key,
+                                                                  u64 *__restrict__ prod, std::size_t prod_stride,
+                                                                  std::size_t count, int logn)
+        {
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const int k = d->k, nsp = d->nsp, rows = k + nsp, nd = d->nd, n_total = d->n_total;
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t c = i & (N - 1);
+            const std::size_t rr = i >> logn;
+            const int r = static_cast<int>(rr % rows);
+            const std::size_t item = rr / rows;
+            if (item >= count)
+                return;
+            const int rns_idx = d->row_prime[r];
+            const int my_digit = r < k ? r / nsp : -1;
+            const u64 *pext = ext + item * ext_stride + static_cast<std::size_t>(r) * N + c;
+            const u64 *pkey = key + static_cast<std::size_t>(rns_idx) * N + c;
+            const std::size_t key_comp = static_cast<std::size_t>(n_total) * N;
+            u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+            for (int j = 0; j < nd; j++)
+            {
+                const u64 x = j == my_digit ? target[item * target_stride + static_cast<std::size_t>(r) * N + c]
+                                            : pext[static_cast<std::size_t>(j) * ext_digit_stride];
+                const u64 k0 = pkey[(2 * static_cast<std::size_t>(j)) * key_comp];
+                const u64 k1 = pkey[(2 * static_cast<std::size_t>(j) + 1) * key_comp];
+                mac128(lo0, hi0, x, k0);
+                mac128(lo1, hi1, x, k1);
+            }
+            const PrimeDev &P = primes[rns_idx];
+            u64 *pp = prod + item * prod_stride + static_cast<std::size_t>(r) * N + c;
+            pp[0] = barrett_reduce_128(lo0, hi0, P.p, P.cr0, P.cr1);
+            pp[static_cast<std::size_t>(rows) * N] = barrett_reduce_128(lo1, hi1, P.p, P.cr0, P.cr1);
+        }
+
+        // rescale_special_rns_inplace, steps 1-2 (multi_special_primes.cpp:253-282): from the (coefficient
+        // form) special rows of one polynomial compute temp_i for every ciphertext prime i.
+        __global__ __launch_bounds__(kThreads) void ks_moddown_pre_kernel(const KsDev *__restrict__ d,
+                                                                          const PrimeDev *__restrict__ primes,
+                                                                          const u64 *__restrict__ prod,
+                                                                          std::size_t prod_stride,
+                                                                          u64 *__restrict__ temp,
+                                                                          std::size_t temp_stride, std::size_t npolys,
+                                                                          int logn)
+        {
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t poly = i >> logn;
+            if (poly >= npolys)
+                return;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const std::size_t c = i & (N - 1);
+            const int k = d->k, nsp = d->nsp;
+            const u64 *sp = prod + poly * prod_stride + static_cast<std::size_t>(k) * N + c;
+            u64 *pt = temp + poly * temp_stride + c;
+            if (nsp == 1)
+            {
+                const PrimeDev &S = primes[d->row_prime[k]];
+                const u64 v = neg_mod(barrett_reduce_63(sp[0], S.p, S.cr1), S.p); // :270-273
+                for (int q = 0; q < k; q++)
+                {
+                    const PrimeDev &Q = primes[d->row_prime[q]];
+                    pt[q * N] = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
+                }
+                return;
+            }
+            for (int q = 0; q < k; q++)
+            {
+                const PrimeDev &Q = primes[d->row_prime[q]];
+                u64 lo = 0, hi = 0;
+                for (int j = 0; j < nsp; j++)
+                {
+                    const u64 pj = primes[d->row_prime[k + j]].p;
+                    const u64 y = mulmod_shoup(sp[j * N], d->inv_hat[j], d->inv_hat_shoup[j], pj); // :262-267
+                    mac128(lo, hi, y, d->neg_hat[q * nsp + j]);
+                }
+                pt[q * N] = barrett_reduce_128(lo, hi, Q.p, Q.cr0, Q.cr1);
+            }
+        }
+
+        // step 4 (multi_special_primes.cpp:291-302) + the final add_poly_coeffmod of evaluator.cpp:2363-2366
+        __global__ __launch_bounds__(kThreads) void ks_moddown_post_kernel(const KsDev *__restrict__ d,
+                                                                           const PrimeDev *__restrict__ primes,
+                                                                           u64 *__restrict__ prod,
+                                                                           std::size_t prod_stride,
+                                                                           const u64 *__restrict__ temp,
+                                                                           std::size_t temp_stride,
+                                                                           u64 *__restrict__ ct,
+                                                                           std::size_t ct_item_stride,
+                                                                           std::size_t npolys, int logn,
+                                                                           int add_into_ct)
+        {
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const int k = d->k;
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t c = i & (N - 1);
+            const std::size_t rr = i >> logn;
+            const int q = static_cast<int>(rr % k);
+            const std::size_t poly = rr / k;
+            if (poly >= npolys)
+                return;
+            const PrimeDev &Q = primes[d->row_prime[q]];
+            u64 *pp = prod + poly * prod_stride + static_cast<std::size_t>(q) * N + c;
+            const u64 v = mulmod_shoup(*pp + temp[poly * temp_stride + static_cast<std::size_t>(q) * N + c], d->invP[q],
+                                       d->invP_shoup[q], Q.p);
+            if (add_into_ct)
+            {
+                // polynomial `poly` is component (poly & 1) of ciphertext (poly >> 1)
+                u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
+                *pc = add_mod(v, *pc, Q.p);
+            }
+            else
+                *pp = v;
+        }
+
+        inline unsigned blocks_for(std::size_t lanes)
+        {
+            return static_cast<unsigned>((lanes + kThreads - 1) / kThreads);
+        }
+    } // namespace
+
+    hipError_t launch_ks_modup(const Engine &e, const KsDev *d, const KsDev &, const u64 *coeff,
+                               std::size_t coeff_stride, u64 *ext, std::size_t ext_stride,
+                               std::size_t ext_digit_stride, std::size_t count, int only_digit)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "ks_modup", 0);
+        ks_modup_kernel<<<blocks_for(count << e.logn), kThreads, 0, e.stream>>>(
+            d, e.d_primes, coeff, coeff_stride, ext, ext_stride, ext_digit_stride, count, e.logn, only_digit);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_ks_mac(const Engine &e, const KsDev *d, const KsDev &h, const u64 *target,
+                             std::size_t target_stride, const u64 *ext, std::size_t ext_stride,
+                             std::size_t ext_digit_stride, const u64 *key, u64 *prod, std::size_t prod_stride,
+                             std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        const u64 *tg = target;
+        const std::size_t lanes = (count * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
+        ProfScope prof(e, "ks_mac", 0);
+        ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
+                                                                    ext_digit_stride, key, prod, prod_stride, count,
+                                                                    e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_ks_moddown_pre(const Engine &e, const KsDev *d, const KsDev &, const u64 *prod,
+                                     std::size_t prod_stride, u64 *temp, std::size_t temp_stride, std::size_t npolys)
+    {
+        if (!npolys)
+            return hipSuccess;
+        ProfScope prof(e, "ks_moddown_pre", 0);
+        ks_moddown_pre_kernel<<<blocks_for(npolys << e.logn), kThreads, 0, e.stream>>>(
+            d, e.d_primes, prod, prod_stride, temp, temp_stride, npolys, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
+                                      std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
+                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct)
+    {
+        if (!npolys)
+            return hipSuccess;
+        const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
+        ProfScope prof(e, "ks_moddown_post", 0);
+        ks_moddown_post_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(
+            d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct);
+        return hipGetLastError();
+    }
+} // namespace sealhip

@@ -1,0 +1,340 @@
+// pipeline.cpp -- the Evaluator-level operations composed from the kernels: BFV/CKKS multiply
+// (native/src/seal/evaluator.cpp:274-527), hybrid key switch (:2259-2368), modulus switch / rescale
+// (:829-957) and apply_galois (:1841-1943), batched over independent ciphertexts. Large batches are
+// processed in chunks sized to the workspace arena; every chunk is a fixed sequence of launches on
+// one stream, so temporaries are reused in stream order without host synchronisation.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace sealhip
+{
+    namespace
+    {
+        std::size_t workspace_budget_bytes()
+        {
+            static const std::size_t budget = [] {
+                const char *env = std::getenv("SEALHIP_WORKSPACE_MB");
+                std::size_t mb = env ? static_cast<std::size_t>(std::strtoull(env, nullptr, 10)) : 8192;
+                if (mb < 64)
+                    mb = 64;
+                return mb << 20;
+            }();
+            return budget;
+        }
+
+        std::size_t pad256(std::size_t words)
+        {
+            return ((words * sizeof(u64) + 255) & ~static_cast<std::size_t>(255));
+        }
+
+        // how many items fit the arena, given the padded byte need of one item (sum over its buffers)
+        std::size_t plan_chunk(Engine &e, std::size_t count, std::size_t bytes_per_item, int n_buffers)
+        {
+            const std::size_t budget = workspace_budget_bytes();
+            std::size_t chunk = budget / (bytes_per_item ? bytes_per_item : 1);
+            chunk = std::max<std::size_t>(1, std::min(chunk, count));
+            e.ws_reserve(chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
+            return chunk;
+        }
+
+        void check(hipError_t err, const char *what)
+        {
+            if (err != hipSuccess)
+                throw HipError(err, (std::string(what) + ": " + hipGetErrorString(err)).c_str());
+        }
+
+        RowMap skip_map(const RowMap &base, int keep_lo, int keep_hi)
+        {
+            RowMap m = base;
+            for (int r = 0; r < m.rows; r++)
+                if (r < keep_lo || r >= keep_hi)
+                    m.prime[r] = kSkipRow;
+            return m;
+        }
+    } // namespace
+
+    // ------------------------------------------------------------------------------------------
+    // switch_key_inplace (evaluator.cpp:2259-2368)
+    // ------------------------------------------------------------------------------------------
+    void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
+                       std::size_t count, const KSwitchKey &key)
+    {
+        if (k > e.k_first)
+            throw std::invalid_argument("key switching needs a ciphertext level");
+        LevelTools &lt = e.level(k);
+        const KsDev &h = lt.h_ks;
+        if (static_cast<int>(key.n_digits) < h.nd)
+            throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        const std::size_t N = e.n;
+        const int rows = k + e.nsp, nd = h.nd;
+        const bool ckks = e.scheme == 2;
+        const bool strict_bfv = e.mode_strict && !ckks;
+        // per item words
+        const std::size_t w_coeff = (ckks || strict_bfv) ? static_cast<std::size_t>(k) * N : 0;
+        const std::size_t w_ext = static_cast<std::size_t>(nd) * rows * N;
+        const std::size_t w_prod = 2ull * rows * N;
+        const std::size_t w_temp = 2ull * k * N;
+        const std::size_t per_item = (w_coeff + w_ext + w_prod + w_temp) * sizeof(u64);
+        const std::size_t chunk = plan_chunk(e, count, per_item, 4);
+        const RowMap map_q = lt.map_q;
+        const RowMap map_rows = lt.map_key;
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *coeff = w_coeff ? e.ws_alloc(w_coeff * m) : nullptr;
+            u64 *ext = e.ws_alloc(w_ext * m);
+            u64 *prod = e.ws_alloc(w_prod * m);
+            u64 *temp = e.ws_alloc(w_temp * m);
+            const u64 *tg = target + off * target_stride;
+            u64 *ctp = ct + off * ct_stride;
+            const std::size_t ext_item = static_cast<std::size_t>(rows) * N;
+            const std::size_t ext_digit = ext_item * m; // digit-major
+
+            // Step 1 (:2302-2307): CKKS bundles go back to coefficient form (canonical inverse NTT)
+            const u64 *src = tg;
+            std::size_t src_stride = target_stride;
+            if (ckks)
+            {
+                check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
+                check(launch_ntt(e, coeff, m * k, map_q, true, kNttCanonical), "intt(target)");
+                src = coeff;
+                src_stride = static_cast<std::size_t>(k) * N;
+            }
+            // Step 2 (:2310): mod-up of every bundle
+            check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
+            // Step 3a (:2322): lazy forward NTT of every row outside the bundle, per digit
+            for (int j = 0; j < nd; j++)
+            {
+                RowMap mj = map_rows;
+                const int r0 = j * e.nsp, r1 = std::min(r0 + e.nsp, k);
+                for (int r = r0; r < r1; r++)
+                    mj.prime[r] = kSkipRow;
+                check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
+            }
+            // in-bundle rows: the reference multiplies the target rows as they are (:2319-2320);
+            // STRICT transforms the coefficient-form BFV rows first
+            const u64 *inb = tg;
+            std::size_t inb_stride = target_stride;
+            if (strict_bfv)
+            {
+                check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
+                check(launch_ntt(e, coeff, m * k, map_q, false, 0), "ntt(target)");
+                inb = coeff;
+                inb_stride = static_cast<std::size_t>(k) * N;
+            }
+            // Step 3b + 4 (:2326-2349): 128-bit inner product over the digits, reduced
+            check(launch_ks_mac(e, lt.d_ks, h, inb, inb_stride, ext, ext_item, ext_digit, key.d_data, prod, w_prod, m),
+                  "mac");
+            // (:2351-2355) special rows back to coefficient form (lazy)
+            check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, 0), "intt(special)");
+            // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
+            check(launch_ks_moddown_pre(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, 2 * m),
+                  "moddown_pre");
+            if (ckks)
+                check(launch_ntt(e, temp, m * 2 * k, map_q, false, 0), "ntt(temp)");
+            else
+                check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, 0), "intt(prod)");
+            check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
+                                         ct_stride, 2 * m, 1),
+                  "moddown_post");
+        }
+    }
+
+    // modup_rns as a standalone operation (multi_special_primes.cpp:151-185)
+    void op_modup(Engine &e, int k, int bundle, u64 *ext, std::size_t count)
+    {
+        LevelTools &lt = e.level(k);
+        if (k > e.k_first || bundle < 0 || bundle >= lt.h_ks.nd)
+            throw std::invalid_argument("modup_rns: src_bundle_index out of bound");
+        const std::size_t stride = static_cast<std::size_t>(k + e.nsp) * e.n;
+        check(launch_ks_modup(e, lt.d_ks, lt.h_ks, ext, stride, ext, stride, 0, count, bundle), "modup");
+    }
+
+    // rescale_special_rns_inplace as a standalone operation (multi_special_primes.cpp:237-304)
+    void op_rescale_special_inplace(Engine &e, int k, u64 *poly, std::size_t count)
+    {
+        if (k > e.k_first)
+            throw std::invalid_argument("rescale_special needs a ciphertext level");
+        LevelTools &lt = e.level(k);
+        const std::size_t N = e.n;
+        const int rows = k + e.nsp;
+        const std::size_t per_item = static_cast<std::size_t>(k) * N * sizeof(u64);
+        const std::size_t chunk = plan_chunk(e, count, per_item, 1);
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *temp = e.ws_alloc(static_cast<std::size_t>(k) * N * m);
+            u64 *p = poly + off * rows * N;
+            check(launch_ks_moddown_pre(e, lt.d_ks, lt.h_ks, p, static_cast<std::size_t>(rows) * N, temp,
+                                        static_cast<std::size_t>(k) * N, m),
+                  "moddown_pre");
+            if (e.scheme == 2)
+                check(launch_ntt(e, temp, m * k, lt.map_q, false, 0), "ntt(temp)");
+            else
+                check(launch_ntt(e, p, m * rows, skip_map(lt.map_key, 0, k), true, 0), "intt(poly)");
+            check(launch_ks_moddown_post(e, lt.d_ks, lt.h_ks, p, static_cast<std::size_t>(rows) * N, temp,
+                                         static_cast<std::size_t>(k) * N, nullptr, 0, m, 0),
+                  "moddown_post");
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // bfv_multiply (evaluator.cpp:274-445)
+    // ------------------------------------------------------------------------------------------
+    void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out)
+    {
+        LevelTools &lt = e.level(k);
+        const RnsDev &h = lt.h_rns;
+        const std::size_t N = e.n;
+        const int nB = h.nB, kb = k + nB, sin = sa + sb, dest = sa + sb - 1;
+        const std::size_t w_x = static_cast<std::size_t>(sin) * kb * N;
+        const std::size_t w_d = static_cast<std::size_t>(dest) * kb * N;
+        const std::size_t chunk = plan_chunk(e, count, (w_x + w_d) * sizeof(u64), 2);
+        const std::size_t poly_q = static_cast<std::size_t>(k) * N, poly_x = static_cast<std::size_t>(kb) * N;
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *X = e.ws_alloc(w_x * m);
+            u64 *D = e.ws_alloc(w_d * m);
+            // steps (1)-(3) (:335-353): copy the q rows, lift to Bsk (fastbconv_m_tilde + sm_mrq), one lazy NTT
+            for (int s = 0; s < sin; s++)
+            {
+                const bool first = s < sa;
+                const u64 *src = first ? a + off * sa * poly_q + s * poly_q : b + off * sb * poly_q + (s - sa) * poly_q;
+                const std::size_t src_stride = (first ? sa : sb) * poly_q;
+                u64 *dst = X + s * poly_x;
+                check(launch_copy_rows(e, src, src_stride, dst, w_x, m, k), "copy");
+                check(launch_bfv_lift(e, lt.d_rns, h, src, src_stride, dst + poly_q, w_x, m), "bfv_lift");
+            }
+            check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
+            // step (4) (:376-420)
+            check(launch_tensor_product(e, X, sa, w_x, X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
+            // step (5) (:423-424)
+            check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, kNttCanonical), "intt(D)");
+            // steps (6)-(8) (:427-444)
+            for (int I = 0; I < dest; I++)
+                check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
+                                          dest * poly_q, m),
+                      "floor_sk");
+        }
+    }
+
+    // ckks_multiply (evaluator.cpp:447-527)
+    void op_ckks_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out)
+    {
+        LevelTools &lt = e.level(k);
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        check(launch_tensor_product(e, a, sa, sa * poly, b, sb, sb * poly, out, (sa + sb - 1) * poly, count, lt.map_q),
+              "tensor");
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // mod_switch_scale_to_next (evaluator.cpp:829-892): BFV mod_switch_to_next / CKKS rescale_to_next
+    // ------------------------------------------------------------------------------------------
+    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out)
+    {
+        if (k < 2)
+            throw std::invalid_argument("end of modulus switching chain reached"); // evaluator.cpp:1005-1008
+        LevelTools &lt = e.level(k);
+        const std::size_t N = e.n, npolys = count * size;
+        const std::size_t in_stride = static_cast<std::size_t>(k) * N, out_stride = static_cast<std::size_t>(k - 1) * N;
+        if (e.scheme == 1)
+        {
+            check(launch_divround_bfv(e, lt.d_rns, lt.h_rns, ct, in_stride, out, out_stride, npolys, k - 1), "divround");
+            return;
+        }
+        // CKKS (rns.cpp:777-851), without the reference's full copy of the ciphertext: only the last row is
+        // duplicated because only it is modified
+        const std::size_t per_poly = (N + static_cast<std::size_t>(k - 1) * N) * sizeof(u64);
+        const std::size_t chunk = plan_chunk(e, npolys, per_poly, 2);
+        const RowMap map_low = e.level_host(k - 1).map_q;
+        for (std::size_t off = 0; off < npolys; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, npolys - off);
+            e.ws_reset();
+            u64 *last = e.ws_alloc(N * m);
+            u64 *temp = e.ws_alloc(out_stride * m);
+            check(launch_copy_rows(e, ct + off * in_stride + static_cast<std::size_t>(k - 1) * N, in_stride, last, N, m, 1),
+                  "copy(last)");
+            RowMap one{};
+            one.rows = 1;
+            one.prime[0] = static_cast<unsigned short>(k - 1);
+            check(launch_ntt(e, last, m, one, true, kNttCanonical), "intt(last)");
+            check(launch_rescale_pre(e, lt.d_rns, lt.h_rns, last, N, temp, out_stride, m), "rescale_pre");
+            check(launch_ntt(e, temp, m * (k - 1), map_low, false, 0), "ntt(temp)");
+            check(launch_rescale_post(e, lt.d_rns, lt.h_rns, ct + off * in_stride, in_stride, temp, out_stride,
+                                      out + off * out_stride, out_stride, m),
+                  "rescale_post");
+        }
+    }
+
+    // divide_and_round_q_last_ntt_inplace (rns.cpp:777-851), in place like the reference (last row clobbered)
+    void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count)
+    {
+        if (k < 2)
+            throw std::invalid_argument("divide_and_round_q_last needs at least two primes");
+        LevelTools &lt = e.level(k);
+        const std::size_t N = e.n;
+        const std::size_t stride = static_cast<std::size_t>(k) * N, tstride = static_cast<std::size_t>(k - 1) * N;
+        const std::size_t chunk = plan_chunk(e, count, tstride * sizeof(u64), 1);
+        const RowMap map_low = e.level_host(k - 1).map_q;
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *temp = e.ws_alloc(tstride * m);
+            u64 *p = data + off * stride;
+            check(launch_ntt(e, p, m * k, skip_map(lt.map_q, k - 1, k), true, kNttCanonical), "intt(last)");
+            check(launch_rescale_pre(e, lt.d_rns, lt.h_rns, p + static_cast<std::size_t>(k - 1) * N, stride, temp,
+                                     tstride, m),
+                  "rescale_pre");
+            check(launch_ntt(e, temp, m * (k - 1), map_low, false, 0), "ntt(temp)");
+            check(launch_rescale_post(e, lt.d_rns, lt.h_rns, p, stride, temp, tstride, p, stride, m), "rescale_post");
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // apply_galois_inplace (evaluator.cpp:1841-1943)
+    // ------------------------------------------------------------------------------------------
+    void op_apply_galois(Engine &e, int k, u64 *ct, std::size_t count, std::uint32_t elt, const KSwitchKey &key)
+    {
+        const std::uint64_t m2 = static_cast<std::uint64_t>(e.n) * 2;
+        if (!(elt & 1) || elt >= m2)
+            throw std::invalid_argument("Galois element is not valid"); // :1880-1883
+        LevelTools &lt = e.level(k);
+        const std::size_t N = e.n, poly = static_cast<std::size_t>(k) * N;
+        const std::uint32_t *table = e.scheme == 2 ? e.galois_table(elt) : nullptr;
+        // the Galois image of both components needs count * 2 polys of scratch *outside* the arena that
+        // op_switch_key re-plans, so it is carved from the front of the arena after reserving both needs
+        const std::size_t per_item = 2 * poly * sizeof(u64);
+        const std::size_t budget_items = std::max<std::size_t>(1, std::min<std::size_t>(count, (512ull << 20) / per_item));
+        u64 *scratch = nullptr;
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&scratch), budget_items * per_item));
+        try
+        {
+            for (std::size_t off = 0; off < count; off += budget_items)
+            {
+                const std::size_t m = std::min(budget_items, count - off);
+                u64 *c = ct + off * 2 * poly;
+                check(launch_galois(e, c, scratch, m * 2 * k, lt.map_q, elt, table), "galois");
+                check(launch_copy_rows(e, scratch, 2 * poly, c, 2 * poly, m, k), "copy(c0)"); // :1903 / :1917
+                SEALHIP_CHECK(hipMemset2DAsync(c + poly, 2 * poly * sizeof(u64), 0, poly * sizeof(u64), m,
+                                               e.stream)); // :1928
+                op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
+            }
+            SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        }
+        catch (...)
+        {
+            (void)hipStreamSynchronize(e.stream);
+            (void)hipFree(scratch);
+            throw;
+        }
+        SEALHIP_CHECK(hipFree(scratch));
+    }
+} // namespace sealhip

@@ -1,0 +1,231 @@
+// poly.hip -- coefficient-wise kernels (native/src/seal/util/polyarithsmallmod.{h,cpp}) and the
+// Galois automorphisms (native/src/seal/util/galois.cpp) over batches of RNS rows.
+// All of these are pure HBM streaming: 16-byte loads/stores, two coefficients per lane.
+#include "engine.hpp"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr int kThreads = 256;
+
+        inline unsigned grid_for(std::size_t work_items)
+        {
+            std::size_t blocks = (work_items + kThreads - 1) / kThreads;
+            const std::size_t cap = 256u * 16u; // grid-stride the rest
+            return static_cast<unsigned>(blocks < cap ? (blocks ? blocks : 1) : cap);
+        }
+
+        template <int OP>
+        __device__ __forceinline__ u64 apply_op(u64 a, u64 b, u64 scalar, const PrimeDev &P)
+        {
+            if (OP == 0)
+                return mul_mod(a, b, P.p, P.cr0, P.cr1); // dyadic_product_coeffmod, polyarithsmallmod.cpp:63-117
+            if (OP == 1)
+                return add_mod(a, b, P.p);
+            if (OP == 2)
+                return sub_mod(a, b, P.p);
+            if (OP == 3)
+                return neg_mod(a, P.p);
+            return mul_mod(a, scalar, P.p, P.cr0, P.cr1); // multiply_poly_scalar_coeffmod, :15-61
+        }
+
+        template <int OP>
+        __global__ __launch_bounds__(kThreads) void poly_op_kernel(const u64 *__restrict__ a,
+                                                                   const u64 *__restrict__ b, u64 scalar,
+                                                                   u64 *__restrict__ r,
+                                                                   const PrimeDev *__restrict__ primes, RowMap map,
+                                                                   int logn, std::size_t npairs)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < npairs;
+                 i += stride)
+            {
+                const std::size_t row = (2 * i) >> logn;
+                const unsigned short pid = map.prime[row % map.rows];
+                if (pid == kSkipRow)
+                    continue;
+                const PrimeDev &P = primes[pid];
+                const ulonglong2 va = reinterpret_cast<const ulonglong2 *>(a)[i];
+                ulonglong2 vb = va;
+                if (OP == 0 || OP == 1 || OP == 2)
+                    vb = reinterpret_cast<const ulonglong2 *>(b)[i];
+                ulonglong2 out;
+                out.x = apply_op<OP>(va.x, vb.x, scalar, P);
+                out.y = apply_op<OP>(va.y, vb.y, scalar, P);
+                reinterpret_cast<ulonglong2 *>(r)[i] = out;
+            }
+        }
+
+        // out[I] = sum over i1 + i2 = I of a[i1] (.) b[i2], each term reduced (dyadic_product_coeffmod) and
+        // accumulated with add_poly_coeffmod, exactly as evaluator.cpp:376-420 / :493-520 do.
+        __global__ __launch_bounds__(kThreads) void tensor_product_kernel(
+            const u64 *__restrict__ a, int sa, std::size_t a_stride, const u64 *__restrict__ b, int sb,
+            std::size_t b_stride, u64 *__restrict__ out, std::size_t out_stride, const PrimeDev *__restrict__ primes,
+            RowMap map, int logn, std::size_t npairs_per_item, std::size_t count)
+        {
+            const std::size_t total = npairs_per_item * count;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t poly_words = static_cast<std::size_t>(map.rows) << logn;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t item = i / npairs_per_item;
+                const std::size_t off = 2 * (i - item * npairs_per_item); // word offset inside one polynomial
+                const PrimeDev &P = primes[map.prime[off >> logn]];
+                const u64 *pa = a + item * a_stride + off;
+                const u64 *pb = b + item * b_stride + off;
+                u64 *po = out + item * out_stride + off;
+                if (sa == 2 && sb == 2)
+                {
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(pa);
+                    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(pa + poly_words);
+                    const ulonglong2 b0 = *reinterpret_cast<const ulonglong2 *>(pb);
+                    const ulonglong2 b1 = *reinterpret_cast<const ulonglong2 *>(pb + poly_words);
+                    ulonglong2 c0, c1, c2;
+                    c0.x = mul_mod(a0.x, b0.x, P.p, P.cr0, P.cr1);
+                    c0.y = mul_mod(a0.y, b0.y, P.p, P.cr0, P.cr1);
+                    c1.x = add_mod(mul_mod(a1.x, b0.x, P.p, P.cr0, P.cr1), mul_mod(a0.x, b1.x, P.p, P.cr0, P.cr1), P.p);
+                    c1.y = add_mod(mul_mod(a1.y, b0.y, P.p, P.cr0, P.cr1), mul_mod(a0.y, b1.y, P.p, P.cr0, P.cr1), P.p);
+                    c2.x = mul_mod(a1.x, b1.x, P.p, P.cr0, P.cr1);
+                    c2.y = mul_mod(a1.y, b1.y, P.p, P.cr0, P.cr1);
+                    *reinterpret_cast<ulonglong2 *>(po) = c0;
+                    *reinterpret_cast<ulonglong2 *>(po + poly_words) = c1;
+                    *reinterpret_cast<ulonglong2 *>(po + 2 * poly_words) = c2;
+                    continue;
+                }
+                const int dest = sa + sb - 1;
+                for (int I = 0; I < dest; I++)
+                {
+                    const int last1 = I < sa - 1 ? I : sa - 1;
+                    const int first2 = I < sb - 1 ? I : sb - 1;
+                    const int first1 = I - first2;
+                    ulonglong2 acc;
+                    acc.x = 0;
+                    acc.y = 0;
+                    for (int i1 = first1; i1 <= last1; i1++)
+                    {
+                        const int i2 = I - i1;
+                        const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(pa + i1 * poly_words);
+                        const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(pb + i2 * poly_words);
+                        acc.x = add_mod(mul_mod(va.x, vb.x, P.p, P.cr0, P.cr1), acc.x, P.p);
+                        acc.y = add_mod(mul_mod(va.y, vb.y, P.p, P.cr0, P.cr1), acc.y, P.p);
+                    }
+                    *reinterpret_cast<ulonglong2 *>(po + I * poly_words) = acc;
+                }
+            }
+        }
+
+        __global__ __launch_bounds__(kThreads) void copy_rows_kernel(const u64 *__restrict__ src,
+                                                                     std::size_t src_stride, u64 *__restrict__ dst,
+                                                                     std::size_t dst_stride,
+                                                                     std::size_t pairs_per_poly, std::size_t npolys)
+        {
+            const std::size_t total = pairs_per_poly * npolys;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t poly = i / pairs_per_poly;
+                const std::size_t off = 2 * (i - poly * pairs_per_poly);
+                *reinterpret_cast<ulonglong2 *>(dst + poly * dst_stride + off) =
+                    *reinterpret_cast<const ulonglong2 *>(src + poly * src_stride + off);
+            }
+        }
+
+        // NTT form: out[i] = in[table[i]] (galois.cpp:188-214); coefficient form: out[(i*g) mod N] = +-in[i]
+        // (galois.cpp:144-186). One coefficient per lane: the permutation defeats wider accesses on one side.
+        __global__ __launch_bounds__(kThreads) void galois_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                                  const PrimeDev *__restrict__ primes, RowMap map,
+                                                                  int logn, std::size_t total, std::uint32_t elt,
+                                                                  const std::uint32_t *__restrict__ table)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t nmask = (static_cast<std::size_t>(1) << logn) - 1;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t row = i >> logn;
+                const std::size_t c = i & nmask;
+                if (table)
+                {
+                    out[i] = in[(row << logn) + table[c]];
+                }
+                else
+                {
+                    const u64 p = primes[map.prime[row % map.rows]].p;
+                    const u64 raw = static_cast<u64>(c) * elt;
+                    u64 v = in[i];
+                    if ((raw >> logn) & 1)
+                        v = neg_mod(v, p);
+                    out[(row << logn) + (raw & nmask)] = v;
+                }
+            }
+        }
+    } // namespace
+
+    hipError_t launch_poly_op(const Engine &e, PolyOp op, const u64 *a, const u64 *b, u64 scalar, u64 *r,
+                              std::size_t nrows, const RowMap &map)
+    {
+        const std::size_t npairs = (nrows << e.logn) / 2;
+        if (npairs == 0)
+            return hipSuccess;
+        const unsigned grid = grid_for(npairs);
+        ProfScope prof(e, "poly_op", 0);
+        switch (op)
+        {
+        case PolyOp::Dyadic:
+            poly_op_kernel<0><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        case PolyOp::Add:
+            poly_op_kernel<1><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        case PolyOp::Sub:
+            poly_op_kernel<2><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        case PolyOp::Negate:
+            poly_op_kernel<3><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        case PolyOp::Scalar:
+            poly_op_kernel<4><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        }
+        return hipGetLastError();
+    }
+
+    hipError_t launch_tensor_product(const Engine &e, const u64 *a, int sa, std::size_t a_stride, const u64 *b, int sb,
+                                     std::size_t b_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                     const RowMap &map)
+    {
+        const std::size_t pairs = (static_cast<std::size_t>(map.rows) << e.logn) / 2;
+        if (pairs * count == 0)
+            return hipSuccess;
+        ProfScope prof(e, "tensor_product", 0);
+        tensor_product_kernel<<<grid_for(pairs * count), kThreads, 0, e.stream>>>(
+            a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_copy_rows(const Engine &e, const u64 *src, std::size_t src_poly_stride, u64 *dst,
+                                std::size_t dst_poly_stride, std::size_t npolys, int rows)
+    {
+        const std::size_t pairs = (static_cast<std::size_t>(rows) << e.logn) / 2;
+        if (pairs * npolys == 0)
+            return hipSuccess;
+        ProfScope prof(e, "copy_rows", 0);
+        copy_rows_kernel<<<grid_for(pairs * npolys), kThreads, 0, e.stream>>>(src, src_poly_stride, dst,
+                                                                             dst_poly_stride, pairs, npolys);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_galois(const Engine &e, const u64 *in, u64 *out, std::size_t nrows, const RowMap &map,
+                             std::uint32_t elt, const std::uint32_t *table)
+    {
+        const std::size_t total = nrows << e.logn;
+        if (total == 0)
+            return hipSuccess;
+        ProfScope prof(e, "galois", 0);
+        galois_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(in, out, e.d_primes, map, e.logn, total, elt, table);
+        return hipGetLastError();
+    }
+} // namespace sealhip

@@ -1,0 +1,485 @@
+// rns.hip -- BEHZ base conversions and modulus switching (native/src/seal/util/rns.cpp:731-1068) as
+// column-parallel kernels: one lane owns one coefficient column of one item and walks the RNS rows,
+// so every global access is a coalesced row segment; the per-prime constants are wave-uniform
+// (scalar loads). All outputs are canonical residues, so constants are fused where the reference
+// multiplies twice (e.g. m_tilde * q^_i^{-1}).
+#include "engine.hpp"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr int kThreads = 256;
+
+        struct Cols
+        {
+            std::size_t item, c;
+        };
+        __device__ __forceinline__ bool column(std::size_t count, int logn, Cols &out)
+        {
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            out.item = i >> logn;
+            out.c = i & ((static_cast<std::size_t>(1) << logn) - 1);
+            return out.item < count;
+        }
+
+        // t[i] = x_i * (q^_i)^{-1} mod q_i  (first loop of fast_convert_array, rns.cpp:476-485)
+        // then out_j = sum_i t[i] * M[j][i] mod p_j  (dot_product_mod, rns.cpp:487-495)
+        template <int KMAX>
+        __device__ __forceinline__ u64 dot_mod(const u64 (&t)[KMAX], int k, const u64 *__restrict__ mrow,
+                                               const PrimeDev &P)
+        {
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                    mac128(lo, hi, t[i], mrow[i]);
+            return barrett_reduce_128(lo, hi, P.p, P.cr0, P.cr1);
+        }
+
+        // fastbconv_m_tilde (rns.cpp:1025-1068): k rows -> |Bsk|+1 rows
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void fastbconv_m_tilde_kernel(
+            const RnsDev *__restrict__ d, const PrimeDev *__restrict__ primes, const u64 *__restrict__ in,
+            std::size_t in_stride, u64 *__restrict__ out, std::size_t out_stride, std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, nB = d->nB;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            u64 t[KMAX];
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    t[i] = mul_mod(pin[i * N], d->q_mt_inv[i], Q.p, Q.cr0, Q.cr1);
+                }
+            for (int j = 0; j < nB; j++)
+                pout[j * N] = dot_mod<KMAX>(t, k, d->q_to_Bsk + j * k, primes[d->bsk_prime[j]]);
+            u64 acc = 0; // modulus 2^32: only the low word matters
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                    acc += t[i] * d->q_to_mt[i];
+            pout[nB * N] = acc & 0xFFFFFFFFull;
+        }
+
+        // sm_mrq (rns.cpp:925-981)
+        __device__ __forceinline__ u64 sm_mrq_one(u64 in_b, u64 r_mt, const RnsDev *d, int j, const PrimeDev &Bp)
+        {
+            u64 temp = r_mt;
+            if (temp >= (1ull << 31))
+                temp += Bp.p - (1ull << 32);
+            return mul_mod(mul_add_mod(d->prod_q_mod_Bsk[j], temp, in_b, Bp.p, Bp.cr0, Bp.cr1), d->inv_mt_mod_Bsk[j],
+                           Bp.p, Bp.cr0, Bp.cr1);
+        }
+        __device__ __forceinline__ u64 r_m_tilde(u64 in_mt, const RnsDev *d)
+        {
+            const u64 temp = (in_mt * d->inv_prod_q_mod_mt) & 0xFFFFFFFFull;
+            return temp ? (1ull << 32) - temp : 0;
+        }
+
+        __global__ __launch_bounds__(kThreads) void sm_mrq_kernel(const RnsDev *__restrict__ d,
+                                                                  const PrimeDev *__restrict__ primes,
+                                                                  const u64 *__restrict__ in, std::size_t in_stride,
+                                                                  u64 *__restrict__ out, std::size_t out_stride,
+                                                                  std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int nB = d->nB;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            const u64 r_mt = r_m_tilde(pin[nB * N], d);
+            for (int j = 0; j < nB; j++)
+                pout[j * N] = sm_mrq_one(pin[j * N], r_mt, d, j, primes[d->bsk_prime[j]]);
+        }
+
+        // fused fastbconv_m_tilde + sm_mrq (evaluator.cpp:345-348): k rows -> |Bsk| rows
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void bfv_lift_kernel(const RnsDev *__restrict__ d,
+                                                                    const PrimeDev *__restrict__ primes,
+                                                                    const u64 *__restrict__ in, std::size_t in_stride,
+                                                                    u64 *__restrict__ out, std::size_t out_stride,
+                                                                    std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, nB = d->nB;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            u64 t[KMAX];
+            u64 acc = 0;
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    t[i] = mul_mod(pin[i * N], d->q_mt_inv[i], Q.p, Q.cr0, Q.cr1);
+                    acc += t[i] * d->q_to_mt[i];
+                }
+            const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
+            for (int j = 0; j < nB; j++)
+            {
+                const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                const u64 conv = dot_mod<KMAX>(t, k, d->q_to_Bsk + j * k, Bp);
+                pout[j * N] = sm_mrq_one(conv, r_mt, d, j, Bp);
+            }
+        }
+
+        // fast_floor (rns.cpp:983-1023), optionally preceded by the multiplication by t of
+        // evaluator.cpp:432-434: (k + |Bsk|) rows -> |Bsk| rows
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void fast_floor_kernel(const RnsDev *__restrict__ d,
+                                                                      const PrimeDev *__restrict__ primes,
+                                                                      const u64 *__restrict__ in, std::size_t in_stride,
+                                                                      u64 *__restrict__ out, std::size_t out_stride,
+                                                                      std::size_t count, int logn, int mul_t)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, nB = d->nB;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            u64 t[KMAX];
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    u64 x = pin[i * N];
+                    if (mul_t)
+                        x = mul_mod(x, d->t, Q.p, Q.cr0, Q.cr1);
+                    t[i] = mul_mod(x, d->q_inv[i], Q.p, Q.cr0, Q.cr1);
+                }
+            for (int j = 0; j < nB; j++)
+            {
+                const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                const u64 conv = dot_mod<KMAX>(t, k, d->q_to_Bsk + j * k, Bp);
+                u64 x = pin[(k + j) * N];
+                if (mul_t)
+                    x = mul_mod(x, d->t, Bp.p, Bp.cr0, Bp.cr1);
+                pout[j * N] = mul_mod(x + (Bp.p - conv), d->inv_prod_q_mod_Bsk[j], Bp.p, Bp.cr0, Bp.cr1);
+            }
+        }
+
+        // Shenoy-Kumaresan tail shared by fastbconv_sk and the fused kernel (rns.cpp:880-922)
+        template <int KMAX>
+        __device__ __forceinline__ void sk_finish(const RnsDev *d, const PrimeDev *primes, const u64 (&tb)[KMAX + 1],
+                                                  u64 in_sk, u64 *pout, std::size_t N)
+        {
+            const int k = d->k, B = d->B;
+            const PrimeDev &Msk = primes[d->bsk_prime[B]];
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < KMAX + 1; i++)
+                if (i < B)
+                    mac128(lo, hi, tb[i], d->B_to_msk[i]);
+            const u64 conv_sk = barrett_reduce_128(lo, hi, Msk.p, Msk.cr0, Msk.cr1);
+            const u64 alpha = mul_mod(conv_sk + (Msk.p - in_sk), d->inv_prod_B_mod_msk, Msk.p, Msk.cr0, Msk.cr1);
+            const bool neg = alpha > (Msk.p >> 1);
+            for (int i = 0; i < k; i++)
+            {
+                const PrimeDev &Q = primes[d->q_prime[i]];
+                u64 l2 = 0, h2 = 0;
+                const u64 *mrow = d->B_to_q + i * B;
+#pragma unroll
+                for (int a = 0; a < KMAX + 1; a++)
+                    if (a < B)
+                        mac128(l2, h2, tb[a], mrow[a]);
+                const u64 conv = barrett_reduce_128(l2, h2, Q.p, Q.cr0, Q.cr1);
+                const u64 pB = d->prod_B_mod_q[i];
+                pout[i * N] = neg ? mul_add_mod(pB, Msk.p - alpha, conv, Q.p, Q.cr0, Q.cr1)
+                                  : mul_add_mod(Q.p - pB, alpha, conv, Q.p, Q.cr0, Q.cr1);
+            }
+        }
+
+        // fastbconv_sk (rns.cpp:853-923): |Bsk| rows -> k rows
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void fastbconv_sk_kernel(const RnsDev *__restrict__ d,
+                                                                        const PrimeDev *__restrict__ primes,
+                                                                        const u64 *__restrict__ in,
+                                                                        std::size_t in_stride, u64 *__restrict__ out,
+                                                                        std::size_t out_stride, std::size_t count,
+                                                                        int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int B = d->B;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 tb[KMAX + 1];
+#pragma unroll
+            for (int i = 0; i < KMAX + 1; i++)
+                if (i < B)
+                {
+                    const PrimeDev &Bp = primes[d->bsk_prime[i]];
+                    tb[i] = mul_mod(pin[i * N], d->B_inv[i], Bp.p, Bp.cr0, Bp.cr1);
+                }
+            sk_finish<KMAX>(d, primes, tb, pin[B * N], out + cc.item * out_stride + cc.c, N);
+        }
+
+        // fused BEHZ steps (6)-(8) of evaluator.cpp:427-444: (k+|Bsk|) rows -> k rows
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void bfv_floor_sk_kernel(const RnsDev *__restrict__ d,
+                                                                        const PrimeDev *__restrict__ primes,
+                                                                        const u64 *__restrict__ in,
+                                                                        std::size_t in_stride, u64 *__restrict__ out,
+                                                                        std::size_t out_stride, std::size_t count,
+                                                                        int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, B = d->B;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 t[KMAX];
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    const u64 x = mul_mod(pin[i * N], d->t, Q.p, Q.cr0, Q.cr1);
+                    t[i] = mul_mod(x, d->q_inv[i], Q.p, Q.cr0, Q.cr1);
+                }
+            u64 tb[KMAX + 1];
+            u64 in_sk = 0;
+#pragma unroll
+            for (int j = 0; j < KMAX + 2; j++)
+                if (j <= B)
+                {
+                    const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                    const u64 conv = dot_mod<KMAX>(t, k, d->q_to_Bsk + j * k, Bp);
+                    const u64 x = mul_mod(pin[(k + j) * N], d->t, Bp.p, Bp.cr0, Bp.cr1);
+                    const u64 fl = mul_mod(x + (Bp.p - conv), d->inv_prod_q_mod_Bsk[j], Bp.p, Bp.cr0, Bp.cr1);
+                    if (j < B)
+                    {
+                        if (j < KMAX + 1)
+                            tb[j < KMAX + 1 ? j : 0] = mul_mod(fl, d->B_inv[j], Bp.p, Bp.cr0, Bp.cr1);
+                    }
+                    else
+                        in_sk = fl;
+                }
+            sk_finish<KMAX>(d, primes, tb, in_sk, out + cc.item * out_stride + cc.c, N);
+        }
+
+        // divide_and_round_q_last_inplace (rns.cpp:731-775); writes out_rows rows (k-1, or k to mirror the
+        // reference's clobbered last row)
+        __global__ __launch_bounds__(kThreads) void divround_bfv_kernel(const RnsDev *__restrict__ d,
+                                                                        const PrimeDev *__restrict__ primes,
+                                                                        const u64 *__restrict__ in,
+                                                                        std::size_t in_stride, u64 *__restrict__ out,
+                                                                        std::size_t out_stride, std::size_t count,
+                                                                        int logn, int out_rows)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            const PrimeDev &L = primes[d->q_prime[k - 1]];
+            const u64 half = L.p >> 1;
+            const u64 last = barrett_reduce_63(pin[(k - 1) * N] + half, L.p, L.cr1);
+            for (int i = 0; i < k - 1; i++)
+            {
+                const PrimeDev &Q = primes[d->q_prime[i]];
+                u64 temp = barrett_reduce_63(last, Q.p, Q.cr1);
+                temp = sub_mod(temp, barrett_reduce_63(half, Q.p, Q.cr1), Q.p);
+                const u64 v = sub_mod(pin[i * N], temp, Q.p);
+                pout[i * N] = mul_mod(v, d->inv_q_last_mod_q[i], Q.p, Q.cr0, Q.cr1);
+            }
+            if (out_rows == k)
+                pout[(k - 1) * N] = last;
+        }
+
+        // divide_and_round_q_last_ntt_inplace, part before the forward NTTs (rns.cpp:800-827); `last` is the
+        // already inverse-transformed last row and is updated in place like the reference does
+        __global__ __launch_bounds__(kThreads) void rescale_pre_kernel(const RnsDev *__restrict__ d,
+                                                                       const PrimeDev *__restrict__ primes,
+                                                                       u64 *__restrict__ last_row,
+                                                                       std::size_t last_stride,
+                                                                       u64 *__restrict__ temp, std::size_t temp_stride,
+                                                                       std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            u64 *plast = last_row + cc.item * last_stride + cc.c;
+            u64 *ptemp = temp + cc.item * temp_stride + cc.c;
+            const PrimeDev &L = primes[d->q_prime[k - 1]];
+            const u64 half = L.p >> 1;
+            const u64 last = barrett_reduce_63(*plast + half, L.p, L.cr1);
+            *plast = last;
+            for (int i = 0; i < k - 1; i++)
+            {
+                const PrimeDev &Q = primes[d->q_prime[i]];
+                const u64 v = Q.p < L.p ? barrett_reduce_63(last, Q.p, Q.cr1) : last;
+                ptemp[i * N] = v + (Q.p - barrett_reduce_63(half, Q.p, Q.cr1));
+            }
+        }
+
+        // ... and the part after them (rns.cpp:841-849)
+        __global__ __launch_bounds__(kThreads) void rescale_post_kernel(const RnsDev *__restrict__ d,
+                                                                        const PrimeDev *__restrict__ primes,
+                                                                        const u64 *__restrict__ in,
+                                                                        std::size_t in_stride,
+                                                                        const u64 *__restrict__ temp,
+                                                                        std::size_t temp_stride, u64 *__restrict__ out,
+                                                                        std::size_t out_stride, std::size_t count,
+                                                                        int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            const u64 *ptemp = temp + cc.item * temp_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            for (int i = 0; i < k - 1; i++)
+            {
+                const PrimeDev &Q = primes[d->q_prime[i]];
+                const u64 v = pin[i * N] + (Q.p << 2) - ptemp[i * N];
+                pout[i * N] = mul_mod(v, d->inv_q_last_mod_q[i], Q.p, Q.cr0, Q.cr1);
+            }
+        }
+
+        inline unsigned blocks_for(std::size_t count, int logn)
+        {
+            return static_cast<unsigned>(((count << logn) + kThreads - 1) / kThreads);
+        }
+    } // namespace
+
+#define SEALHIP_DISPATCH_K(kval, KERNEL, ...)                                             \
+    do                                                                                    \
+    {                                                                                     \
+        if ((kval) <= 4)                                                                  \
+            KERNEL<4><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                      \
+        else if ((kval) <= 8)                                                             \
+            KERNEL<8><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                      \
+        else if ((kval) <= 16)                                                            \
+            KERNEL<16><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+        else if ((kval) <= 32)                                                            \
+            KERNEL<32><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+        else                                                                              \
+            KERNEL<64><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+    } while (0)
+
+    hipError_t launch_fastbconv_m_tilde(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                        std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        const unsigned grid = blocks_for(count, e.logn);
+        ProfScope prof(e, "fastbconv_m_tilde", 0);
+        SEALHIP_DISPATCH_K(h.k, fastbconv_m_tilde_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_sm_mrq(const Engine &e, const RnsDev *d, const RnsDev &, const u64 *in, std::size_t in_stride,
+                             u64 *out, std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "sm_mrq", 0);
+        sm_mrq_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,
+                                                                            out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
+                               u64 *out, std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        const unsigned grid = blocks_for(count, e.logn);
+        ProfScope prof(e, "bfv_lift", 0);
+        SEALHIP_DISPATCH_K(h.k, bfv_lift_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_fast_floor(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                 std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count, int mul_t)
+    {
+        if (!count)
+            return hipSuccess;
+        const unsigned grid = blocks_for(count, e.logn);
+        ProfScope prof(e, "fast_floor", 0);
+        SEALHIP_DISPATCH_K(h.k, fast_floor_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn,
+                           mul_t);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_fastbconv_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        const unsigned grid = blocks_for(count, e.logn);
+        ProfScope prof(e, "fastbconv_sk", 0);
+        SEALHIP_DISPATCH_K(h.k, fastbconv_sk_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_bfv_floor_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        const unsigned grid = blocks_for(count, e.logn);
+        ProfScope prof(e, "bfv_floor_sk", 0);
+        SEALHIP_DISPATCH_K(h.k, bfv_floor_sk_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &, const u64 *in,
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                   int out_rows)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "divround_bfv", 0);
+        divround_bfv_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,
+                                                                                  out_stride, count, e.logn, out_rows);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_rescale_pre(const Engine &e, const RnsDev *d, const RnsDev &, u64 *last,
+                                  std::size_t last_stride, u64 *temp, std::size_t temp_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "rescale_pre", 0);
+        rescale_pre_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, last, last_stride,
+                                                                                 temp, temp_stride, count, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_rescale_post(const Engine &e, const RnsDev *d, const RnsDev &, const u64 *in,
+                                   std::size_t in_stride, const u64 *temp, std::size_t temp_stride, u64 *out,
+                                   std::size_t out_stride, std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "rescale_post", 0);
+        rescale_post_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(
+            d, e.d_primes, in, in_stride, temp, temp_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+} // namespace sealhip

@@ -1,0 +1,415 @@
+"""Host-side Python mirror of the reference's Evaluator interface over the sealhip C ABI.
+
+The product path is `libsealhip.so` (hand-written HIP for gfx950 behind include/sealhip.h); this module
+only binds it with ctypes and mirrors the names, argument meaning and error behaviour of
+seal::Evaluator (native/src/seal/evaluator.h) so that tests read like the reference's own.
+There is NO CPU fallback: if the library or a HIP device is missing, calls raise.
+
+Error mapping (native/src/seal/c/defines.h:34-49 <-> evaluator.cpp exceptions):
+  E_INVALIDARG -> ValueError (std::invalid_argument), COR_E_INVALIDOPERATION -> LogicError
+  (std::logic_error), E_POINTER -> TypeError, E_OUTOFMEMORY -> MemoryError, E_UNEXPECTED -> RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsealhip.so")
+
+S_OK = 0
+E_POINTER = 0x80004003
+E_INVALIDARG = 0x80070057
+E_OUTOFMEMORY = 0x8007000E
+E_UNEXPECTED = 0x8000FFFF
+COR_E_INVALIDOPERATION = 0x80131509
+
+SCHEME_BFV, SCHEME_CKKS = 1, 2
+MODE_PARITY, MODE_STRICT = 0, 1
+BASE_Q, BASE_BSK, BASE_KEY = 0, 1, 2
+
+
+class LogicError(RuntimeError):
+    """std::logic_error of the reference (unsupported operation for the scheme, host-only context, ...)."""
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("scheme", C.c_uint32),
+        ("log_n", C.c_uint32),
+        ("n_key_moduli", C.c_uint32),
+        ("n_special_primes", C.c_uint32),
+        ("key_moduli", C.POINTER(C.c_uint64)),
+        ("plain_modulus", C.c_uint64),
+        ("mode", C.c_uint32),
+        ("device", C.c_int32),
+    ]
+
+
+_lib = None
+
+# every symbol include/sealhip.h declares: name -> argtypes (restype is always long unless noted)
+_vp, _u32, _u64, _sz, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int32
+SYMBOLS = {
+    "sealhip_last_error_string": None,
+    "sealhip_num_devices": [C.POINTER(C.c_int32)],
+    "sealhip_context_create": [C.POINTER(Params), C.POINTER(_vp)],
+    "sealhip_context_destroy": [_vp],
+    "sealhip_context_first_level": [_vp, C.POINTER(_u32)],
+    "sealhip_context_bsk_size": [_vp, _u32, C.POINTER(_u32)],
+    "sealhip_set_stream": [_vp, _vp],
+    "sealhip_synchronize": [_vp],
+    "sealhip_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "sealhip_free": [_vp, _vp],
+    "sealhip_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "sealhip_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "sealhip_profile_enable": [_vp, _i32],
+    "sealhip_profile_fetch": [_vp, C.c_char_p, _sz],
+    "sealhip_debug_ntt_table": [_vp, _u32, _u32, _vp, _sz],
+    "sealhip_debug_rns_constants": [_vp, _u32, _u32, _vp, _sz, C.POINTER(_sz)],
+    "sealhip_ntt_negacyclic_harvey_lazy": [_vp, _vp, _sz, _u32, _u32],
+    "sealhip_ntt_negacyclic_harvey": [_vp, _vp, _sz, _u32, _u32],
+    "sealhip_inverse_ntt_negacyclic_harvey_lazy": [_vp, _vp, _sz, _u32, _u32],
+    "sealhip_inverse_ntt_negacyclic_harvey": [_vp, _vp, _sz, _u32, _u32],
+    "sealhip_dyadic_product_coeffmod": [_vp, _vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_multiply_poly_scalar_coeffmod": [_vp, _vp, _sz, _u32, _u32, _u64, _vp],
+    "sealhip_add_poly_coeffmod": [_vp, _vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_sub_poly_coeffmod": [_vp, _vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_negate_poly_coeffmod": [_vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_fastbconv_m_tilde": [_vp, _u32, _vp, _sz, _vp],
+    "sealhip_sm_mrq": [_vp, _u32, _vp, _sz, _vp],
+    "sealhip_fast_floor": [_vp, _u32, _vp, _sz, _vp],
+    "sealhip_fastbconv_sk": [_vp, _u32, _vp, _sz, _vp],
+    "sealhip_divide_and_round_q_last_inplace": [_vp, _u32, _vp, _sz],
+    "sealhip_divide_and_round_q_last_ntt_inplace": [_vp, _u32, _vp, _sz],
+    "sealhip_galois_elt_from_step": [_vp, _i32, C.POINTER(_u32)],
+    "sealhip_apply_galois": [_vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_apply_galois_ntt": [_vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_kswitch_key_load": [_vp, _vp, _u32, _i32, C.POINTER(_vp)],
+    "sealhip_kswitch_key_destroy": [_vp, _vp],
+    "sealhip_modup_rns": [_vp, _u32, _u32, _vp, _sz],
+    "sealhip_rescale_special_rns_inplace": [_vp, _u32, _vp, _sz],
+    "sealhip_switch_key_inplace": [_vp, _u32, _vp, _vp, _sz, _vp],
+    "sealhip_evaluator_multiply": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_square": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_relinearize": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
+    "sealhip_evaluator_mod_switch_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_rescale_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_apply_galois": [_vp, _u32, _vp, _sz, _u32, _vp],
+    "sealhip_evaluator_transform_to_ntt": [_vp, _u32, _vp, _u32, _sz],
+    "sealhip_evaluator_transform_from_ntt": [_vp, _u32, _vp, _u32, _sz],
+}
+
+
+def lib():
+    """Load libsealhip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsealhip.so is missing (%s): build it with __graft_entry__.build() / make -C gemini-seal_amd; "
+                "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, argtypes in SYMBOLS.items():
+            fn = getattr(L, name)
+            if argtypes is None:
+                fn.restype = C.c_char_p
+                fn.argtypes = []
+            else:
+                fn.restype = C.c_long
+                fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def _check(hr):
+    hr &= 0xFFFFFFFF
+    if hr == S_OK:
+        return
+    msg = lib().sealhip_last_error_string().decode("utf-8", "replace")
+    if hr == E_INVALIDARG:
+        raise ValueError(msg)
+    if hr == COR_E_INVALIDOPERATION:
+        raise LogicError(msg)
+    if hr == E_POINTER:
+        raise TypeError(msg)
+    if hr == E_OUTOFMEMORY:
+        raise MemoryError(msg)
+    raise RuntimeError("sealhip error 0x%08x: %s" % (hr, msg))
+
+
+def num_devices():
+    n = C.c_int32(0)
+    _check(lib().sealhip_num_devices(C.byref(n)))
+    return n.value
+
+
+def _ptr(x):
+    """Device pointer of a DeviceBuffer, a torch CUDA tensor, or a raw integer address."""
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class DeviceBuffer:
+    """uint64 words in HBM, owned through sealhip_malloc / sealhip_free."""
+
+    def __init__(self, ctx, words):
+        self.ctx, self.words = ctx, int(words)
+        p = C.c_void_p()
+        _check(lib().sealhip_malloc(ctx.handle, self.words * 8, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        assert host.size == self.words, (host.size, self.words)
+        _check(lib().sealhip_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, host.size * 8))
+        return self
+
+    def download(self, shape=None):
+        out = np.empty(self.words, dtype=np.uint64)
+        _check(lib().sealhip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.words * 8))
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            _check(lib().sealhip_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class KSwitchKeys:
+    """One key-switch key (n_digits x 2 x n_key x N, keygenerator.cpp:325-369) resident in HBM."""
+
+    def __init__(self, ctx, key, n_digits=None, from_host=True):
+        self.ctx = ctx
+        if from_host:
+            key = np.ascontiguousarray(key, dtype=np.uint64)
+            if n_digits is None:
+                n_digits = key.shape[0]
+            src = key.ctypes.data
+        else:
+            src = _ptr(key)
+        h = C.c_void_p()
+        _check(lib().sealhip_kswitch_key_load(ctx.handle, src, n_digits, 1 if from_host else 0, C.byref(h)))
+        self.handle = h.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().sealhip_kswitch_key_destroy(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Context:
+    """Plain mirror of what the path needs from SEALContext (context.cpp:455-540)."""
+
+    def __init__(self, scheme, log_n, key_moduli, n_special_primes=1, plain_modulus=0, mode=MODE_PARITY, device=0):
+        self.scheme, self.log_n, self.n = scheme, log_n, 1 << log_n
+        self.key_moduli = [int(x) for x in key_moduli]
+        self.n_key, self.nsp = len(self.key_moduli), n_special_primes
+        arr = (C.c_uint64 * self.n_key)(*self.key_moduli)
+        p = Params(scheme, log_n, self.n_key, n_special_primes, arr, plain_modulus, mode, device)
+        h = C.c_void_p()
+        _check(lib().sealhip_context_create(C.byref(p), C.byref(h)))
+        self.handle = h.value
+        self.k_first = self.n_key - n_special_primes
+
+    # -- memory
+    def alloc(self, words):
+        return DeviceBuffer(self, words)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        return DeviceBuffer(self, host.size).upload(host)
+
+    def synchronize(self):
+        _check(lib().sealhip_synchronize(self.handle))
+
+    def set_stream(self, stream_ptr):
+        _check(lib().sealhip_set_stream(self.handle, stream_ptr))
+
+    def bsk_size(self, k):
+        v = C.c_uint32()
+        _check(lib().sealhip_context_bsk_size(self.handle, k, C.byref(v)))
+        return v.value
+
+    def rows(self, k, base):
+        if base == BASE_Q:
+            return k
+        if base == BASE_BSK:
+            return self.bsk_size(k)
+        return k + self.nsp
+
+    def profile_enable(self, on=True):
+        _check(lib().sealhip_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_fetch(self):
+        """{kernel tag: {"launches", "ms", "units"}} from HIP events on the launch stream; clears the records."""
+        import json
+
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().sealhip_profile_fetch(self.handle, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    # -- introspection (host only)
+    def debug_ntt_table(self, prime_index, kind):
+        out = np.empty(self.n, dtype=np.uint64)
+        _check(lib().sealhip_debug_ntt_table(self.handle, prime_index, kind, out.ctypes.data, out.size))
+        return out
+
+    def debug_rns_constants(self, k, which):
+        out = np.empty(70 * 70, dtype=np.uint64)
+        w = C.c_size_t()
+        _check(lib().sealhip_debug_rns_constants(self.handle, k, which, out.ctypes.data, out.size, C.byref(w)))
+        return out[: w.value].copy()
+
+    def galois_elt_from_step(self, step):
+        v = C.c_uint32()
+        _check(lib().sealhip_galois_elt_from_step(self.handle, step, C.byref(v)))
+        return v.value
+
+    # -- L2 functions (names of native/src/seal/util/*.h)
+    def ntt_negacyclic_harvey_lazy(self, data, count, k, base=BASE_Q):
+        _check(lib().sealhip_ntt_negacyclic_harvey_lazy(self.handle, _ptr(data), count, k, base))
+
+    def ntt_negacyclic_harvey(self, data, count, k, base=BASE_Q):
+        _check(lib().sealhip_ntt_negacyclic_harvey(self.handle, _ptr(data), count, k, base))
+
+    def inverse_ntt_negacyclic_harvey_lazy(self, data, count, k, base=BASE_Q):
+        _check(lib().sealhip_inverse_ntt_negacyclic_harvey_lazy(self.handle, _ptr(data), count, k, base))
+
+    def inverse_ntt_negacyclic_harvey(self, data, count, k, base=BASE_Q):
+        _check(lib().sealhip_inverse_ntt_negacyclic_harvey(self.handle, _ptr(data), count, k, base))
+
+    def dyadic_product_coeffmod(self, a, b, count, k, result, base=BASE_Q):
+        _check(lib().sealhip_dyadic_product_coeffmod(self.handle, _ptr(a), _ptr(b), count, k, base, _ptr(result)))
+
+    def multiply_poly_scalar_coeffmod(self, a, count, k, scalar, result, base=BASE_Q):
+        _check(lib().sealhip_multiply_poly_scalar_coeffmod(self.handle, _ptr(a), count, k, base, scalar, _ptr(result)))
+
+    def add_poly_coeffmod(self, a, b, count, k, result, base=BASE_Q):
+        _check(lib().sealhip_add_poly_coeffmod(self.handle, _ptr(a), _ptr(b), count, k, base, _ptr(result)))
+
+    def sub_poly_coeffmod(self, a, b, count, k, result, base=BASE_Q):
+        _check(lib().sealhip_sub_poly_coeffmod(self.handle, _ptr(a), _ptr(b), count, k, base, _ptr(result)))
+
+    def negate_poly_coeffmod(self, a, count, k, result, base=BASE_Q):
+        _check(lib().sealhip_negate_poly_coeffmod(self.handle, _ptr(a), count, k, base, _ptr(result)))
+
+    def fastbconv_m_tilde(self, k, inp, count, out):
+        _check(lib().sealhip_fastbconv_m_tilde(self.handle, k, _ptr(inp), count, _ptr(out)))
+
+    def sm_mrq(self, k, inp, count, out):
+        _check(lib().sealhip_sm_mrq(self.handle, k, _ptr(inp), count, _ptr(out)))
+
+    def fast_floor(self, k, inp, count, out):
+        _check(lib().sealhip_fast_floor(self.handle, k, _ptr(inp), count, _ptr(out)))
+
+    def fastbconv_sk(self, k, inp, count, out):
+        _check(lib().sealhip_fastbconv_sk(self.handle, k, _ptr(inp), count, _ptr(out)))
+
+    def divide_and_round_q_last_inplace(self, k, data, count):
+        _check(lib().sealhip_divide_and_round_q_last_inplace(self.handle, k, _ptr(data), count))
+
+    def divide_and_round_q_last_ntt_inplace(self, k, data, count):
+        _check(lib().sealhip_divide_and_round_q_last_ntt_inplace(self.handle, k, _ptr(data), count))
+
+    def apply_galois(self, inp, count, k, galois_elt, out):
+        _check(lib().sealhip_apply_galois(self.handle, _ptr(inp), count, k, galois_elt, _ptr(out)))
+
+    def apply_galois_ntt(self, inp, count, k, galois_elt, out):
+        _check(lib().sealhip_apply_galois_ntt(self.handle, _ptr(inp), count, k, galois_elt, _ptr(out)))
+
+    def modup_rns(self, k, src_bundle_index, ext, count):
+        _check(lib().sealhip_modup_rns(self.handle, k, src_bundle_index, _ptr(ext), count))
+
+    def rescale_special_rns_inplace(self, k, poly, count):
+        _check(lib().sealhip_rescale_special_rns_inplace(self.handle, k, _ptr(poly), count))
+
+    def switch_key_inplace(self, k, ct, target, count, key):
+        _check(lib().sealhip_switch_key_inplace(self.handle, k, _ptr(ct), _ptr(target), count, key.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().sealhip_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Evaluator:
+    """Batched mirror of seal::Evaluator for the hot path (native/src/seal/evaluator.h:246-1239).
+
+    Ciphertexts are device buffers in the reference layout (size x k x N uint64), `count` of them back to back;
+    `k` names the level (number of coefficient-modulus primes)."""
+
+    def __init__(self, context):
+        self.ctx = context
+
+    def multiply(self, a, size_a, b, size_b, k, count, out):
+        _check(lib().sealhip_evaluator_multiply(self.ctx.handle, k, _ptr(a), size_a, _ptr(b), size_b, count, _ptr(out)))
+
+    def square(self, a, size_a, k, count, out):
+        _check(lib().sealhip_evaluator_square(self.ctx.handle, k, _ptr(a), size_a, count, _ptr(out)))
+
+    def relinearize_inplace(self, ct, size, k, count, relin_keys):
+        keys = (C.c_void_p * max(1, len(relin_keys)))(*[rk.handle for rk in relin_keys])
+        _check(lib().sealhip_evaluator_relinearize(self.ctx.handle, k, _ptr(ct), size, count, keys, len(relin_keys)))
+
+    def mod_switch_to_next(self, ct, size, k, count, out):
+        _check(lib().sealhip_evaluator_mod_switch_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
+
+    def rescale_to_next(self, ct, size, k, count, out):
+        _check(lib().sealhip_evaluator_rescale_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
+
+    def apply_galois_inplace(self, ct, k, count, galois_elt, galois_key):
+        _check(lib().sealhip_evaluator_apply_galois(self.ctx.handle, k, _ptr(ct), count, galois_elt, galois_key.handle))
+
+    def rotate_vector_inplace(self, ct, k, count, steps, galois_keys):
+        """rotate_internal (evaluator.cpp:1945-2000): direct key if present, else the NAF decomposition.
+        galois_keys: dict galois_elt -> KSwitchKeys."""
+        if steps == 0:
+            return
+        elt = self.ctx.galois_elt_from_step(steps)
+        if elt in galois_keys:
+            return self.apply_galois_inplace(ct, k, count, elt, galois_keys[elt])
+        naf = _naf(steps)
+        if len(naf) == 1:
+            raise ValueError("Galois key not present")
+        for s in naf:
+            if abs(s) != (self.ctx.n >> 1):
+                self.rotate_vector_inplace(ct, k, count, s, galois_keys)
+
+    rotate_rows_inplace = rotate_vector_inplace
+
+    def transform_to_ntt_inplace(self, ct, size, k, count):
+        _check(lib().sealhip_evaluator_transform_to_ntt(self.ctx.handle, k, _ptr(ct), size, count))
+
+    def transform_from_ntt_inplace(self, ct, size, k, count):
+        _check(lib().sealhip_evaluator_transform_from_ntt(self.ctx.handle, k, _ptr(ct), size, count))
+
+
+def _naf(value):
+    """util/numth.h:22-42"""
+    res, sign, value, i = [], value < 0, abs(value), 0
+    while value:
+        zi = 2 - (value % 4) if value % 2 else 0
+        value = (value - zi) // 2
+        if zi:
+            res.append((-zi if sign else zi) * (1 << i))
+        i += 1
+    return res

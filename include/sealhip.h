@@ -1,0 +1,198 @@
+/*
+ * sealhip.h -- C ABI of the MI355X-native RNS-NTT polynomial engine that replaces the hot path
+ * behind seal::Evaluator (Gemini-SEAL, a Microsoft SEAL 3.5.3 fork).
+ *
+ * Conventions (modelled on the reference's own C export layer, native/src/seal/c/defines.h:34-58):
+ *   - every function returns an HRESULT-compatible `long`: S_OK (0) or one of the SEALHIP_E_* codes;
+ *     nothing throws across the ABI; sealhip_last_error_string() returns the thread's last message;
+ *   - plain pointers and sizes only, no C++/torch types;
+ *   - all polynomial data are `uint64_t` matrices in the reference layout: a ciphertext is `size`
+ *     polynomials, each a row-major (k x N) matrix, RNS row i of polynomial j at
+ *     data + (j*k + i)*N   (native/src/seal/ciphertext.h:359-368, util/iterator.h:746-766);
+ *   - a *batch* is `count` such objects stored back to back (the data-parallel axis);
+ *   - unless a function name ends in `_host`, every data pointer is a DEVICE pointer (hipMalloc'd,
+ *     or a torch CUDA tensor's data_ptr()); work is enqueued on the context's stream and is
+ *     asynchronous until sealhip_synchronize();
+ *   - a ciphertext level is addressed by `k` = number of leading coefficient-modulus primes
+ *     (the chain drops the last prime per level: native/src/seal/context.cpp:423-431).
+ *
+ * There is no CPU fallback: without a HIP device every compute entry point fails with
+ * SEALHIP_E_UNEXPECTED.
+ */
+#ifndef SEALHIP_H
+#define SEALHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HRESULT values of native/src/seal/c/defines.h:34-49 */
+#define SEALHIP_S_OK 0L
+#define SEALHIP_E_POINTER ((long)0x80004003L)
+#define SEALHIP_E_INVALIDARG ((long)0x80070057L)
+#define SEALHIP_E_OUTOFMEMORY ((long)0x8007000EL)
+#define SEALHIP_E_UNEXPECTED ((long)0x8000FFFFL)
+#define SEALHIP_COR_E_INVALIDOPERATION ((long)0x80131509L)
+
+/* scheme_type values (native/src/seal/encryptionparams.h:24-34) */
+#define SEALHIP_SCHEME_BFV 1u
+#define SEALHIP_SCHEME_CKKS 2u
+
+/* PARITY reproduces the reference bit for bit (including SURVEY F2/F3); STRICT is the
+   mathematically correct variant (Harvey-corrected butterflies, NTT'd in-bundle rows for BFV). */
+#define SEALHIP_MODE_PARITY 0u
+#define SEALHIP_MODE_STRICT 1u
+
+/* which RNS base the rows of a polynomial belong to */
+#define SEALHIP_BASE_Q 0u   /* the first k coefficient-modulus primes                     */
+#define SEALHIP_BASE_BSK 1u /* BEHZ auxiliary base Bsk of level k (B..., m_sk last)       */
+#define SEALHIP_BASE_KEY 2u /* k ciphertext primes followed by the nsp special primes     */
+
+typedef struct sealhip_context sealhip_context;
+typedef struct sealhip_kswitch_key sealhip_kswitch_key;
+
+/* Plain mirror of what the path needs from EncryptionParameters / SEALContext
+   (native/src/seal/encryptionparams.h:205-214,319-322; native/src/seal/context.cpp:455-540). */
+typedef struct sealhip_params
+{
+    uint32_t scheme;           /* SEALHIP_SCHEME_*                                                   */
+    uint32_t log_n;            /* log2(poly_modulus_degree), 3..16                                   */
+    uint32_t n_key_moduli;     /* |coeff_modulus| at key level (special primes last)                 */
+    uint32_t n_special_primes; /* EncryptionParameters::n_special_primes(), >= 1                     */
+    const uint64_t *key_moduli;
+    uint64_t plain_modulus;    /* BFV only; 0 for CKKS                                               */
+    uint32_t mode;             /* SEALHIP_MODE_*                                                     */
+    int32_t device;            /* HIP device ordinal; -1 = host-only context (tables, no compute)    */
+} sealhip_params;
+
+/* ---------------------------------------------------------------- library / context */
+const char *sealhip_last_error_string(void);
+long sealhip_num_devices(int32_t *count);
+long sealhip_context_create(const sealhip_params *params, sealhip_context **out);
+long sealhip_context_destroy(sealhip_context *ctx);
+long sealhip_context_first_level(const sealhip_context *ctx, uint32_t *k_first); /* = n_key - nsp */
+long sealhip_context_bsk_size(sealhip_context *ctx, uint32_t k, uint32_t *bsk_size); /* |Bsk| of level k */
+long sealhip_set_stream(sealhip_context *ctx, void *hip_stream); /* NULL = the context's own stream */
+long sealhip_synchronize(sealhip_context *ctx);
+
+/* device memory helpers for hosts that do not bring their own allocator */
+long sealhip_malloc(sealhip_context *ctx, size_t bytes, void **dptr);
+long sealhip_free(sealhip_context *ctx, void *dptr);
+long sealhip_memcpy_h2d(sealhip_context *ctx, void *dst_dev, const void *src_host, size_t bytes);
+long sealhip_memcpy_d2h(sealhip_context *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* Per-kernel timing with HIP events recorded on the launch stream. While enabled every kernel launch of
+   the engine is bracketed by two events; sealhip_profile_fetch synchronises the stream, writes a JSON
+   object {"<kernel tag>": {"launches": n, "ms": total, "units": u}, ...} (NUL-terminated) into `json`,
+   and clears the records. `units` counts RNS rows for the NTT passes (0 for other kernels). */
+long sealhip_profile_enable(sealhip_context *ctx, int32_t enable);
+long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity);
+
+/* Introspection of the precomputed tables (works on host-only contexts; used by the CPU tests).
+   kind: 0 root_powers, 1 scaled_root_powers, 2 inv_root_powers (reference order, n^-1 merged),
+   3 scaled_inv_root_powers; prime_index: 0..n_key-1 key primes, n_key.. = 60-bit auxiliary primes
+   in get_primes order (m_sk, gamma, B_0, B_1, ...). */
+long sealhip_debug_ntt_table(sealhip_context *ctx, uint32_t prime_index, uint32_t kind, uint64_t *out_host,
+                             size_t capacity);
+/* which: 0 Bsk primes, 1 inv_prod_q_mod_Bsk, 2 prod_q_mod_Bsk, 3 inv_m_tilde_mod_Bsk, 4 prod_B_mod_q,
+   5 inv_q_last_mod_q, 6 {inv_prod_q_mod_m_tilde, inv_prod_B_mod_m_sk, m_sk, gamma},
+   7 q->Bsk matrix (row-major [Bsk][q]), 8 B->q matrix ([q][B]), 9 q inv_punctured, 10 B inv_punctured,
+   11 q->m_tilde row, 12 B->m_sk row */
+long sealhip_debug_rns_constants(sealhip_context *ctx, uint32_t k, uint32_t which, uint64_t *out_host,
+                                 size_t capacity, size_t *written);
+
+/* ---------------------------------------------------------------- L2: NTT (util/ntt.h:189-368)
+   data: count polynomials x rows x N, in place. `base` selects the primes of the `rows` rows of one
+   polynomial: BASE_Q -> rows = k; BASE_BSK -> rows = |Bsk|(k); BASE_KEY -> rows = k + nsp. */
+long sealhip_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
+                                        uint32_t base);
+long sealhip_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base);
+long sealhip_inverse_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
+                                                uint32_t base);
+long sealhip_inverse_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
+                                           uint32_t base);
+
+/* ---------------------------------------------------------------- L2: coefficient-wise (util/polyarithsmallmod.{h,cpp})
+   operands: count polynomials x rows x N of the given base/level; result may alias an operand. */
+long sealhip_dyadic_product_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count,
+                                     uint32_t k, uint32_t base, uint64_t *result);
+long sealhip_multiply_poly_scalar_coeffmod(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k,
+                                           uint32_t base, uint64_t scalar, uint64_t *result);
+long sealhip_add_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count, uint32_t k,
+                               uint32_t base, uint64_t *result);
+long sealhip_sub_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, const uint64_t *b, size_t count, uint32_t k,
+                               uint32_t base, uint64_t *result);
+long sealhip_negate_poly_coeffmod(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k, uint32_t base,
+                                  uint64_t *result);
+
+/* ---------------------------------------------------------------- L2: RNSTool (util/rns.cpp:731-1068), level k, batched
+   shapes per item:  fastbconv_m_tilde k x N -> (|Bsk|+1) x N;  sm_mrq (|Bsk|+1) x N -> |Bsk| x N;
+   fast_floor (k+|Bsk|) x N -> |Bsk| x N;  fastbconv_sk |Bsk| x N -> k x N;
+   divide_and_round_q_last[_ntt]_inplace: k x N in place (last row clobbered). */
+long sealhip_fastbconv_m_tilde(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
+long sealhip_sm_mrq(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
+long sealhip_fast_floor(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
+long sealhip_fastbconv_sk(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
+long sealhip_divide_and_round_q_last_inplace(sealhip_context *ctx, uint32_t k, uint64_t *data, size_t count);
+long sealhip_divide_and_round_q_last_ntt_inplace(sealhip_context *ctx, uint32_t k, uint64_t *data, size_t count);
+
+/* ---------------------------------------------------------------- L2: Galois (util/galois.cpp) */
+long sealhip_galois_elt_from_step(const sealhip_context *ctx, int32_t step, uint32_t *galois_elt);
+/* coefficient form (galois.cpp:144-186) / NTT form (:188-214); in and out must not alias */
+long sealhip_apply_galois(sealhip_context *ctx, const uint64_t *in, size_t count, uint32_t k, uint32_t galois_elt,
+                          uint64_t *out);
+long sealhip_apply_galois_ntt(sealhip_context *ctx, const uint64_t *in, size_t count, uint32_t k,
+                              uint32_t galois_elt, uint64_t *out);
+
+/* ---------------------------------------------------------------- hybrid key switch (multi_special_primes.cpp, evaluator.cpp:2259-2368) */
+/* Key in the K1 layout of KeyGenerator::generate_one_kswitch_key (keygenerator.cpp:325-369):
+   n_digits x 2 x n_key x N uint64 (digit, component, key-level row, coefficient). The key is copied
+   to the device (from host memory if from_host != 0) and stays resident until destroyed. */
+long sealhip_kswitch_key_load(sealhip_context *ctx, const uint64_t *key, uint32_t n_digits, int32_t from_host,
+                              sealhip_kswitch_key **out);
+long sealhip_kswitch_key_destroy(sealhip_context *ctx, sealhip_kswitch_key *key);
+/* modup_rns (multi_special_primes.cpp:151-185): ext is count x (k+nsp) x N; the rows of bundle
+   `src_bundle_index` are the input, every other row is overwritten. */
+long sealhip_modup_rns(sealhip_context *ctx, uint32_t k, uint32_t src_bundle_index, uint64_t *ext, size_t count);
+/* rescale_special_rns_inplace (multi_special_primes.cpp:237-304): poly is count x (k+nsp) x N */
+long sealhip_rescale_special_rns_inplace(sealhip_context *ctx, uint32_t k, uint64_t *poly, size_t count);
+/* switch_key_inplace: ct is count x 2 x k x N (updated in place), target count x k x N */
+long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, const uint64_t *target, size_t count,
+                                const sealhip_kswitch_key *key);
+
+/* ---------------------------------------------------------------- L4: Evaluator operations (native/src/seal/evaluator.h)
+   All are batched over `count` independent ciphertexts at level k. */
+/* Evaluator::multiply (evaluator.cpp:235-527): a (size_a polys), b (size_b polys) -> out (size_a+size_b-1).
+   BFV: coefficient form in/out (bfv_multiply); CKKS: NTT form (ckks_multiply). out must not alias a or b. */
+long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a,
+                                const uint64_t *b, uint32_t size_b, size_t count, uint64_t *out);
+/* Evaluator::square (evaluator.cpp:529-770) */
+long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, size_t count,
+                              uint64_t *out);
+/* Evaluator::relinearize (evaluator.cpp:772-827): ct has `size` polys and is reduced in place to 2;
+   relin_keys[i] is the key at RelinKeys::get_index(i + 2) (relinkeys.h:61-68). The batch stride stays
+   size x k x N. */
+long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                   const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys);
+/* Evaluator::mod_switch_to_next (evaluator.cpp:996-1036): BFV divide-and-round, CKKS drop.
+   out: count x size x (k-1) x N */
+long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                          size_t count, uint64_t *out);
+/* Evaluator::rescale_to_next (evaluator.cpp:1090-1126), CKKS only */
+long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                       size_t count, uint64_t *out);
+/* Evaluator::apply_galois_inplace (evaluator.cpp:1841-1943): ct is count x 2 x k x N */
+long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *ct, size_t count,
+                                    uint32_t galois_elt, const sealhip_kswitch_key *galois_key);
+/* Evaluator::transform_to_ntt_inplace / transform_from_ntt_inplace (evaluator.cpp:1746-1839) */
+long sealhip_evaluator_transform_to_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count);
+long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size,
+                                          size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEALHIP_H */

@@ -1,0 +1,535 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs,
+against the committed golden digests of the compiled reference, and -- at full BASELINE sizes --
+through size-independent properties. Bar: bit-exact (all arithmetic is unsigned 64-bit integer)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DIG = json.load(open(os.path.join(HERE, "golden", "survey_digests.json")))
+L = O.lib()
+
+
+def h(a):
+    return "%016x" % O.fnv(a)
+
+
+@pytest.fixture(scope="module")
+def sealhip():
+    import sealhip as S
+
+    assert S.num_devices() >= 1, "no HIP device visible: the engine has no CPU fallback"
+    return S
+
+
+def rand_rows(rng, moduli, n, full_range=False):
+    rows = []
+    for p in moduli:
+        if full_range:
+            rows.append(rng.integers(0, 2**64, size=n, dtype=np.uint64))
+        else:
+            rows.append(rng.integers(0, p, size=n, dtype=np.uint64))
+    return np.stack(rows)
+
+
+# ------------------------------------------------------------------ NTT
+NTT_CASES = [(3, [20]), (4, [30, 30]), (5, [25]), (6, [30] * 4), (8, [40, 41]), (10, [50] * 3), (12, [36, 36, 37]),
+             (13, [59, 58]), (14, [50] * 6), (15, [55] * 8), (16, [50] * 3)]
+
+
+@pytest.mark.parametrize("logn,bits", NTT_CASES, ids=lambda x: str(x))
+def test_ntt_all_variants_vs_oracle(sealhip, logn, bits):
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, bits) + O.get_primes(n, 59 if logn < 16 else 58, 1)
+    k = len(mods) - 1
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    tabs = [O.Tables(logn, p) for p in mods[:k]]
+    rng = np.random.default_rng(1000 + logn)
+    count = 3
+    x = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+    variants = [
+        ("fwd_lazy", ctx.ntt_negacyclic_harvey_lazy, lambda r, t: L.ref_ntt_forward_lazy(O.ptr(r), C.byref(t.t), 0)),
+        ("fwd", ctx.ntt_negacyclic_harvey, lambda r, t: L.ref_ntt_forward(O.ptr(r), C.byref(t.t), 0)),
+        ("inv_lazy", ctx.inverse_ntt_negacyclic_harvey_lazy, lambda r, t: L.ref_ntt_inverse_lazy(O.ptr(r), C.byref(t.t))),
+        ("inv", ctx.inverse_ntt_negacyclic_harvey, lambda r, t: L.ref_ntt_inverse(O.ptr(r), C.byref(t.t))),
+    ]
+    for name, gpu_fn, ref_fn in variants:
+        buf = ctx.upload(x)
+        gpu_fn(buf, count, k)
+        got = buf.download(x.shape)
+        exp = x.copy()
+        for c in range(count):
+            for i in range(k):
+                ref_fn(exp[c, i], tabs[i])
+        assert np.array_equal(got, exp), name
+    # round trip on the device
+    buf = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey(buf, count, k)
+    ctx.inverse_ntt_negacyclic_harvey(buf, count, k)
+    assert np.array_equal(buf.download(x.shape), x)
+
+
+@pytest.mark.parametrize("row", DIG["ntt_digests"], ids=lambda r: "logn%d_k%d" % (r["logn"], len(r["bits"])))
+def test_ntt_golden_digests(sealhip, row):
+    """The survey's digests of util::ntt_negacyclic_harvey & co. from the compiled reference."""
+    logn, k = row["logn"], len(row["bits"])
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, row["bits"])
+    x = O.SplitMix(0x5EA1 + 1000 * logn + k).fill(k, n, mods)
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods + O.get_primes(n, 40, 1), 1, 0)
+    f = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey(f, 1, k)
+    fwd = f.download(x.shape)
+    assert h(fwd) == row["fwd"]
+    lz = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey_lazy(lz, 1, k)
+    assert h(lz.download()) == row["fwd_lazy"]
+    dy = ctx.alloc(x.size)
+    ctx.dyadic_product_coeffmod(f, f, 1, k, dy)
+    assert h(dy.download()) == row["dyadic_sq"]
+    iv = ctx.upload(x)
+    ctx.inverse_ntt_negacyclic_harvey(iv, 1, k)
+    assert h(iv.download()) == row["inv"]
+
+
+@pytest.mark.parametrize("logn", [6, 12, 13, 15])
+def test_ntt_bsk_base_60bit_wraparound(sealhip, logn):
+    """on the 60-bit Bsk primes the reference's uncorrected lazy butterflies wrap mod 2^64;
+    PARITY must reproduce the wrapped words, for canonical and for arbitrary 64-bit inputs."""
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, [40, 40, 41])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, mods, 1, 65537)
+    k = 2
+    nb = ctx.bsk_size(k)
+    ref = O.RefContext(1, logn, mods, 1, 65537)
+    rt = ref.rns_tool(k)
+    bsk = [int(rt.contents.Bsk[i].value) for i in range(nb)]
+    rng = np.random.default_rng(7 + logn)
+    wrapped = False
+    for full in (False, True):
+        x = rand_rows(rng, bsk, n, full_range=full)
+        if not full:
+            x[0, :] = np.uint64(bsk[0] - 1)  # worst case growth
+        buf = ctx.upload(x)
+        ctx.ntt_negacyclic_harvey_lazy(buf, 1, k, sealhip.BASE_BSK)
+        got = buf.download(x.shape)
+        exp, strict = x.copy(), x.copy()
+        for i in range(nb):
+            L.ref_ntt_forward_lazy(O.ptr(exp[i]), C.byref(rt.contents.Bsk_ntt[i]), 0)
+            L.ref_ntt_forward(O.ptr(strict[i]), C.byref(rt.contents.Bsk_ntt[i]), 1)
+        assert np.array_equal(got, exp)
+        canon = exp.copy()
+        for i in range(nb):
+            p = np.uint64(bsk[i])
+            canon[i] = canon[i] % p
+        if not np.array_equal(canon, strict):
+            wrapped = True
+    if logn >= 12:
+        assert wrapped, "expected the 60-bit overflow regime to be exercised"
+
+
+def test_strict_mode_forward_matches_math(sealhip):
+    logn = 12
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, [40, 40, 41])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, mods, 1, 65537, mode=sealhip.MODE_STRICT)
+    k = 2
+    nb = ctx.bsk_size(k)
+    ref = O.RefContext(1, logn, mods, 1, 65537, mode=1)
+    rt = ref.rns_tool(k)
+    bsk = [int(rt.contents.Bsk[i].value) for i in range(nb)]
+    x = rand_rows(np.random.default_rng(3), bsk, n)
+    buf = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey_lazy(buf, 1, k, sealhip.BASE_BSK)
+    exp = x.copy()
+    for i in range(nb):
+        L.ref_ntt_forward_lazy(O.ptr(exp[i]), C.byref(rt.contents.Bsk_ntt[i]), 1)
+    assert np.array_equal(buf.download(x.shape), exp)
+
+
+# ------------------------------------------------------------------ coefficient-wise
+def test_poly_ops_vs_oracle(sealhip):
+    logn, n = 10, 1 << 10
+    mods = O.coeff_modulus_create(n, [59, 30, 45, 20])
+    k = 3
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    rng = np.random.default_rng(11)
+    count = 2
+    a = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+    b = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+    lazy_a = np.stack([rand_rows(rng, mods[:k], n, full_range=True) for _ in range(count)])
+    da, db, dl, out = ctx.upload(a), ctx.upload(b), ctx.upload(lazy_a), ctx.alloc(a.size)
+    ms = [O.modulus(p) for p in mods[:k]]
+
+    def ref2(fn, x, y):
+        r = np.empty_like(x)
+        for c in range(count):
+            for i in range(k):
+                fn(O.ptr(x[c, i]), O.ptr(y[c, i]), n, C.byref(ms[i]), O.ptr(r[c, i]))
+        return r
+
+    ctx.dyadic_product_coeffmod(dl, db, count, k, out)  # lazy (any 64-bit) first operand, like the NTT outputs
+    assert np.array_equal(out.download(a.shape), ref2(L.ref_dyadic_product_coeffmod, lazy_a, b))
+    ctx.add_poly_coeffmod(da, db, count, k, out)
+    assert np.array_equal(out.download(a.shape), ref2(L.ref_add_poly_coeffmod, a, b))
+    ctx.sub_poly_coeffmod(da, db, count, k, out)
+    assert np.array_equal(out.download(a.shape), ref2(L.ref_sub_poly_coeffmod, a, b))
+    ctx.negate_poly_coeffmod(da, count, k, out)
+    r = np.empty_like(a)
+    for c in range(count):
+        for i in range(k):
+            L.ref_negate_poly_coeffmod(O.ptr(a[c, i]), n, C.byref(ms[i]), O.ptr(r[c, i]))
+    assert np.array_equal(out.download(a.shape), r)
+    scalar = 0x123456789ABCDEF
+    ctx.multiply_poly_scalar_coeffmod(dl, count, k, scalar, out)
+    for c in range(count):
+        for i in range(k):
+            L.ref_multiply_poly_scalar_coeffmod(O.ptr(lazy_a[c, i]), n, scalar, C.byref(ms[i]), O.ptr(r[c, i]))
+    assert np.array_equal(out.download(a.shape), r)
+    # in place (result aliases an operand), as Evaluator uses them
+    ctx.add_poly_coeffmod(da, db, count, k, da)
+    assert np.array_equal(da.download(a.shape), ref2(L.ref_add_poly_coeffmod, a, b))
+
+
+def test_galois_vs_oracle_and_kat(sealhip):
+    kat = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))["galois"]
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, 3, [17, 97], 1, 0)
+    x = np.array(kat["in"], dtype=np.uint64)
+    d, o = ctx.upload(x), ctx.alloc(8)
+    ctx.apply_galois(d, 1, 1, kat["elt"], o)
+    assert [int(v) for v in o.download()] == kat["apply_galois"]
+    ctx.apply_galois_ntt(d, 1, 1, kat["elt"], o)
+    assert [int(v) for v in o.download()] == kat["apply_galois_ntt"]
+    with pytest.raises(ValueError):
+        ctx.apply_galois(d, 1, 1, 4, o)
+    with pytest.raises(ValueError):
+        ctx.apply_galois(d, 1, 1, 3, d)
+    for row in DIG["galois_elts"]:
+        n = 1 << row["logn"]
+        c2 = sealhip.Context(sealhip.SCHEME_CKKS, row["logn"], O.coeff_modulus_create(n, [30, 30]), 1, 0)
+        assert c2.galois_elt_from_step(1) == row["step1"]
+        assert c2.galois_elt_from_step(0) == row["step0"]
+        assert c2.galois_elt_from_step(-1) == row["stepm1"]
+    logn, n = 11, 1 << 11
+    mods = O.coeff_modulus_create(n, [50, 50, 50])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, mods, 1, 65537)
+    x = np.stack([rand_rows(np.random.default_rng(5), mods[:2], n) for _ in range(2)])
+    d, o = ctx.upload(x), ctx.alloc(x.size)
+    for elt in (5, 3, 2 * n - 1, ctx.galois_elt_from_step(-3)):
+        e1, e2 = np.empty_like(x), np.empty_like(x)
+        for c in range(2):
+            for i in range(2):
+                m = O.modulus(mods[i])
+                L.ref_apply_galois(O.ptr(x[c, i]), logn, elt, C.byref(m), O.ptr(e1[c, i]))
+                L.ref_apply_galois_ntt(O.ptr(x[c, i]), logn, elt, O.ptr(e2[c, i]))
+        ctx.apply_galois(d, 2, 2, elt, o)
+        assert np.array_equal(o.download(x.shape), e1)
+        ctx.apply_galois_ntt(d, 2, 2, elt, o)
+        assert np.array_equal(o.download(x.shape), e2)
+
+
+# ------------------------------------------------------------------ RNSTool + key-switch pieces: survey digests
+UD = DIG["unit_digests"]
+
+
+@pytest.mark.parametrize("ci", range(len(UD["columns"])), ids=[c["name"] for c in UD["columns"]])
+def test_unit_functions_golden_digests(sealhip, ci):
+    """Every hot-path L2 function on the survey's inputs, against the compiled reference's digests."""
+    col = UD["columns"][ci]
+    logn, nsp = col["logn"], col["nsp"]
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, col["bits"])
+    nk = len(kmods)
+    k = nk - nsp
+    bfv = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, nsp, col["t"])
+    ckks = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, nsp, 0)
+    nb = bfv.bsk_size(k)
+    bsk = [int(v) for v in bfv.debug_rns_constants(k, 0)]
+    q = kmods[:k]
+    sm = O.SplitMix(0)
+    res = {}
+    sm.set(0xF00D0001)
+    out = bfv.alloc((nb + 1) * n)
+    bfv.fastbconv_m_tilde(k, bfv.upload(sm.fill(k, n, q)), 1, out)
+    res["fastbconv_m_tilde"] = h(out.download())
+    sm.set(0xF00D0002)
+    out = bfv.alloc(nb * n)
+    bfv.sm_mrq(k, bfv.upload(sm.fill(nb + 1, n, bsk + [1 << 32])), 1, out)
+    res["sm_mrq"] = h(out.download())
+    sm.set(0xF00D0003)
+    bfv.fast_floor(k, bfv.upload(sm.fill(k + nb, n, q + bsk)), 1, out)
+    res["fast_floor"] = h(out.download())
+    sm.set(0xF00D0004)
+    out = bfv.alloc(k * n)
+    bfv.fastbconv_sk(k, bfv.upload(sm.fill(nb, n, bsk)), 1, out)
+    res["fastbconv_sk"] = h(out.download())
+    sm.set(0xF00D0005)
+    d = bfv.upload(sm.fill(k, n, q))
+    bfv.divide_and_round_q_last_inplace(k, d, 1)
+    res["divide_and_round_q_last_inplace"] = h(d.download((k, n))[: k - 1])
+    sm.set(0xF00D0006)
+    d = bfv.upload(sm.fill(k, n, q))
+    bfv.divide_and_round_q_last_ntt_inplace(k, d, 1)
+    res["divide_and_round_q_last_ntt_inplace"] = h(d.download((k, n))[: k - 1])
+    sm.set(0xF00D0007)
+    d, o = bfv.upload(sm.fill(1, n, q[:1])), bfv.alloc(n)
+    bfv.apply_galois(d, 1, 1, 5, o)
+    res["apply_galois"] = h(o.download())
+    bfv.apply_galois_ntt(d, 1, 1, 5, o)
+    res["apply_galois_ntt"] = h(o.download())
+    for key, b in (("modup_rns_first", 0), ("modup_rns_last", col["modup_last_bundle"])):
+        ext = np.zeros((k + nsp, n), dtype=np.uint64)
+        sm.set(0xF00D0008 + b)
+        r0 = b * nsp
+        r1 = min(r0 + nsp, k)
+        ext[r0:r1] = sm.fill(r1 - r0, n, kmods[r0:r1])
+        d = bfv.upload(ext)
+        bfv.modup_rns(k, b, d, 1)
+        res[key] = h(d.download())
+    for key, c in (("rescale_special_ckks", ckks), ("rescale_special_bfv", bfv)):
+        sm.set(0xF00D0010 + (1 if c is ckks else 0))
+        d = c.upload(sm.fill(k + nsp, n, kmods[:k] + kmods[nk - nsp:]))
+        c.rescale_special_rns_inplace(k, d, 1)
+        res[key] = h(d.download((k + nsp, n))[:k])
+    for key, val in res.items():
+        assert val == UD[key][ci], key
+
+
+def test_rns_tool_batched_vs_oracle(sealhip):
+    """Batched, ragged level (k < k_first) and a non-trivial |B| = k+1 case against the oracle."""
+    logn, n = 9, 1 << 9
+    kmods = O.coeff_modulus_create(n, [59, 59, 59, 59, 40])
+    t = (1 << 58) + 1  # large plain modulus -> base_B_size bump (rns.cpp:568-573)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ref = O.RefContext(1, logn, kmods, 1, t)
+    rng = np.random.default_rng(21)
+    count = 3
+    for k in (4, 3, 2):
+        rt = ref.rns_tool(k)
+        nb = rt.contents.Bsk_size
+        assert ctx.bsk_size(k) == nb
+        if k == 4:
+            assert rt.contents.B_size == k + 1
+        bsk = [int(rt.contents.Bsk[i].value) for i in range(nb)]
+        q = kmods[:k]
+        x = np.stack([rand_rows(rng, q, n) for _ in range(count)])
+        o = ctx.alloc(count * (nb + 1) * n)
+        ctx.fastbconv_m_tilde(k, ctx.upload(x), count, o)
+        exp = np.zeros((count, nb + 1, n), dtype=np.uint64)
+        for c in range(count):
+            L.ref_fastbconv_m_tilde(rt, O.ptr(x[c]), O.ptr(exp[c]))
+        assert np.array_equal(o.download(exp.shape), exp)
+        o2 = ctx.alloc(count * nb * n)
+        ctx.sm_mrq(k, o, count, o2)
+        exp2 = np.zeros((count, nb, n), dtype=np.uint64)
+        for c in range(count):
+            L.ref_sm_mrq(rt, O.ptr(exp[c]), O.ptr(exp2[c]))
+        assert np.array_equal(o2.download(exp2.shape), exp2)
+        y = np.stack([rand_rows(rng, q + bsk, n) for _ in range(count)])
+        ctx.fast_floor(k, ctx.upload(y), count, o2)
+        exp3 = np.zeros((count, nb, n), dtype=np.uint64)
+        for c in range(count):
+            L.ref_fast_floor(rt, O.ptr(y[c]), O.ptr(exp3[c]))
+        assert np.array_equal(o2.download(exp3.shape), exp3)
+        o4 = ctx.alloc(count * k * n)
+        ctx.fastbconv_sk(k, o2, count, o4)
+        exp4 = np.zeros((count, k, n), dtype=np.uint64)
+        for c in range(count):
+            L.ref_fastbconv_sk(rt, O.ptr(exp3[c]), O.ptr(exp4[c]))
+        assert np.array_equal(o4.download(exp4.shape), exp4)
+
+
+# ------------------------------------------------------------------ end to end: the reference's op chain
+@pytest.mark.parametrize("row", DIG["end_to_end"], ids=lambda r: "cfg%d" % r["cfg"])
+def test_end_to_end_golden_digests(sealhip, row):
+    """multiply -> relinearize -> mod_switch/rescale (+ rotate_vector for CKKS) through the C ABI on the
+    survey's synthetic inputs must reproduce the digests of the compiled reference,
+    including the F2/F3 behaviour of the BFV configs."""
+    inp = synth.end_to_end_inputs(row)
+    n, k, logn = inp["n"], inp["k"], inp["logn"]
+    scheme = row["scheme"]
+    ctx = sealhip.Context(scheme, logn, inp["kmods"], row["nsp"], row["t"])
+    ev = sealhip.Evaluator(ctx)
+    got = {}
+    rk = sealhip.KSwitchKeys(ctx, inp["rk"])
+    if scheme == 2:
+        gk = sealhip.KSwitchKeys(ctx, inp["gk"])
+        c = ctx.upload(inp["a"])
+        ev.rotate_vector_inplace(c, k, 1, 1, {ctx.galois_elt_from_step(1): gk})
+        got["rotate"] = h(c.download())
+    a, b = ctx.upload(inp["a"]), ctx.upload(inp["b"])
+    c = ctx.alloc(3 * k * n)
+    ev.multiply(a, 2, b, 2, k, 1, c)
+    got["mul"] = h(c.download())
+    ev.relinearize_inplace(c, 3, k, 1, [rk])
+    c2 = c.download((3, k, n))[:2].copy()
+    got["relin"] = h(c2)
+    o = ctx.alloc(2 * (k - 1) * n)
+    d2 = ctx.upload(c2)
+    if scheme == 1:
+        ev.mod_switch_to_next(d2, 2, k, 1, o)
+        got["modswitch"] = h(o.download())
+    else:
+        ev.rescale_to_next(d2, 2, k, 1, o)
+        got["rescale"] = h(o.download())
+    assert got == row["digests"]
+
+
+@pytest.mark.parametrize("scheme,logn,bits,nsp,t", [
+    (1, 10, [40, 40, 40, 40, 41], 2, 65537),      # BFV, two special primes, ragged last bundle (k=3, nsp=2)
+    (2, 10, [45, 45, 45, 45, 45, 46], 3, 0),       # CKKS, three special primes
+    (2, 11, [40, 40, 40, 41], 1, 0),
+])
+def test_batched_chain_vs_oracle_all_levels(sealhip, scheme, logn, bits, nsp, t):
+    """A batch of independent ciphertexts through multiply/relinearize/mod-switch/apply_galois at the first
+    level and one level below, item by item against the oracle."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    nk = len(kmods)
+    ctx = sealhip.Context(scheme, logn, kmods, nsp, t)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t)
+    rng = np.random.default_rng(99)
+    k_first = nk - nsp
+    d_full = (k_first + nsp - 1) // nsp
+    key = np.stack([rand_rows(rng, kmods * 2, n).reshape(2, nk, n) for _ in range(d_full)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    count = 3
+    for k in (k_first, k_first - 1):
+        if k < 2:
+            continue
+        a = np.stack([rand_rows(rng, kmods[:k] * 2, n).reshape(2, k, n) for _ in range(count)])
+        b = np.stack([rand_rows(rng, kmods[:k] * 2, n).reshape(2, k, n) for _ in range(count)])
+        out = ctx.alloc(count * 3 * k * n)
+        ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, out)
+        exp = np.zeros((count, 3, k, n), dtype=np.uint64)
+        mul = L.ref_bfv_multiply if scheme == 1 else L.ref_ckks_multiply
+        for c in range(count):
+            assert mul(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(b[c]), 2, O.ptr(exp[c])) == 0
+        assert np.array_equal(out.download(exp.shape), exp), "multiply k=%d" % k
+        sq = ctx.alloc(count * 3 * k * n)
+        ev.square(ctx.upload(a), 2, k, count, sq)
+        exps = np.zeros((count, 3, k, n), dtype=np.uint64)
+        for c in range(count):
+            assert mul(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(a[c]), 2, O.ptr(exps[c])) == 0
+        assert np.array_equal(sq.download(exps.shape), exps), "square k=%d" % k
+        ev.relinearize_inplace(out, 3, k, count, [dkey])
+        keys = (C.c_void_p * 1)(key.ctypes.data)
+        for c in range(count):
+            assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp[c]), 3, keys) == 0
+        got = out.download(exp.shape)
+        assert np.array_equal(got[:, :2], exp[:, :2]), "relinearize k=%d" % k
+        c2 = np.ascontiguousarray(exp[:, :2])
+        o = ctx.alloc(count * 2 * (k - 1) * n)
+        exp_ms = np.zeros((count, 2, k - 1, n), dtype=np.uint64)
+        if scheme == 1:
+            ev.mod_switch_to_next(ctx.upload(c2), 2, k, count, o)
+        else:
+            ev.rescale_to_next(ctx.upload(c2), 2, k, count, o)
+        for c in range(count):
+            assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(c2[c]), 2, O.ptr(exp_ms[c])) == 0
+        assert np.array_equal(o.download(exp_ms.shape), exp_ms), "mod switch k=%d" % k
+        if scheme == 2:
+            ev.mod_switch_to_next(ctx.upload(c2), 2, k, count, o)
+            assert np.array_equal(o.download(exp_ms.shape), c2[:, :, : k - 1]), "mod_switch_drop k=%d" % k
+        elt = ctx.galois_elt_from_step(-2)
+        g = ctx.upload(c2)
+        ev.apply_galois_inplace(g, k, count, elt, dkey)
+        expg = c2.copy()
+        for c in range(count):
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(expg[c]), elt, O.ptr(key)) == 0
+        assert np.array_equal(g.download(expg.shape), expg), "apply_galois k=%d" % k
+
+
+def test_strict_mode_chain_vs_oracle(sealhip):
+    """STRICT = Harvey-corrected butterflies + NTT'd in-bundle rows, against the oracle's STRICT."""
+    logn, n = 12, 1 << 12
+    kmods = O.coeff_modulus_create(n, [36, 36, 37])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433, mode=sealhip.MODE_STRICT)
+    par = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=786433, mode=1)
+    rng = np.random.default_rng(5)
+    k = 2
+    key = np.stack([rand_rows(rng, kmods * 2, n).reshape(2, 3, n) for _ in range(2)])
+    a = rand_rows(rng, kmods[:k] * 2, n).reshape(1, 2, k, n)
+    b = rand_rows(rng, kmods[:k] * 2, n).reshape(1, 2, k, n)
+    exp = np.zeros((1, 3, k, n), dtype=np.uint64)
+    assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a), 2, O.ptr(b), 2, O.ptr(exp)) == 0
+    out, outp = ctx.alloc(exp.size), par.alloc(exp.size)
+    sealhip.Evaluator(ctx).multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, 1, out)
+    sealhip.Evaluator(par).multiply(par.upload(a), 2, par.upload(b), 2, k, 1, outp)
+    assert np.array_equal(out.download(exp.shape), exp)
+    assert not np.array_equal(outp.download(exp.shape), exp), "PARITY and STRICT must differ in the F2 regime"
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp), 3, keys) == 0
+    sealhip.Evaluator(ctx).relinearize_inplace(out, 3, k, 1, [sealhip.KSwitchKeys(ctx, key)])
+    assert np.array_equal(out.download(exp.shape)[:, :2], exp[:, :2])
+
+
+# ------------------------------------------------------------------ full BASELINE sizes: properties
+@pytest.mark.parametrize("logn,bits,count", [(14, [50] * 6, 64), (15, [55] * 8, 32), (16, [50] * 4, 8)])
+def test_full_size_ntt_properties(sealhip, logn, bits, count):
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, bits)
+    k = len(mods) - 1
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    rng = np.random.default_rng(logn)
+    x = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+    y = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+    dx, dy, ds = ctx.upload(x), ctx.upload(y), ctx.alloc(x.size)
+    ctx.add_poly_coeffmod(dx, dy, count, k, ds)
+    for d in (dx, dy, ds):
+        ctx.ntt_negacyclic_harvey(d, count, k)
+    # linearity: NTT(x + y) == NTT(x) + NTT(y)
+    chk = ctx.alloc(x.size)
+    ctx.add_poly_coeffmod(dx, dy, count, k, chk)
+    assert np.array_equal(chk.download(), ds.download())
+    fx = dx.download(x.shape)
+    for i in range(k):
+        assert fx[:, i].max() < mods[i]
+    # spot-check one item against the oracle
+    tabs = [O.Tables(logn, p) for p in mods[:k]]
+    c = count - 1
+    exp = x[c].copy()
+    for i in range(k):
+        L.ref_ntt_forward(O.ptr(exp[i]), C.byref(tabs[i].t), 0)
+    assert np.array_equal(fx[c], exp)
+    # round trip
+    ctx.inverse_ntt_negacyclic_harvey(dx, count, k)
+    assert np.array_equal(dx.download(x.shape), x)
+
+
+def test_edge_cases_and_errors(sealhip):
+    logn, n = 8, 1 << 8
+    mods = O.coeff_modulus_create(n, [40, 40, 41])
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    buf = ctx.upload(np.zeros((2, 2, n), dtype=np.uint64))
+    ctx.ntt_negacyclic_harvey(buf, 0, 2)  # empty batch is a no-op
+    ctx.ntt_negacyclic_harvey(buf, 2, 2)  # all-zero input
+    assert not buf.download().any()
+    with pytest.raises(ValueError):
+        ctx.ntt_negacyclic_harvey(buf, 1, 9)  # level out of range
+    with pytest.raises(ValueError):
+        ctx.ntt_negacyclic_harvey(buf, 1, 2, sealhip.BASE_BSK)  # no Bsk base in CKKS
+    with pytest.raises(sealhip.LogicError):
+        ctx.fastbconv_m_tilde(2, buf, 1, buf)  # BFV-only function
+    with pytest.raises(ValueError):
+        ev.rescale_to_next(buf, 2, 1, 1, buf)  # end of chain
+    with pytest.raises(TypeError):
+        ctx.ntt_negacyclic_harvey(0, 1, 2)  # null pointer -> E_POINTER
+    bfv = sealhip.Context(sealhip.SCHEME_BFV, logn, mods, 1, 257)
+    with pytest.raises(ValueError):
+        sealhip.Evaluator(bfv).rescale_to_next(buf, 2, 2, 1, buf)  # unsupported for BFV
+    with pytest.raises(ValueError):
+        sealhip.Context(sealhip.SCHEME_CKKS, logn, [17, 19], 1, 0)  # not NTT-friendly primes
+    with pytest.raises(ValueError):
+        sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 3, 0)  # #moduli <= n_special_primes

@@ -1,0 +1,133 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol that
+include/sealhip.h declares, the tables/constants it regenerates equal the oracle's (and therefore the
+reference's), errors map to the reference's HRESULT convention, and nothing computes without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sealhip
+
+    return sealhip
+
+
+def test_library_exports_every_declared_symbol(S):
+    header = open(os.path.join(ROOT, "include", "sealhip.h")).read()
+    declared = set(re.findall(r"\b(sealhip_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    lib = C.CDLL(S.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(S.SYMBOLS), declared ^ set(S.SYMBOLS)
+
+
+@pytest.mark.parametrize("logn,bits", [(3, [20, 21]), (6, [30] * 4), (12, [36, 36, 37]), (15, [55, 50])])
+def test_ntt_tables_equal_oracle(S, logn, bits):
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, bits)
+    ctx = S.Context(S.SCHEME_BFV, logn, mods, 1, 65537, device=-1)
+    aux = O.get_primes(n, 60, len(mods) + 3)
+    names = ["root_powers", "scaled_root_powers", "inv_root_powers", "scaled_inv_root_powers"]
+    for idx, p in enumerate(mods + aux):
+        if idx == len(mods) + 1:
+            with pytest.raises(ValueError):
+                ctx.debug_ntt_table(idx, 0)  # gamma has no tables
+            continue
+        t = O.Tables(logn, p)
+        for kind, name in enumerate(names):
+            assert np.array_equal(ctx.debug_ntt_table(idx, kind), t.arr(name)), (p, name)
+
+
+@pytest.mark.parametrize("logn,bits,t", [(6, [30] * 5, 65537), (12, [36, 36, 37], 786433), (9, [59, 59, 59, 59, 40], (1 << 58) + 1)])
+def test_rns_constants_equal_oracle(S, logn, bits, t):
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, bits)
+    ctx = S.Context(S.SCHEME_BFV, logn, mods, 1, t, device=-1)
+    ref = O.RefContext(1, logn, mods, 1, t)
+    for k in range(1, len(mods)):
+        rt = ref.rns_tool(k).contents
+        nb, B = rt.Bsk_size, rt.B_size
+        arr = lambda p, cnt: [int(p[i]) for i in range(cnt)]
+        assert [int(v) for v in ctx.debug_rns_constants(k, 0)] == [int(rt.Bsk[i].value) for i in range(nb)]
+        assert [int(v) for v in ctx.debug_rns_constants(k, 1)] == arr(rt.inv_prod_q_mod_Bsk, nb)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 2)] == arr(rt.prod_q_mod_Bsk, nb)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 3)] == arr(rt.inv_m_tilde_mod_Bsk, nb)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 4)] == arr(rt.prod_B_mod_q, k)
+        if k > 1:
+            assert [int(v) for v in ctx.debug_rns_constants(k, 5)] == arr(rt.inv_q_last_mod_q, k - 1)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 6)] == [
+            rt.inv_prod_q_mod_m_tilde, rt.inv_prod_B_mod_m_sk, rt.m_sk.value, rt.gamma.value]
+        assert [int(v) for v in ctx.debug_rns_constants(k, 7)] == arr(rt.q_to_Bsk.matrix, nb * k)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 8)] == arr(rt.B_to_q.matrix, k * B)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 9)] == arr(rt.q_to_Bsk.inv_punct, k)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 10)] == arr(rt.B_to_q.inv_punct, B)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 11)] == arr(rt.q_to_m_tilde.matrix, k)
+        assert [int(v) for v in ctx.debug_rns_constants(k, 12)] == arr(rt.B_to_m_sk.matrix, B)
+        assert ctx.bsk_size(k) == nb
+
+
+def test_no_cpu_fallback_and_error_mapping(S):
+    mods = O.coeff_modulus_create(64, [30, 30, 30])
+    ctx = S.Context(S.SCHEME_CKKS, 6, mods, 1, 0, device=-1)
+    assert ctx.k_first == 2
+    # a host-only context never computes: std::logic_error -> COR_E_INVALIDOPERATION
+    with pytest.raises(S.LogicError):
+        ctx.ntt_negacyclic_harvey(0x1000, 1, 2)
+    with pytest.raises(S.LogicError):
+        S.Evaluator(ctx).multiply(0x1000, 2, 0x2000, 2, 2, 1, 0x3000)
+    with pytest.raises(S.LogicError):
+        ctx.alloc(16)
+    # E_POINTER before anything else, like the reference's IfNullRet
+    with pytest.raises(TypeError):
+        ctx.ntt_negacyclic_harvey(0, 1, 2)
+    # invalid parameters -> E_INVALIDARG (std::invalid_argument)
+    for bad in (
+        dict(scheme=3, log_n=6, key_moduli=mods),
+        dict(scheme=S.SCHEME_CKKS, log_n=2, key_moduli=mods),
+        dict(scheme=S.SCHEME_CKKS, log_n=17, key_moduli=mods),
+        dict(scheme=S.SCHEME_CKKS, log_n=6, key_moduli=mods, n_special_primes=3),
+        dict(scheme=S.SCHEME_CKKS, log_n=6, key_moduli=[mods[0], mods[0], mods[1]]),
+        dict(scheme=S.SCHEME_CKKS, log_n=6, key_moduli=[97, 193]),  # 193 = 1 mod 128 but 97 is not
+        dict(scheme=S.SCHEME_BFV, log_n=6, key_moduli=mods, plain_modulus=0),
+    ):
+        with pytest.raises(ValueError):
+            S.Context(device=-1, **bad)
+    if S.num_devices() == 0:
+        with pytest.raises(RuntimeError):
+            S.Context(S.SCHEME_CKKS, 6, mods, 1, 0, device=0)  # no HIP device -> E_UNEXPECTED, never a CPU path
+
+
+def test_galois_elt_from_step_and_naf(S):
+    mods = O.coeff_modulus_create(64, [30, 30])
+    ctx = S.Context(S.SCHEME_CKKS, 6, mods, 1, 0, device=-1)
+    L = O.lib()
+    for step in range(-31, 32):
+        assert ctx.galois_elt_from_step(step) == L.ref_galois_elt_from_step(64, step, None)
+    with pytest.raises(ValueError):
+        ctx.galois_elt_from_step(32)
+    # util/numth.h:22-42
+    assert S._naf(3) == [-1, 4] and S._naf(-3) == [1, -4] and S._naf(8) == [8] and S._naf(7) == [-1, 8]
+
+
+def test_multi_rank_sharding_plan_gloo():
+    """bench.py shards the batch of independent ciphertexts contiguously over ranks with no data-path
+    collective; the N>1 path is exercised on CPU with world_size 2 over gloo."""
+    import subprocess
+    import sys
+
+    script = os.path.join(ROOT, "tests", "_gloo_shard_worker.py")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+         "127.0.0.1", "--master-port", "29571", script],
+        capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "SHARD_OK" in out.stdout
