@@ -46,7 +46,10 @@ namespace sealhip
             const int t = ps.t, c = ps.c, b_lo = ps.b_lo, logn = ps.logn;
             const int tile = blockIdx.x & ((1 << (logn - t)) - 1);
             const size_t row = blockIdx.x >> (logn - t);
-            const PrimeDev P = primes[map.prime[row % map.rows]];
+            const unsigned short pid = map.prime[row % map.rows];
+            if (pid == kSkipRow)
+                return; // block-uniform: this row is not part of the transform (e.g. in-bundle rows)
+            const PrimeDev P = primes[pid];
             const u64 p = P.p, two_p = P.two_p;
             u64 *rowp = data + (row << logn);
             const int cmask = (1 << c) - 1;
@@ -175,7 +178,10 @@ namespace sealhip
             const size_t row = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
             if (row >= nrows)
                 return;
-            const PrimeDev P = primes[map.prime[row % map.rows]];
+            const unsigned short pid = map.prime[row % map.rows];
+            if (pid == kSkipRow)
+                return;
+            const PrimeDev P = primes[pid];
             const u64 p = P.p, two_p = P.two_p;
             u64 *x = data + (row << logn);
             const int N = 1 << logn;

@@ -48,7 +48,7 @@ NTT_CASES = [(3, [20]), (4, [30, 30]), (5, [25]), (6, [30] * 4), (8, [40, 41]), 
 @pytest.mark.parametrize("logn,bits", NTT_CASES, ids=lambda x: str(x))
 def test_ntt_all_variants_vs_oracle(sealhip, logn, bits):
     n = 1 << logn
-    mods = O.coeff_modulus_create(n, bits) + O.get_primes(n, 59 if logn < 16 else 58, 1)
+    mods = O.coeff_modulus_create(n, bits) + O.get_primes(n, 57, 1)
     k = len(mods) - 1
     ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
     tabs = [O.Tables(logn, p) for p in mods[:k]]
