@@ -236,9 +236,12 @@ def main():
         roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None, "traffic": None}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from separate rocprofv3 --pmc passes (see profiles/README.md)
+    if os.path.exists(tpath) and roof.get("rows_per_launch"):
+        # HBM bytes per RNS row per launch, measured with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # (tools/summarize_prof.py, gfx950 correction applied), scaled to this run's rows per launch
         try:
-            roof["traffic"] = json.load(open(tpath)).get(roof["kernel"])
+            per_row = json.load(open(tpath))[roof["kernel"]]["hbm_bytes_per_row_per_launch"]
+            roof["traffic"] = per_row * roof["rows_per_launch"]
         except Exception:
             pass
 
@@ -271,7 +274,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = max(1, min(16, os.cpu_count() or 1))
-        cpu = cpu_baseline(threads, 2)
+        cpu = cpu_baseline(threads, 6)
         cpu["gpu_over_cpu_allcore"] = value / cpu["value"]
 
     if rank == 0:
