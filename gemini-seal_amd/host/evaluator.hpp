@@ -1,0 +1,284 @@
+// evaluator.hpp -- C++ host adapter with seal::Evaluator's method names over the sealhip C ABI.
+//
+// seal::Evaluator is non-virtual and non-copyable (native/src/seal/evaluator.h:1316-1322), so this is not a
+// subclass: it is a class with the same method names and argument meaning for the hot-path operations
+// (evaluator.h:246-298 multiply/square, :344-371 relinearize, :396-430 mod_switch_to_next, :565-583
+// rescale_to_next, :902-947 transform_to/from_ntt, :984-1021 apply_galois, :1201-1239 rotate_vector), doing
+// the same metadata checks on the host and forwarding raw pointers to the ABI. It is a template over the
+// ciphertext type so that it compiles both against seal::Ciphertext (where the reference headers exist) and
+// against the plain sealhip::HostCiphertext below (everywhere else, e.g. the GPU box).
+//
+// Required of CT: data() -> uint64_t*, size(), coeff_modulus_size(), poly_modulus_degree(), is_ntt_form()
+// (assignable), resize_raw(size, coeff_modulus_size). For seal::Ciphertext the last one is
+//   ct.resize(context, parms_id_of_level, size)  -- see INTEGRATION.md.
+//
+// Exceptions mirror the reference: std::invalid_argument / std::logic_error (evaluator.cpp:238-271).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sealhip.h"
+
+namespace sealhip_host
+{
+    inline void throw_on(long hr)
+    {
+        if (hr == SEALHIP_S_OK)
+            return;
+        const std::string msg = sealhip_last_error_string();
+        if (hr == SEALHIP_E_INVALIDARG || hr == SEALHIP_E_POINTER)
+            throw std::invalid_argument(msg);
+        if (hr == SEALHIP_COR_E_INVALIDOPERATION)
+            throw std::logic_error(msg);
+        if (hr == SEALHIP_E_OUTOFMEMORY)
+            throw std::bad_alloc();
+        throw std::runtime_error(msg);
+    }
+
+    // Plain stand-in with the reference's layout (ciphertext.h:359-368): size x k x N uint64, row-major.
+    struct HostCiphertext
+    {
+        std::vector<std::uint64_t> words;
+        std::size_t size_ = 0, k_ = 0, n_ = 0;
+        bool ntt_form_ = false;
+        double scale_ = 1.0;
+        std::uint64_t *data() { return words.data(); }
+        const std::uint64_t *data() const { return words.data(); }
+        std::size_t size() const { return size_; }
+        std::size_t coeff_modulus_size() const { return k_; }
+        std::size_t poly_modulus_degree() const { return n_; }
+        bool &is_ntt_form() { return ntt_form_; }
+        bool is_ntt_form() const { return ntt_form_; }
+        double &scale() { return scale_; }
+        void resize_raw(std::size_t size, std::size_t k)
+        {
+            // like IntArray::resize: keeps the leading words, zero-fills the rest (ciphertext.cpp:84-133)
+            std::vector<std::uint64_t> next(size * k * n_, 0);
+            const std::size_t polys = size < size_ ? size : size_;
+            const std::size_t rows = k < k_ ? k : k_;
+            for (std::size_t s = 0; s < polys; s++)
+                for (std::size_t r = 0; r < rows; r++)
+                    for (std::size_t c = 0; c < n_; c++)
+                        next[(s * k + r) * n_ + c] = words[(s * k_ + r) * n_ + c];
+            words.swap(next);
+            size_ = size;
+            k_ = k;
+        }
+    };
+
+    class Context
+    {
+    public:
+        explicit Context(const sealhip_params &p) : scheme_(p.scheme), n_(std::size_t(1) << p.log_n)
+        {
+            throw_on(sealhip_context_create(&p, &ctx_));
+        }
+        ~Context()
+        {
+            if (ctx_)
+                sealhip_context_destroy(ctx_);
+        }
+        Context(const Context &) = delete;
+        Context &operator=(const Context &) = delete;
+        sealhip_context *get() const { return ctx_; }
+        std::uint32_t scheme() const { return scheme_; }
+        std::size_t n() const { return n_; }
+
+    private:
+        sealhip_context *ctx_ = nullptr;
+        std::uint32_t scheme_;
+        std::size_t n_;
+    };
+
+    // device staging of one host object
+    class Staged
+    {
+    public:
+        Staged(const Context &c, std::size_t words) : c_(c), words_(words)
+        {
+            throw_on(sealhip_malloc(c.get(), words * 8, &d_));
+        }
+        ~Staged()
+        {
+            if (d_)
+                sealhip_free(c_.get(), d_);
+        }
+        void up(const std::uint64_t *h, std::size_t words) { throw_on(sealhip_memcpy_h2d(c_.get(), d_, h, words * 8)); }
+        void down(std::uint64_t *h, std::size_t words) { throw_on(sealhip_memcpy_d2h(c_.get(), h, d_, words * 8)); }
+        std::uint64_t *ptr() { return static_cast<std::uint64_t *>(d_); }
+
+    private:
+        const Context &c_;
+        void *d_ = nullptr;
+        std::size_t words_;
+    };
+
+    class KSwitchKeys // one key of RelinKeys / GaloisKeys (kswitchkeys.h:92-130), resident on the device
+    {
+    public:
+        KSwitchKeys(const Context &c, const std::uint64_t *host_key, std::uint32_t n_digits) : c_(c)
+        {
+            throw_on(sealhip_kswitch_key_load(c.get(), host_key, n_digits, 1, &key_));
+        }
+        ~KSwitchKeys()
+        {
+            if (key_)
+                sealhip_kswitch_key_destroy(c_.get(), key_);
+        }
+        KSwitchKeys(const KSwitchKeys &) = delete;
+        const sealhip_kswitch_key *get() const { return key_; }
+
+    private:
+        const Context &c_;
+        sealhip_kswitch_key *key_ = nullptr;
+    };
+
+    template <class CT>
+    class Evaluator
+    {
+    public:
+        explicit Evaluator(const Context &context) : ctx_(context) {}
+
+        // Evaluator::multiply_inplace (evaluator.cpp:235-272)
+        void multiply_inplace(CT &encrypted1, const CT &encrypted2)
+        {
+            check_pair(encrypted1, encrypted2);
+            const bool bfv = ctx_.scheme() == SEALHIP_SCHEME_BFV;
+            if (bfv && (encrypted1.is_ntt_form() || encrypted2.is_ntt_form()))
+                throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form"); // :276-279
+            if (!bfv && !(encrypted1.is_ntt_form() && encrypted2.is_ntt_form()))
+                throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form"); // :449-452
+            const std::size_t k = encrypted1.coeff_modulus_size(), n = ctx_.n();
+            const std::size_t s1 = encrypted1.size(), s2 = encrypted2.size(), dest = s1 + s2 - 1;
+            Staged a(ctx_, s1 * k * n), b(ctx_, s2 * k * n), o(ctx_, dest * k * n);
+            a.up(encrypted1.data(), s1 * k * n);
+            b.up(encrypted2.data(), s2 * k * n);
+            throw_on(sealhip_evaluator_multiply(ctx_.get(), std::uint32_t(k), a.ptr(), std::uint32_t(s1), b.ptr(),
+                                                std::uint32_t(s2), 1, o.ptr()));
+            encrypted1.resize_raw(dest, k); // :324 / :484
+            o.down(encrypted1.data(), dest * k * n);
+        }
+
+        void square_inplace(CT &encrypted)
+        {
+            const CT copy = encrypted;
+            multiply_inplace(encrypted, copy); // same canonical residues as bfv_square / ckks_square (:560-770)
+        }
+
+        // Evaluator::relinearize_inplace (evaluator.cpp:772-827); relin_keys[i] = key of get_index(i + 2)
+        void relinearize_inplace(CT &encrypted, const std::vector<const KSwitchKeys *> &relin_keys)
+        {
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n(), size = encrypted.size();
+            if (size < 2)
+                throw std::invalid_argument("encrypted is not valid for encryption parameters");
+            if (relin_keys.size() + 2 < size)
+                throw std::invalid_argument("not enough relinearization keys"); // :793-796
+            if (size == 2)
+                return;
+            std::vector<const sealhip_kswitch_key *> raw;
+            for (auto *rk : relin_keys)
+                raw.push_back(rk ? rk->get() : nullptr);
+            Staged c(ctx_, size * k * n);
+            c.up(encrypted.data(), size * k * n);
+            throw_on(sealhip_evaluator_relinearize(ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1,
+                                                   raw.data(), std::uint32_t(raw.size())));
+            c.down(encrypted.data(), size * k * n);
+            encrypted.resize_raw(2, k); // :819
+        }
+
+        // Evaluator::mod_switch_to_next_inplace (evaluator.cpp:996-1036)
+        void mod_switch_to_next_inplace(CT &encrypted) { switch_level(encrypted, false); }
+        // Evaluator::rescale_to_next_inplace (evaluator.cpp:1090-1126); the caller updates scale() /= q_last (:889-890)
+        void rescale_to_next_inplace(CT &encrypted) { switch_level(encrypted, true); }
+
+        void transform_to_ntt_inplace(CT &encrypted)
+        {
+            if (encrypted.is_ntt_form())
+                throw std::invalid_argument("encrypted is already in NTT form"); // :1759-1762
+            transform(encrypted, true);
+            encrypted.is_ntt_form() = true;
+        }
+        void transform_from_ntt_inplace(CT &encrypted_ntt)
+        {
+            if (!encrypted_ntt.is_ntt_form())
+                throw std::invalid_argument("encrypted_ntt is not in NTT form"); // :1807-1810
+            transform(encrypted_ntt, false);
+            encrypted_ntt.is_ntt_form() = false;
+        }
+
+        // Evaluator::apply_galois_inplace (evaluator.cpp:1841-1943)
+        void apply_galois_inplace(CT &encrypted, std::uint32_t galois_elt, const KSwitchKeys &galois_key)
+        {
+            if (encrypted.size() > 2)
+                throw std::invalid_argument("encrypted size must be 2"); // :1884-1887
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n();
+            Staged c(ctx_, 2 * k * n);
+            c.up(encrypted.data(), 2 * k * n);
+            throw_on(sealhip_evaluator_apply_galois(ctx_.get(), std::uint32_t(k), c.ptr(), 1, galois_elt,
+                                                    galois_key.get()));
+            c.down(encrypted.data(), 2 * k * n);
+        }
+
+        // Evaluator::rotate_vector_inplace / rotate_rows_inplace -> rotate_internal (evaluator.cpp:1945-2000)
+        void rotate_vector_inplace(CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (steps == 0)
+                return;
+            std::uint32_t elt = 0;
+            throw_on(sealhip_galois_elt_from_step(ctx_.get(), steps, &elt));
+            auto it = galois_keys.find(elt);
+            if (it != galois_keys.end())
+                return apply_galois_inplace(encrypted, elt, *it->second);
+            std::vector<int> naf; // util/numth.h:22-42
+            bool neg = steps < 0;
+            int v = neg ? -steps : steps;
+            for (int i = 0; v; i++)
+            {
+                int zi = (v % 2) ? 2 - (v % 4) : 0;
+                v = (v - zi) / 2;
+                if (zi)
+                    naf.push_back((neg ? -zi : zi) * (1 << i));
+            }
+            if (naf.size() == 1)
+                throw std::invalid_argument("Galois key not present"); // :1985-1988
+            for (int s : naf)
+                if (std::size_t(s < 0 ? -s : s) != (ctx_.n() >> 1))
+                    rotate_vector_inplace(encrypted, s, galois_keys);
+        }
+
+    private:
+        void check_pair(const CT &a, const CT &b) const
+        {
+            if (a.poly_modulus_degree() != ctx_.n() || b.poly_modulus_degree() != ctx_.n() || a.size() < 2 || b.size() < 2)
+                throw std::invalid_argument("encrypted1 is not valid for encryption parameters"); // :238-245
+            if (a.coeff_modulus_size() != b.coeff_modulus_size())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch"); // :246-249
+        }
+        void switch_level(CT &ct, bool rescale)
+        {
+            const std::size_t k = ct.coeff_modulus_size(), n = ctx_.n(), size = ct.size();
+            if (k < 2)
+                throw std::invalid_argument("end of modulus switching chain reached"); // :1005-1008
+            Staged c(ctx_, size * k * n), o(ctx_, size * (k - 1) * n);
+            c.up(ct.data(), size * k * n);
+            throw_on((rescale ? sealhip_evaluator_rescale_to_next : sealhip_evaluator_mod_switch_to_next)(
+                ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, o.ptr()));
+            ct.resize_raw(size, k - 1); // :879
+            o.down(ct.data(), size * (k - 1) * n);
+        }
+        void transform(CT &ct, bool to_ntt)
+        {
+            const std::size_t k = ct.coeff_modulus_size(), n = ctx_.n(), size = ct.size();
+            Staged c(ctx_, size * k * n);
+            c.up(ct.data(), size * k * n);
+            throw_on((to_ntt ? sealhip_evaluator_transform_to_ntt : sealhip_evaluator_transform_from_ntt)(
+                ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1));
+            c.down(ct.data(), size * k * n);
+        }
+        const Context &ctx_;
+    };
+} // namespace sealhip_host

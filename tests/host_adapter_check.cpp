@@ -1,0 +1,70 @@
+// Compile-and-link check of the C++ host adapter (gemini-seal_amd/host/evaluator.hpp). With a GPU it also runs one
+// multiply through the adapter and prints a digest that the Python test compares with the oracle.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../gemini-seal_amd/host/evaluator.hpp"
+
+using namespace sealhip_host;
+
+static std::uint64_t splitmix(std::uint64_t &s)
+{
+    std::uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv)
+{
+    // cfg1 of BASELINE.json: BFV N=4096, {36,36,37}
+    const std::uint64_t mods[3] = { 68719230977ULL, 68719403009ULL, 137438822401ULL };
+    sealhip_params p{ SEALHIP_SCHEME_BFV, 12, 3, 1, mods, 786433, SEALHIP_MODE_PARITY, argc > 1 ? std::atoi(argv[1]) : -1 };
+    try
+    {
+        Context ctx(p);
+        if (p.device < 0)
+        {
+            std::printf("host-only context ok\n");
+            return 0;
+        }
+        const std::size_t n = 4096, k = 2;
+        std::uint64_t state = 0xC0FFEE + 1;
+        // same fill order as the survey generator (keys first), SURVEY Appendix B.2
+        std::vector<std::uint64_t> key(2 * 2 * 3 * n);
+        for (std::size_t d = 0; d < 2; d++)
+            for (std::size_t l = 0; l < 2; l++)
+                for (std::size_t r = 0; r < 3; r++)
+                    for (std::size_t c = 0; c < n; c++)
+                        key[((d * 2 + l) * 3 + r) * n + c] = splitmix(state) % mods[r];
+        HostCiphertext a, b;
+        for (HostCiphertext *ct : { &a, &b })
+        {
+            ct->n_ = n;
+            ct->resize_raw(2, k);
+            for (std::size_t s = 0; s < 2; s++)
+                for (std::size_t r = 0; r < k; r++)
+                    for (std::size_t c = 0; c < n; c++)
+                        ct->words[(s * k + r) * n + c] = splitmix(state) % mods[r];
+        }
+        Evaluator<HostCiphertext> ev(ctx);
+        KSwitchKeys rk(ctx, key.data(), 2);
+        ev.multiply_inplace(a, b);
+        ev.relinearize_inplace(a, { &rk });
+        ev.mod_switch_to_next_inplace(a);
+        std::uint64_t h = 0xcbf29ce484222325ULL;
+        for (std::uint64_t w : a.words)
+            for (int i = 0; i < 8; i++)
+            {
+                h ^= (w >> (8 * i)) & 0xff;
+                h *= 0x100000001b3ULL;
+            }
+        std::printf("modswitch digest %016llx\n", (unsigned long long)h);
+    }
+    catch (const std::exception &e)
+    {
+        std::printf("exception: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

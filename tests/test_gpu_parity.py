@@ -533,3 +533,17 @@ def test_edge_cases_and_errors(sealhip):
         sealhip.Context(sealhip.SCHEME_CKKS, logn, [17, 19], 1, 0)  # not NTT-friendly primes
     with pytest.raises(ValueError):
         sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 3, 0)  # #moduli <= n_special_primes
+
+
+def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
+    """multiply -> relinearize -> mod_switch_to_next through the C++ adapter (host buffers in, host buffers out)
+    on the survey's cfg1 inputs reproduces the compiled reference's digest."""
+    import subprocess
+
+    import test_host
+
+    exe = test_host._build_adapter(tmp_path)
+    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = [r for r in DIG["end_to_end"] if r["cfg"] == 1][0]["digests"]["modswitch"]
+    assert "modswitch digest " + want in out.stdout, out.stdout

@@ -131,3 +131,21 @@ def test_multi_rank_sharding_plan_gloo():
         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "SHARD_OK" in out.stdout
+
+
+def _build_adapter(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "host_adapter_check")
+    libdir = os.path.join(ROOT, "gemini-seal_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "host_adapter_check.cpp"),
+                           "-L" + libdir, "-lsealhip", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_host_adapter_compiles_and_links(tmp_path):
+    """gemini-seal_amd/host/evaluator.hpp (the seal::Evaluator-shaped C++ adapter) builds against the ABI."""
+    import subprocess
+
+    out = subprocess.run([_build_adapter(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "host-only context ok" in out.stdout, out.stdout + out.stderr
