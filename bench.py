@@ -217,21 +217,25 @@ def main():
     dominant = max(prof, key=lambda tkey: prof[tkey]["ms"])
     shares = {tkey: round(v["ms"] / total_ms, 4) for tkey, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # launches per full row transform at N=2^15: the single-pass forward kernel completes a transform per launch,
+    # the tiled pass kernel needs two launches (each then counts for half of the 16*N algorithmic bytes)
+    PASSES = {"ntt_fwd_half": 1, "ntt_fwd_pass": 2, "ntt_inv_pass": 2}
+
     def ntt_roofline(tag):
         v = prof.get(tag)
         if not v or not v["launches"]:
             return None
         rows_per_launch = v["units"] / v["launches"]
         avg_s = v["ms"] / v["launches"] / 1e3
-        # 16*N bytes per row transform; an N=2^15 transform is two pass launches, each doing half
-        alg_bytes = rows_per_launch * 16 * n / 2
+        # 16*N bytes per row transform
+        alg_bytes = rows_per_launch * 16 * n / PASSES[tag]
         ach = alg_bytes / avg_s / 1e9
         return {"kernel": tag, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
                 "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches": v["launches"], "share_of_step_kernel_time": v["ms"] / total_ms}
 
-    roof = ntt_roofline(dominant) if dominant.startswith("ntt_") else ntt_roofline("ntt_fwd_pass")
+    roof = ntt_roofline(dominant) if dominant in PASSES else (ntt_roofline("ntt_fwd_half") or ntt_roofline("ntt_fwd_pass"))
     if roof is None:
         roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None, "traffic": None}
@@ -261,7 +265,7 @@ def main():
     nprof = ctx.profile_fetch()
     ctx.profile_enable(False)
     ntt_rows = P * k * reps
-    ntt_kernel_s = nprof["ntt_fwd_pass"]["ms"] / 1e3
+    ntt_kernel_s = sum(v["ms"] for tkey, v in nprof.items() if tkey.startswith("ntt_fwd")) / 1e3
     ntt = {
         "forward_ntt_per_s": world * ntt_rows / ntt_dt,
         "forward_ntt_per_s_kernel_time": ntt_rows / ntt_kernel_s,

@@ -222,6 +222,16 @@ long sealhip_synchronize(sealhip_context *ctx)
     return guarded([&] {
         Engine &e = device_engine(ctx);
         SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        if (e.d_tickets)
+        {
+            unsigned flag = 0;
+            SEALHIP_CHECK(hipMemcpy(&flag, e.d_tickets, sizeof(flag), hipMemcpyDeviceToHost));
+            if (flag)
+            {
+                SEALHIP_CHECK(hipMemset(e.d_tickets, 0, sizeof(flag)));
+                throw std::runtime_error("forward NTT: sibling workgroup wait timed out; results of that launch are invalid");
+            }
+        }
     });
 }
 

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace sealhip
@@ -56,6 +57,7 @@ namespace sealhip
         e->k_first = n_key - nsp;
         e->t = scheme == 1 ? t : 0;
         e->mode_strict = strict;
+        e->use_half_kernel = std::getenv("SEALHIP_NTT_TWO_PASS") == nullptr;
         e->device = device;
         e->key_moduli.assign(key_moduli, key_moduli + n_key);
         for (int i = 0; i < n_key; i++)
@@ -112,6 +114,32 @@ namespace sealhip
         return e;
     }
 
+    unsigned *Engine::ntt_tickets(std::size_t nrows) const
+    {
+        const std::size_t need = nrows + 1;
+        if (need > tickets_cap)
+        {
+            if (d_tickets)
+            {
+                if (hipStreamSynchronize(stream) != hipSuccess || hipFree(d_tickets) != hipSuccess)
+                    return nullptr;
+                d_tickets = nullptr;
+                tickets_cap = 0;
+            }
+            std::size_t cap = 1;
+            while (cap < need)
+                cap <<= 1;
+            if (hipMalloc(reinterpret_cast<void **>(&d_tickets), cap * sizeof(unsigned)) != hipSuccess)
+                return nullptr;
+            tickets_cap = cap;
+            if (hipMemsetAsync(d_tickets, 0, sizeof(unsigned), stream) != hipSuccess) // sticky timeout flag
+                return nullptr;
+        }
+        if (hipMemsetAsync(d_tickets + 1, 0, nrows * sizeof(unsigned), stream) != hipSuccess)
+            return nullptr;
+        return d_tickets;
+    }
+
     void Engine::prof_begin(const char *tag, double units) const
     {
         ProfRecord r{ tag, nullptr, nullptr, units };
@@ -143,6 +171,8 @@ namespace sealhip
             (void)hipFree(p);
         if (ws)
             (void)hipFree(ws);
+        if (d_tickets)
+            (void)hipFree(d_tickets);
         if (own_stream && stream)
             (void)hipStreamDestroy(stream);
     }

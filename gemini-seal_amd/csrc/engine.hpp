@@ -119,6 +119,7 @@ namespace sealhip
         std::size_t n = 0;
         u64 t = 0;
         bool mode_strict = false;
+        bool use_half_kernel = true; // single-pass forward NTT for logn >= 14 (SEALHIP_NTT_TWO_PASS=1 disables)
         int device = -1; // -1: host-only
         std::vector<u64> key_moduli, aux_primes;
         std::vector<HostNttTables> tables; // per prime id
@@ -135,6 +136,10 @@ namespace sealhip
         mutable std::vector<ProfRecord> prof;
         void prof_begin(const char *tag, double units) const;
         void prof_end() const;
+        // per-row tickets of the single-pass forward NTT (word 0 = timeout flag, words 1.. = row counters)
+        mutable unsigned *d_tickets = nullptr;
+        mutable std::size_t tickets_cap = 0;
+        unsigned *ntt_tickets(std::size_t nrows) const;
         // workspace arena (stream-ordered reuse)
         void *ws = nullptr;
         std::size_t ws_bytes = 0, ws_used = 0;

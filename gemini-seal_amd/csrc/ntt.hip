@@ -21,6 +21,8 @@
 //
 // LDS image: index l is stored at l + (l >> 4) (one pad word per 16), which makes both the
 // stride-1 and the stride-16 access patterns of the rounds bank-conflict free for ds_read_b64.
+#include <cstdlib>
+
 #include "engine.hpp"
 
 namespace sealhip
@@ -235,6 +237,473 @@ namespace sealhip
                 }
         }
 
+        // ----------------------------------------------------------------------------------------
+        // Single-pass forward NTT for logn = 14..16 ("half-row" kernel).
+        //
+        // After the top butterfly layer (gap N/2) the two halves of a row are independent sub-transforms.
+        // One workgroup owns one half (2^T coefficients, T = logn-1): it reads BOTH halves with 16-byte
+        // coalesced loads, applies the top layer on the fly (the sibling workgroup of the other half
+        // recomputes the same products: +1/logn of the multiplies, and its reads of the shared half are
+        // L2 hits when the two run on the same XCD, which the block -> (row, half) map arranges), and then
+        // finishes all T remaining layers on chip: 32 coefficients per lane (5 index bits), radix-16 register
+        // rounds, LDS exchanges between rounds. The LDS holds only half of the tile, so every exchange runs
+        // in two phases keyed on index bit 0, which stays in the registers through all rounds ("sticky"):
+        // coefficients with bit0 = p only ever move between slots with slot-bit0 = p.
+        // HBM traffic: one read of the row (+ the sibling re-read, mostly from L2) and one write.
+        //
+        // Arrangement R (R = 1..3: compute rounds on index bits [T-4R, T-4R+4); R = 4: final round on the
+        // remaining T-12 low bits): slot bit 0 <-> index bit 0 always; the other slot bits and the lane id
+        // cover the rest as two runs of consecutive index bits.
+        template <int T, int R>
+        struct Arr
+        {
+            static constexpr int beta = R <= 3 ? T - 4 * R : 0;
+            static constexpr int f = T - 12; // low bits left for the final round (incl. bit 0)
+            static constexpr int slot_bit(int w)
+            {
+                if (w == 0)
+                    return 0;
+                if (R <= 3)
+                    return beta + (w - 1);
+                if (w < f)
+                    return w;
+                return T - (5 - f) + (w - f); // fillers: the top index bits
+            }
+            static constexpr int low_start = R <= 3 ? 1 : f;
+            static constexpr int low_len = R <= 3 ? beta - 1 : T - 5;
+            static constexpr int high_start = beta + 4;
+            __device__ static __forceinline__ int tid_index(int tid)
+            {
+                int v = (tid & ((1 << low_len) - 1)) << low_start;
+                if (R <= 3 && low_len < T - 5)
+                    v |= (tid >> low_len) << high_start;
+                return v;
+            }
+            static constexpr int slot_index(int s)
+            {
+                int r = 0;
+                for (int w = 0; w < 5; w++)
+                    if ((s >> w) & 1)
+                        r |= 1 << slot_bit(w);
+                return r;
+            }
+            // contribution of the slot bits above w to the twiddle index of a butterfly on slot bit w
+            static constexpr int tw_offset(int s, int w)
+            {
+                int r = 0;
+                for (int v = w + 1; v < 5; v++)
+                    if ((s >> v) & 1)
+                        r |= 1 << (slot_bit(v) - slot_bit(w) - 1);
+                return r;
+            }
+        };
+
+        __host__ __device__ constexpr int hpad(int e)
+        {
+            return e + 2 * (e >> 5);
+        }
+
+        template <int T, int RA, int RB>
+        __device__ __forceinline__ void h_exchange(u64 (&x)[32], u64 *lds, int tid)
+        {
+            const int pa = hpad(Arr<T, RA>::tid_index(tid) >> 1);
+            const int pb = hpad(Arr<T, RB>::tid_index(tid) >> 1);
+#pragma unroll
+            for (int phase = 0; phase < 2; phase++)
+            {
+#pragma unroll
+                for (int s = 0; s < 32; s++)
+                    if ((s & 1) == phase)
+                        lds[pa + hpad(Arr<T, RA>::slot_index(s) >> 1)] = x[s];
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < 32; s++)
+                    if ((s & 1) == phase)
+                        x[s] = lds[pb + hpad(Arr<T, RB>::slot_index(s) >> 1)];
+                __syncthreads();
+            }
+        }
+
+        // Twiddle tables are read-only for the lifetime of a context: load them through the global
+        // (address_space 1) or, when the index is wave-uniform, the constant (address_space 4, scalar cache)
+        // address space instead of the generic pointer stored in PrimeDev (which would give flat loads).
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(1))) u64x2 *tw_global_t;
+        typedef const __attribute__((address_space(4))) u64x2 *tw_const_t;
+
+        // all butterflies of one layer (slot bit W) on the 32 registers; PARITY/STRICT as in ntt_pass_kernel.
+        // UNIFORM: the twiddle index does not depend on the lane (round 1) -> scalar loads.
+        template <int T, int R, int W, bool STRICT, bool UNIFORM>
+        __device__ __forceinline__ void h_layer(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+                                                u64 two_p, u64 neg_p, u64 rdp)
+        {
+            constexpr int gb = Arr<T, R>::slot_bit(W);
+            const int tb = (N + jb) >> (gb + 1);
+            constexpr int bit = 1 << W;
+#pragma unroll
+            for (int s = 0; s < 32; s++)
+            {
+                if (s & bit)
+                    continue;
+                u64x2 Wv;
+                if (UNIFORM)
+                    Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
+                else
+                    Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
+                u64 u = x[s];
+                if (STRICT)
+                    u = u >= two_p ? u - two_p : u;
+                else if (gb == 0)
+                    u = barrett_lazy(u, rdp, p); // ForwardLazyLast, ntt.cpp:254-261
+                const u64 v = mulmod_lazy(x[s | bit], Wv.x, Wv.y, p);
+                x[s] = u + v; // ForwardLazy, ntt.cpp:245-252
+                x[s | bit] = u - v + two_p;
+            }
+        }
+
+        template <int T, int R, bool STRICT, bool UNIFORM>
+        __device__ __forceinline__ void h_round(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+                                                u64 two_p, u64 neg_p, u64 rdp)
+        {
+            h_layer<T, R, 4, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
+            h_layer<T, R, 3, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
+            h_layer<T, R, 2, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
+            h_layer<T, R, 1, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
+        }
+
+        // load both halves of the row and apply the top layer (gap N/2, twiddle entry 1) on the fly
+        template <int T, bool STRICT, int HALF>
+        __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
+                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p)
+        {
+            const int jb = Arr<T, 1>::tid_index(tid);
+            const u64x2 W1 = ((tw_const_t)tw)[1];
+#pragma unroll
+            for (int batch = 0; batch < 4; batch++)
+            {
+                ulonglong2 lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int s = (batch * 4 + i) * 2;
+                    const int idx = jb + Arr<T, 1>::slot_index(s);
+                    lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
+                    hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int s = (batch * 4 + i) * 2;
+                    u64 u0 = lo[i].x, u1 = lo[i].y;
+                    if (STRICT)
+                    {
+                        u0 = u0 >= two_p ? u0 - two_p : u0;
+                        u1 = u1 >= two_p ? u1 - two_p : u1;
+                    }
+                    const u64 v0 = mulmod_lazy(hi[i].x, W1.x, W1.y, 0 - neg_p);
+                    const u64 v1 = mulmod_lazy(hi[i].y, W1.x, W1.y, 0 - neg_p);
+                    x[s] = HALF ? u0 - v0 + two_p : u0 + v0;
+                    x[s + 1] = HALF ? u1 - v1 + two_p : u1 + v1;
+                }
+            }
+        }
+
+        template <int LOGN, bool STRICT>
+        __global__ __launch_bounds__(1 << (LOGN - 6), (LOGN == 16 ? 4 : 4)) void ntt_fwd_half_kernel(
+            u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
+            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag)
+        {
+            constexpr int T = LOGN - 1;
+            constexpr int N = 1 << LOGN;
+            extern __shared__ u64 lds[];
+            const int tid = threadIdx.x;
+            // blocks b and b+8 share an XCD under round-robin dispatch (speed only): pair the two halves there
+            const unsigned bid = blockIdx.x;
+            const int half = (bid >> 3) & 1;
+            const std::size_t row = static_cast<std::size_t>(bid >> 4) * 8 + (bid & 7);
+            if (row >= nrows)
+                return;
+            const unsigned short pid = map.prime[row % map.rows];
+            if (pid == kSkipRow)
+                return;
+            const PrimeDev P = primes[pid];
+            const u64 p = P.p, two_p = P.two_p, rdp = P.rdp;
+            const u64 *tw = P.fwd;
+            u64 *rowp = data + (row << LOGN);
+            u64 x[32];
+
+            // ---- load both halves, top layer on the fly, arrangement 1 (block-uniform branch on the half)
+            const u64 neg_p = 0 - p;
+            if (half)
+                h_load_top<T, STRICT, 1>(x, rowp, tw, tid, two_p, neg_p);
+            else
+                h_load_top<T, STRICT, 0>(x, rowp, tw, tid, two_p, neg_p);
+            // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
+            // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
+            // wave bumps the row's counter once its loads have landed in registers; before its store phase
+            // it waits until the counter shows all waves of both workgroups. Only a "finished reading" signal crosses workgroups, so
+            // relaxed agent-scope atomics suffice (no payload is published).
+            // The signal is sent after the first LDS exchange: its barriers are only passed once every wave of
+            // the workgroup has consumed all of its loaded values in round 1, so no extra wait or barrier is needed.
+            const int gbase = half << T;
+            // round 1: every lane index bit lies below the processed bits -> block-uniform twiddles
+            h_round<T, 1, STRICT, true>(x, tw, gbase, N, p, two_p, neg_p, rdp);
+            h_exchange<T, 1, 2>(x, lds, tid);
+            if (tid == 0 && tickets)
+                __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h_round<T, 2, STRICT, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p, neg_p, rdp);
+            h_exchange<T, 2, 3>(x, lds, tid);
+            h_round<T, 3, STRICT, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p, neg_p, rdp);
+            h_exchange<T, 3, 4>(x, lds, tid);
+            {
+                const int jb = gbase + Arr<T, 4>::tid_index(tid);
+                constexpr int f = T - 12;
+                if (f >= 3)
+                    h_layer<T, 4, 2, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
+                if (f >= 2)
+                    h_layer<T, 4, 1, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
+                h_layer<T, 4, 0, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
+            }
+            // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
+            if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
+            {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&tickets[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
+                {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 24))
+                    {
+                        // never observed; do not hang the device: flag the launch as failed and fall through
+                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
+            //  that both workgroups of the row have finished reading)
+            // ---- store (arrangement 4: runs of 2^f consecutive coefficients per lane), optional canonicalisation
+            const bool canon = (flags & kNttCanonical) != 0;
+            const int jb = gbase + Arr<T, 4>::tid_index(tid);
+#pragma unroll
+            for (int s = 0; s < 32; s += 2)
+            {
+                ulonglong2 v;
+                v.x = x[s];
+                v.y = x[s + 1];
+                if (canon)
+                {
+                    v.x = v.x >= two_p ? v.x - two_p : v.x;
+                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    v.x = v.x >= p ? v.x - p : v.x;
+                    v.y = v.y >= p ? v.y - p : v.y;
+                }
+                *reinterpret_cast<ulonglong2 *>(rowp + jb + Arr<T, 4>::slot_index(s)) = v;
+            }
+        }
+
+        // ----------------------------------------------------------------------------------------
+        // Single-pass inverse NTT for logn = 14..16: the mirror image of ntt_fwd_half_kernel. The
+        // Gentleman-Sande layers on index bits 0..T-1 only pair coefficients inside one half of the row, so
+        // a workgroup transforms its half entirely on chip (final arrangement first, then rounds 3, 2, 1,
+        // ascending bits) and stores lazy values in [0, 2p). The top layer (gap N/2, with n^{-1} folded
+        // in, ntt.cpp:393-402) needs both halves and is applied by ntt_inv_top_kernel, a pure streaming
+        // pass (or, inside the pipelines, by the consumer kernel).
+        template <int T, int R, int W>
+        __device__ __forceinline__ void h_layer_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+                                                    u64 two_p)
+        {
+            constexpr int gb = Arr<T, R>::slot_bit(W);
+            const int tb = (N + jb) >> (gb + 1);
+            constexpr int bit = 1 << W;
+#pragma unroll
+            for (int s = 0; s < 32; s++)
+            {
+                if (s & bit)
+                    continue;
+                const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
+                const u64 u = x[s], v = x[s | bit];
+                u64 tt = u + v;
+                tt = tt >= two_p ? tt - two_p : tt; // BackwardLazy, ntt.cpp:265-272
+                x[s] = tt;
+                x[s | bit] = mulmod_lazy(u - v + two_p, Wv.x, Wv.y, p);
+            }
+        }
+
+        template <int T, int R>
+        __device__ __forceinline__ void h_round_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+                                                    u64 two_p)
+        {
+            h_layer_inv<T, R, 1>(x, tw, jb, N, p, two_p);
+            h_layer_inv<T, R, 2>(x, tw, jb, N, p, two_p);
+            h_layer_inv<T, R, 3>(x, tw, jb, N, p, two_p);
+            h_layer_inv<T, R, 4>(x, tw, jb, N, p, two_p);
+        }
+
+        template <int LOGN>
+        __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
+                                                                                  const PrimeDev *__restrict__ primes,
+                                                                                  RowMap map, std::size_t nrows)
+        {
+            constexpr int T = LOGN - 1;
+            constexpr int N = 1 << LOGN;
+            extern __shared__ u64 lds[];
+            const int tid = threadIdx.x;
+            const unsigned bid = blockIdx.x;
+            const int half = (bid >> 3) & 1;
+            const std::size_t row = static_cast<std::size_t>(bid >> 4) * 8 + (bid & 7);
+            if (row >= nrows)
+                return;
+            const unsigned short pid = map.prime[row % map.rows];
+            if (pid == kSkipRow)
+                return;
+            const PrimeDev P = primes[pid];
+            const u64 p = P.p, two_p = P.two_p;
+            const u64 *tw = P.inv;
+            const int gbase = half << T;
+            u64 *halfp = data + (row << LOGN) + gbase;
+            u64 x[32];
+            {
+                const int jb = Arr<T, 4>::tid_index(tid);
+#pragma unroll
+                for (int s = 0; s < 32; s += 2)
+                {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jb + Arr<T, 4>::slot_index(s));
+                    x[s] = v.x;
+                    x[s + 1] = v.y;
+                }
+                constexpr int f = T - 12;
+                h_layer_inv<T, 4, 0>(x, tw, gbase + jb, N, p, two_p);
+                if (f >= 2)
+                    h_layer_inv<T, 4, 1>(x, tw, gbase + jb, N, p, two_p);
+                if (f >= 3)
+                    h_layer_inv<T, 4, 2>(x, tw, gbase + jb, N, p, two_p);
+            }
+            h_exchange<T, 4, 3>(x, lds, tid);
+            h_round_inv<T, 3>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p);
+            h_exchange<T, 3, 2>(x, lds, tid);
+            h_round_inv<T, 2>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p);
+            h_exchange<T, 2, 1>(x, lds, tid);
+            h_round_inv<T, 1>(x, tw, gbase + Arr<T, 1>::tid_index(tid), N, p, two_p);
+            {
+                const int jb = Arr<T, 1>::tid_index(tid);
+#pragma unroll
+                for (int s = 0; s < 32; s += 2)
+                {
+                    ulonglong2 v;
+                    v.x = x[s];
+                    v.y = x[s + 1];
+                    *reinterpret_cast<ulonglong2 *>(halfp + jb + Arr<T, 1>::slot_index(s)) = v;
+                }
+            }
+        }
+
+        // top inverse layer (gap N/2): x0 = (u+v)*n^-1, x1 = (u-v+2p)*(w*n^-1)  (BackwardLazyLast, ntt.cpp:274-281)
+        __global__ __launch_bounds__(256) void ntt_inv_top_kernel(u64 *__restrict__ data,
+                                                                  const PrimeDev *__restrict__ primes, RowMap map,
+                                                                  int logn, std::size_t npairs, int flags)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t half = static_cast<std::size_t>(1) << (logn - 1);
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < npairs; i += stride)
+            {
+                // i enumerates 16-byte pairs of the lower halves: row = i / (N/4), pair inside the half = i % (N/4)
+                const std::size_t row = i >> (logn - 2);
+                const std::size_t off = (i & ((half >> 1) - 1)) * 2;
+                const unsigned short pid = map.prime[row % map.rows];
+                if (pid == kSkipRow)
+                    continue;
+                const PrimeDev &P = primes[pid];
+                const u64 p = P.p, two_p = P.two_p;
+                u64 *lo = data + (row << logn) + off;
+                u64 *hi = lo + half;
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(lo);
+                const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(hi);
+                ulonglong2 r0, r1;
+                u64 t0 = a.x + b.x, t1 = a.y + b.y;
+                t0 = t0 >= two_p ? t0 - two_p : t0;
+                t1 = t1 >= two_p ? t1 - two_p : t1;
+                r0.x = mulmod_lazy(t0, P.inv_n, P.inv_n_shoup, p);
+                r0.y = mulmod_lazy(t1, P.inv_n, P.inv_n_shoup, p);
+                r1.x = mulmod_lazy(a.x - b.x + two_p, P.inv_n_w, P.inv_n_w_shoup, p);
+                r1.y = mulmod_lazy(a.y - b.y + two_p, P.inv_n_w, P.inv_n_w_shoup, p);
+                if (flags & kNttCanonical)
+                {
+                    r0.x = r0.x >= p ? r0.x - p : r0.x;
+                    r0.y = r0.y >= p ? r0.y - p : r0.y;
+                    r1.x = r1.x >= p ? r1.x - p : r1.x;
+                    r1.y = r1.y >= p ? r1.y - p : r1.y;
+                }
+                *reinterpret_cast<ulonglong2 *>(lo) = r0;
+                *reinterpret_cast<ulonglong2 *>(hi) = r1;
+            }
+        }
+
+        template <int LOGN>
+        hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags)
+        {
+            constexpr int T = LOGN - 1;
+            const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
+            const std::size_t blocks = ((nrows + 7) / 8) * 16;
+            if (blocks > 0x7fffffffull)
+                return hipErrorInvalidValue;
+            {
+                ProfScope prof(e, "ntt_inv_half", static_cast<double>(nrows));
+                ntt_inv_half_kernel<LOGN><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                    data, e.d_primes, map, nrows);
+                hipError_t err = hipGetLastError();
+                if (err != hipSuccess)
+                    return err;
+            }
+            const std::size_t npairs = nrows << (LOGN - 2);
+            std::size_t grid = (npairs + 255) / 256;
+            if (grid > 256u * 32u)
+                grid = 256u * 32u;
+            ProfScope prof(e, "ntt_inv_top", static_cast<double>(nrows));
+            ntt_inv_top_kernel<<<static_cast<unsigned>(grid), 256, 0, e.stream>>>(data, e.d_primes, map, LOGN, npairs,
+                                                                               flags);
+            return hipGetLastError();
+        }
+
+        template <int LOGN>
+        hipError_t launch_half(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags)
+        {
+            constexpr int T = LOGN - 1;
+            const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
+            const std::size_t groups = (nrows + 7) / 8;
+            const std::size_t blocks = groups * 16;
+            if (blocks > 0x7fffffffull)
+                return hipErrorInvalidValue;
+            // SEALHIP_NTT_NO_TICKET=1 is a measurement-only switch (A/B of the hand-off cost); it re-opens the race
+            static const bool no_ticket = std::getenv("SEALHIP_NTT_NO_TICKET") != nullptr;
+            unsigned *tickets = no_ticket ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
+            if (!tickets && !no_ticket)
+                return hipErrorOutOfMemory;
+            ProfScope prof(e, "ntt_fwd_half", static_cast<double>(nrows));
+            if (flags & kNttStrict)
+                ntt_fwd_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets);
+            else
+                ntt_fwd_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets);
+            return hipGetLastError();
+        }
+
+        template <int LOGN>
+        hipError_t init_half()
+        {
+            const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (err != hipSuccess)
+                return err;
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (err != hipSuccess)
+                return err;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        }
+
         void make_rounds(NttPass &ps, int lo, int hi, bool inverse)
         {
             const int count = hi - lo + 1;
@@ -344,14 +813,40 @@ namespace sealhip
                                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (err != hipSuccess)
             return err;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (err == hipSuccess)
+            err = init_half<14>();
+        if (err == hipSuccess)
+            err = init_half<15>();
+        if (err == hipSuccess)
+            err = init_half<16>();
+        return err;
     }
 
     hipError_t launch_ntt(const Engine &e, u64 *data, size_t nrows, const RowMap &map, bool inverse, int flags)
     {
         if (e.mode_strict)
             flags |= kNttStrict;
+        if (!inverse && e.use_half_kernel && nrows > 0)
+        {
+            // single-pass forward transform for the large rings
+            if (e.logn == 14)
+                return launch_half<14>(e, data, nrows, map, flags);
+            if (e.logn == 15)
+                return launch_half<15>(e, data, nrows, map, flags);
+            if (e.logn == 16)
+                return launch_half<16>(e, data, nrows, map, flags);
+        }
+        if (inverse && e.use_half_kernel && nrows > 0)
+        {
+            if (e.logn == 14)
+                return launch_half_inv<14>(e, data, nrows, map, flags);
+            if (e.logn == 15)
+                return launch_half_inv<15>(e, data, nrows, map, flags);
+            if (e.logn == 16)
+                return launch_half_inv<16>(e, data, nrows, map, flags);
+        }
         const NttPlan plan = plan_ntt(e.logn, inverse, flags);
         return inverse ? launch_dir<1>(e, data, nrows, map, plan) : launch_dir<0>(e, data, nrows, map, plan);
     }

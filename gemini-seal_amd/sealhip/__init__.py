@@ -169,6 +169,7 @@ class DeviceBuffer:
         return self
 
     def download(self, shape=None):
+        self.ctx.synchronize()  # also surfaces asynchronous kernel-side failures
         out = np.empty(self.words, dtype=np.uint64)
         _check(lib().sealhip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.words * 8))
         return out.reshape(shape) if shape is not None else out

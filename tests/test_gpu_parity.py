@@ -547,3 +547,31 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     want = [r for r in DIG["end_to_end"] if r["cfg"] == 1][0]["digests"]["modswitch"]
     assert "modswitch digest " + want in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("logn", [14, 15, 16])
+def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
+    """The single-pass forward NTT is in place while the two workgroups of a row each read both halves; the
+    ticket hand-off must make the result independent of dispatch timing. Uneven launches (odd row counts,
+    small and large batches back to back), every word checked against the first run and one row against the oracle."""
+    n = 1 << logn
+    mods = O.coeff_modulus_create(n, [50, 50, 50]) + O.get_primes(n, 57, 1)
+    k = 3
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    rng = np.random.default_rng(logn)
+    tabs = [O.Tables(logn, p) for p in mods[:k]]
+    for count in (1, 3, 37, 5, 64, 1):
+        x = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+        want = None
+        for rep in range(4):
+            d = ctx.upload(x)
+            ctx.ntt_negacyclic_harvey(d, count, k)
+            got = d.download(x.shape)
+            if want is None:
+                want = got
+                exp = x[count - 1].copy()
+                for i in range(k):
+                    L.ref_ntt_forward(O.ptr(exp[i]), C.byref(tabs[i].t), 0)
+                assert np.array_equal(got[count - 1], exp)
+            else:
+                assert np.array_equal(got, want), (count, rep)
