@@ -58,6 +58,7 @@ namespace sealhip
         e->t = scheme == 1 ? t : 0;
         e->mode_strict = strict;
         e->use_half_kernel = std::getenv("SEALHIP_NTT_TWO_PASS") == nullptr;
+        e->unfused_rns = std::getenv("SEALHIP_RNS_UNFUSED") != nullptr;
         e->device = device;
         e->key_moduli.assign(key_moduli, key_moduli + n_key);
         for (int i = 0; i < n_key; i++)
@@ -271,6 +272,29 @@ namespace sealhip
             }
             rd.B_to_q = upload<u64>(*this, lt.owned, hr.B_to_q.matrix.data(), hr.B_to_q.matrix.size());
             rd.inv_prod_B_mod_msk = hr.inv_prod_B_mod_m_sk;
+            // folded constants of the fused kernels
+            std::vector<u64> L1(static_cast<std::size_t>(nB) * k), G2(static_cast<std::size_t>(nB) * k);
+            for (int j = 0; j < nB; j++)
+            {
+                const u64 b = hr.Bsk[j];
+                const u64 inv_mt = hr.inv_m_tilde_mod_Bsk[j];
+                u64 g = hr.inv_prod_q_mod_Bsk[j];
+                if (j < B)
+                    g = mulmod(g, hr.B_to_q.inv_punct[j], b);
+                rd.lift_L2[j] = mulmod(hr.prod_q_mod_Bsk[j], inv_mt, b);
+                rd.floor_G1[j] = mulmod(t % b, g, b);
+                for (int i = 0; i < k; i++)
+                {
+                    const u64 m = hr.q_to_Bsk.matrix[static_cast<std::size_t>(j) * k + i];
+                    L1[static_cast<std::size_t>(j) * k + i] = mulmod(m, inv_mt, b);
+                    const u64 mg = mulmod(m, g, b);
+                    G2[static_cast<std::size_t>(j) * k + i] = mg ? b - mg : 0;
+                }
+            }
+            for (int i = 0; i < k; i++)
+                rd.floor_F0[i] = mulmod(t % hr.q[i], hr.q_to_Bsk.inv_punct[i], hr.q[i]);
+            rd.lift_L1 = upload<u64>(*this, lt.owned, L1.data(), L1.size());
+            rd.floor_G2 = upload<u64>(*this, lt.owned, G2.data(), G2.size());
         }
         lt.h_rns = rd;
         lt.d_rns = upload<RnsDev>(*this, lt.owned, &rd, 1);

@@ -68,6 +68,14 @@ namespace sealhip
         u64 inv_prod_B_mod_msk;
         u64 prod_B_mod_q[kMaxModuli];
         u64 inv_q_last_mod_q[kMaxModuli];
+        // constant-folded forms used by the fused BFV kernels (canonical results are unchanged):
+        //   lift : out_j = ( sum_i t_i*lift_L1[j][i] + temp_j*lift_L2[j] ) mod b_j
+        //   floor: tb_j  = ( in_j*floor_G1[j] + sum_i t_i*floor_G2[j][i] ) mod b_j,  t_i = in_i*floor_F0[i] mod q_i
+        const u64 *lift_L1;  // [nB][k]  M_ji * m_tilde^{-1} mod b_j
+        const u64 *floor_G2; // [nB][k]  -(M_ji * (prod q)^{-1} [* B^_j^{-1} for j < B]) mod b_j
+        u64 lift_L2[kMaxModuli + 2];  // prod_q * m_tilde^{-1} mod b_j
+        u64 floor_G1[kMaxModuli + 2]; // t * (prod q)^{-1} [* B^_j^{-1} for j < B] mod b_j
+        u64 floor_F0[kMaxModuli];     // t * (q^_i)^{-1} mod q_i
         unsigned short q_prime[kMaxModuli];       // prime ids of q rows
         unsigned short bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
     };
@@ -119,6 +127,7 @@ namespace sealhip
         std::size_t n = 0;
         u64 t = 0;
         bool mode_strict = false;
+        bool unfused_rns = false;    // SEALHIP_RNS_UNFUSED=1: step-by-step BEHZ kernels (also used for k > 32)
         bool use_half_kernel = true; // single-pass forward NTT for logn >= 14 (SEALHIP_NTT_TWO_PASS=1 disables)
         int device = -1; // -1: host-only
         std::vector<u64> key_moduli, aux_primes;

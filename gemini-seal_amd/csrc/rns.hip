@@ -135,6 +135,123 @@ namespace sealhip
             }
         }
 
+        // Constant-folded variant of bfv_lift_kernel (k <= 32): the chain
+        //   conv_j = sum_i t_i M_ji mod b;  u = (prod_q*temp + conv_j) mod b;  out = u * m_tilde^{-1} mod b
+        // (rns.cpp:1062-1067 + :960-980) is a composition of exact modular operations, so it equals
+        //   out = ( sum_i t_i*(M_ji*m_tilde^{-1}) + temp*(prod_q*m_tilde^{-1}) ) mod b
+        // with ONE 128-bit accumulation and ONE Barrett reduction per output instead of three.
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void bfv_lift2_kernel(const RnsDev *__restrict__ d,
+                                                                     const PrimeDev *__restrict__ primes,
+                                                                     const u64 *__restrict__ in, std::size_t in_stride,
+                                                                     u64 *__restrict__ out, std::size_t out_stride,
+                                                                     std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, nB = d->nB;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            u64 t[KMAX];
+            u64 acc = 0;
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    t[i] = mul_mod(pin[i * N], d->q_mt_inv[i], Q.p, Q.cr0, Q.cr1);
+                    acc += t[i] * d->q_to_mt[i];
+                }
+            const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
+            for (int j = 0; j < nB; j++)
+            {
+                const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                u64 temp = r_mt;
+                if (temp >= (1ull << 31))
+                    temp += Bp.p - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
+                const u64 *row = d->lift_L1 + j * k;
+                u64 lo = temp * d->lift_L2[j], hi = mulhi(temp, d->lift_L2[j]);
+#pragma unroll
+                for (int i = 0; i < KMAX; i++)
+                    if (i < k)
+                        mac128(lo, hi, t[i], row[i]);
+                pout[j * N] = barrett_reduce_128(lo, hi, Bp.p, Bp.cr0, Bp.cr1);
+            }
+        }
+
+        // Constant-folded variant of bfv_floor_sk_kernel (k <= 32); see RnsDev for the folded constants.
+        // Every output is the same canonical residue as the step-by-step version: only exact modular
+        // identities are used ((b - c)*g == -c*g, (x*t)*g == x*(t*g), mul_add_mod(a,b,c) == a*b + c (mod q)).
+        template <int KMAX>
+        __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d,
+                                                                         const PrimeDev *__restrict__ primes,
+                                                                         const u64 *__restrict__ in,
+                                                                         std::size_t in_stride, u64 *__restrict__ out,
+                                                                         std::size_t out_stride, std::size_t count,
+                                                                         int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k, B = d->B;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * in_stride + cc.c;
+            u64 *pout = out + cc.item * out_stride + cc.c;
+            u64 t[KMAX];
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < k)
+                {
+                    const PrimeDev &Q = primes[d->q_prime[i]];
+                    t[i] = mul_mod(pin[i * N], d->floor_F0[i], Q.p, Q.cr0, Q.cr1);
+                }
+            u64 tb[KMAX + 1];
+            u64 fl_sk = 0;
+#pragma unroll
+            for (int j = 0; j < KMAX + 2; j++)
+                if (j <= B)
+                {
+                    const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                    const u64 *row = d->floor_G2 + j * k;
+                    const u64 x = pin[(k + j) * N];
+                    u64 lo = x * d->floor_G1[j], hi = mulhi(x, d->floor_G1[j]);
+#pragma unroll
+                    for (int i = 0; i < KMAX; i++)
+                        if (i < k)
+                            mac128(lo, hi, t[i], row[i]);
+                    const u64 v = barrett_reduce_128(lo, hi, Bp.p, Bp.cr0, Bp.cr1);
+                    if (j < B)
+                        tb[j < KMAX + 1 ? j : 0] = v;
+                    else
+                        fl_sk = v;
+                }
+            const PrimeDev &Msk = primes[d->bsk_prime[B]];
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < KMAX + 1; j++)
+                if (j < B)
+                    mac128(lo, hi, tb[j], d->B_to_msk[j]);
+            const u64 conv_sk = barrett_reduce_128(lo, hi, Msk.p, Msk.cr0, Msk.cr1);
+            const u64 alpha = mul_mod(conv_sk + (Msk.p - fl_sk), d->inv_prod_B_mod_msk, Msk.p, Msk.cr0, Msk.cr1);
+            const bool neg = alpha > (Msk.p >> 1); // rns.cpp:909
+            const u64 a2 = neg ? Msk.p - alpha : alpha;
+            for (int i = 0; i < k; i++)
+            {
+                const PrimeDev &Q = primes[d->q_prime[i]];
+                const u64 pB = d->prod_B_mod_q[i];
+                const u64 c = neg ? pB : Q.p - pB;
+                const u64 *mrow = d->B_to_q + i * B;
+                u64 l2 = a2 * c, h2 = mulhi(a2, c);
+#pragma unroll
+                for (int j = 0; j < KMAX + 1; j++)
+                    if (j < B)
+                        mac128(l2, h2, tb[j], mrow[j]);
+                pout[i * N] = barrett_reduce_128(l2, h2, Q.p, Q.cr0, Q.cr1);
+            }
+        }
+
         // fast_floor (rns.cpp:983-1023), optionally preceded by the multiplication by t of
         // evaluator.cpp:432-434: (k + |Bsk|) rows -> |Bsk| rows
         template <int KMAX>
@@ -410,6 +527,18 @@ namespace sealhip
             return hipSuccess;
         const unsigned grid = blocks_for(count, e.logn);
         ProfScope prof(e, "bfv_lift", 0);
+        if (h.k <= 32 && !e.unfused_rns)
+        {
+            if (h.k <= 4)
+                bfv_lift2_kernel<4><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else if (h.k <= 8)
+                bfv_lift2_kernel<8><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else if (h.k <= 16)
+                bfv_lift2_kernel<16><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else
+                bfv_lift2_kernel<32><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            return hipGetLastError();
+        }
         SEALHIP_DISPATCH_K(h.k, bfv_lift_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
         return hipGetLastError();
     }
@@ -444,6 +573,18 @@ namespace sealhip
             return hipSuccess;
         const unsigned grid = blocks_for(count, e.logn);
         ProfScope prof(e, "bfv_floor_sk", 0);
+        if (h.k <= 32 && !e.unfused_rns)
+        {
+            if (h.k <= 4)
+                bfv_floor_sk2_kernel<4><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else if (h.k <= 8)
+                bfv_floor_sk2_kernel<8><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else if (h.k <= 16)
+                bfv_floor_sk2_kernel<16><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            else
+                bfv_floor_sk2_kernel<32><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+            return hipGetLastError();
+        }
         SEALHIP_DISPATCH_K(h.k, bfv_floor_sk_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
         return hipGetLastError();
     }
