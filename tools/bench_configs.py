@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md (not the driver's bench line): the other BASELINE.json configs on one
+MI355X and the PCIe-inclusive rate of config 3. Prints one JSON line per measurement."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gemini-seal_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import bench
+import sealhip as S
+
+P14 = [1125899903107073, 1125899903500289, 1125899903795201, 1125899903827969, 1125899903991809, 1125899904679937]
+P15_12 = [1125899885412353, 1125899885740033, 1125899886395393, 1125899887312897, 1125899896160257, 1125899899174913,
+          1125899901665281, 1125899902124033, 1125899903107073, 1125899903500289, 1125899903827969, 1125899904679937]
+P16 = [1125899864506369, 1125899865948161, 1125899870011393, 1125899870404609, 1125899877875713, 1125899879710721,
+       1125899882987521, 1125899883380737, 1125899883642881, 1125899884036097, 1125899884167169, 1125899885740033,
+       1125899886395393, 1125899887312897, 1125899902124033, 1125899903827969]
+P12 = [68719230977, 68719403009, 137438822401]
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def mk(ctx, shape, moduli, dev):
+    t = torch.empty(shape, dtype=torch.int64, device=dev)
+    bench.fill_mod_rows(t, moduli)
+    return t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    out = []
+
+    def want(name):
+        return not a.only or name in a.only.split(",")
+
+    if want("cfg2"):
+        logn, n = 14, 1 << 14
+        ctx = S.Context(S.SCHEME_CKKS, logn, P14, 1, 0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        P = 1024
+        x = mk(ctx, (P, 6, n), P14, dev)  # key-level polynomials: 6 rows each (1024 x 6 = 6144 rows)
+        # BASE_KEY at level k=5 = 5 ciphertext primes + 1 special prime = all 6 key primes
+        fwd = timed(lambda: ctx.ntt_negacyclic_harvey(x, P, 5, S.BASE_KEY), 10)
+        inv = timed(lambda: ctx.inverse_ntt_negacyclic_harvey(x, P, 5, S.BASE_KEY), 10)
+        rows = P * 6
+        out.append({"config": "cfg2 CKKS N=2^14 6 primes: batched NTT over 1024 polys (6144 rows)",
+                    "forward_ntt_per_s": rows / fwd, "inverse_ntt_per_s": rows / inv,
+                    "fwd_hbm_roofline_frac": rows * 16 * n / fwd / 8e12, "inv_hbm_roofline_frac": rows * 16 * n / inv / 8e12,
+                    "fwd_plus_inv_ms": (fwd + inv) * 1e3})
+    if want("cfg1"):
+        logn, n = 12, 1 << 12
+        ctx = S.Context(S.SCHEME_BFV, logn, P12, 1, 786433)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 4096, 2
+        x, y = mk(ctx, (B, 2, k, n), P12[:k], dev), mk(ctx, (B, 2, k, n), P12[:k], dev)
+        o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+        key = mk(ctx, (2, 2, 3, n), P12, dev)
+        rk = S.KSwitchKeys(ctx, key, n_digits=2, from_host=False)
+
+        def step():
+            ev.multiply(x, 2, y, 2, k, B, o)
+            ev.relinearize_inplace(o, 3, k, B, [rk])
+        dt = timed(step, 5)
+        out.append({"config": "cfg1 BFV N=4096 3 primes: multiply+relinearize, batch 4096", "ct_mul_relin_per_s": B / dt})
+    if want("cfg4"):
+        logn, n = 15, 1 << 15
+        ctx = S.Context(S.SCHEME_CKKS, logn, P15_12, 1, 0)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 1024, 11  # 8192 ciphertexts / 8 GPUs
+        c = mk(ctx, (B, 2, k, n), P15_12[:k], dev)
+        key = mk(ctx, (k, 2, 12, n), P15_12, dev)
+        gk = S.KSwitchKeys(ctx, key, n_digits=k, from_host=False)
+        elt = ctx.galois_elt_from_step(1)
+        dt = timed(lambda: ev.rotate_vector_inplace(c, k, B, 1, {elt: gk}), 3)
+        # multiply + relinearize + rescale on the same context
+        x, y = mk(ctx, (B, 2, k, n), P15_12[:k], dev), mk(ctx, (B, 2, k, n), P15_12[:k], dev)
+        o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+        o2 = torch.empty((B, 2, k - 1, n), dtype=torch.int64, device=dev)
+
+        def chain():
+            ev.multiply(x, 2, y, 2, k, B, o)
+            ev.relinearize_inplace(o, 3, k, B, [gk])
+        dt2 = timed(chain, 3)
+        out.append({"config": "cfg4 CKKS N=2^15 12 primes (k=11, 11 digits): per-GPU share 1024 ciphertexts",
+                    "rotate_vector_per_s": B / dt, "ct_mul_relin_per_s": B / dt2})
+    if want("cfg5"):
+        logn, n = 16, 1 << 16
+        ctx = S.Context(S.SCHEME_BFV, logn, P16, 1, 786433)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 256, 15
+        x, y = mk(ctx, (B, 2, k, n), P16[:k], dev), mk(ctx, (B, 2, k, n), P16[:k], dev)
+        o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+        o2 = torch.empty((B, 2, k - 1, n), dtype=torch.int64, device=dev)
+        key = mk(ctx, (k, 2, 16, n), P16, dev)
+        rk = S.KSwitchKeys(ctx, key, n_digits=k, from_host=False)
+
+        def step():
+            ev.multiply(x, 2, y, 2, k, B, o)
+            ev.relinearize_inplace(o, 3, k, B, [rk])
+            # relinearized ciphertext = first two polys of each item (batch stride stays 3 polys)
+            ev.mod_switch_to_next(o.view(B, 3, k, n)[:, :2].contiguous(), 2, k, B, o2)
+        dt = timed(step, 3)
+        out.append({"config": "cfg5 BFV N=2^16 16 primes (k=15, |Bsk|=16, 15 digits): multiply+relinearize+mod_switch, batch 256",
+                    "pipeline_per_s": B / dt})
+    if want("pcie"):
+        logn, n = 15, 1 << 15
+        pr = bench.CFG3_PRIMES
+        ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 256, 7
+        ha = torch.empty((B, 2, k, n), dtype=torch.int64).pin_memory()
+        hb = torch.empty((B, 2, k, n), dtype=torch.int64).pin_memory()
+        ho = torch.empty((B, 2, k, n), dtype=torch.int64).pin_memory()
+        for t in (ha, hb):
+            for i, p in enumerate(pr[:k]):
+                t[:, :, i, :] = torch.randint(0, p, (B, 2, n), dtype=torch.int64)
+        key = mk(ctx, (k, 2, 8, n), pr, dev)
+        rk = S.KSwitchKeys(ctx, key, n_digits=k, from_host=False)
+        da = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
+        db = torch.empty_like(da)
+        o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+
+        def step():
+            da.copy_(ha, non_blocking=True)
+            db.copy_(hb, non_blocking=True)
+            ev.multiply(da, 2, db, 2, k, B, o)
+            ev.relinearize_inplace(o, 3, k, B, [rk])
+            ho.copy_(o[:, :2], non_blocking=True)
+        dt = timed(step, 3)
+        out.append({"config": "cfg3 with PCIe: pinned host -> device (2 x 3.67 MB/ct), multiply+relinearize, device -> host (3.67 MB/ct), batch 256, one stream (no overlap)",
+                    "ct_mul_relin_per_s_pcie_inclusive": B / dt})
+    for line in out:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
