@@ -39,19 +39,12 @@ namespace sealhip
         return x * y - q * p;
     }
 
-    // The same value computed as lo64(x*y + q*(2^64 - p)): one multiply-add chain and no 64-bit subtract
-    // (identical bits: arithmetic is mod 2^64). neg_p = 2^64 - p.
+    // The same value computed as lo64(x*y + q*(2^64 - p)): the 64-bit subtract (v_sub_co / s_nop / v_subb on
+    // gfx950) becomes one v_lshl_add_u64. Identical bits: all arithmetic is mod 2^64. neg_p = 2^64 - p.
     __device__ __forceinline__ u64 mulmod_lazy_np(u64 x, u64 y, u64 yshoup, u64 neg_p)
     {
         const u64 q = mulhi(x, yshoup);
-        const unsigned xl = static_cast<unsigned>(x), xh = static_cast<unsigned>(x >> 32);
-        const unsigned yl = static_cast<unsigned>(y), yh = static_cast<unsigned>(y >> 32);
-        const unsigned ql = static_cast<unsigned>(q), qh = static_cast<unsigned>(q >> 32);
-        const unsigned nl = static_cast<unsigned>(neg_p), nh = static_cast<unsigned>(neg_p >> 32);
-        u64 acc = static_cast<u64>(xl) * yl;          // v_mad_u64_u32
-        acc = static_cast<u64>(ql) * nl + acc;        // v_mad_u64_u32 (chained)
-        const unsigned hi = xl * yh + xh * yl + ql * nh + qh * nl; // 4 x v_mul_lo_u32
-        return acc + (static_cast<u64>(hi) << 32);
+        return x * y + q * neg_p;
     }
 
     // canonical Shoup product (multi_special_primes.cpp:13-19)

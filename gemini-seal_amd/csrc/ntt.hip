@@ -355,11 +355,78 @@ namespace sealhip
                     u = u >= two_p ? u - two_p : u;
                 else if (gb == 0)
                     u = barrett_lazy(u, rdp, p); // ForwardLazyLast, ntt.cpp:254-261
-                const u64 v = mulmod_lazy(x[s | bit], Wv.x, Wv.y, p);
+                const u64 v = mulmod_lazy_np(x[s | bit], Wv.x, Wv.y, neg_p);
                 x[s] = u + v; // ForwardLazy, ntt.cpp:245-252
                 x[s | bit] = u - v + two_p;
             }
         }
+
+        // final round, one group at a time: the low f index bits of the 2^f registers that share the filler
+        // slot bits G are finished (layers f-1 .. 0) and stored right away, which bounds the live twiddles
+        template <int T, bool STRICT, int G>
+        __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
+                                                      int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+        {
+            constexpr int f = T - 12;
+#pragma unroll
+            for (int W = f - 1; W >= 0; W--)
+            {
+                const int gb = Arr<T, 4>::slot_bit(W);
+                const int tb = (N + jb) >> (gb + 1);
+                const int bit = 1 << W;
+#pragma unroll
+                for (int e = 0; e < (1 << f); e++)
+                {
+                    if (e & bit)
+                        continue;
+                    const int s = (G << f) | e;
+                    const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    u64 u = x[s];
+                    if (STRICT)
+                        u = u >= two_p ? u - two_p : u;
+                    else if (gb == 0)
+                        u = barrett_lazy(u, rdp, p);
+                    const u64 v = mulmod_lazy_np(x[s | bit], Wv.x, Wv.y, neg_p);
+                    x[s] = u + v;
+                    x[s | bit] = u - v + two_p;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < (1 << f); e += 2)
+            {
+                const int s = (G << f) | e;
+                ulonglong2 v;
+                v.x = x[s];
+                v.y = x[s + 1];
+                if (canon)
+                {
+                    v.x = v.x >= two_p ? v.x - two_p : v.x;
+                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    v.x = v.x >= p ? v.x - p : v.x;
+                    v.y = v.y >= p ? v.y - p : v.y;
+                }
+                *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
+            }
+        }
+
+        template <int T, bool STRICT, int G, int NG>
+        struct FinalGroups
+        {
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
+                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+            {
+                h_final_group<T, STRICT, G>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                if ((G & 1) == 1)
+                    __builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting every group's twiddle loads
+                FinalGroups<T, STRICT, G + 1, NG>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+            }
+        };
+        template <int T, bool STRICT, int NG>
+        struct FinalGroups<T, STRICT, NG, NG>
+        {
+            __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
+            {}
+        };
 
         template <int T, int R, bool STRICT, bool UNIFORM>
         __device__ __forceinline__ void h_round(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
@@ -455,15 +522,6 @@ namespace sealhip
             h_exchange<T, 2, 3>(x, lds, tid);
             h_round<T, 3, STRICT, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p, neg_p, rdp);
             h_exchange<T, 3, 4>(x, lds, tid);
-            {
-                const int jb = gbase + Arr<T, 4>::tid_index(tid);
-                constexpr int f = T - 12;
-                if (f >= 3)
-                    h_layer<T, 4, 2, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
-                if (f >= 2)
-                    h_layer<T, 4, 1, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
-                h_layer<T, 4, 0, STRICT, false>(x, tw, jb, N, p, two_p, neg_p, rdp);
-            }
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
             {
@@ -481,24 +539,9 @@ namespace sealhip
             }
             // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
             //  that both workgroups of the row have finished reading)
-            // ---- store (arrangement 4: runs of 2^f consecutive coefficients per lane), optional canonicalisation
-            const bool canon = (flags & kNttCanonical) != 0;
-            const int jb = gbase + Arr<T, 4>::tid_index(tid);
-#pragma unroll
-            for (int s = 0; s < 32; s += 2)
-            {
-                ulonglong2 v;
-                v.x = x[s];
-                v.y = x[s + 1];
-                if (canon)
-                {
-                    v.x = v.x >= two_p ? v.x - two_p : v.x;
-                    v.y = v.y >= two_p ? v.y - two_p : v.y;
-                    v.x = v.x >= p ? v.x - p : v.x;
-                    v.y = v.y >= p ? v.y - p : v.y;
-                }
-                *reinterpret_cast<ulonglong2 *>(rowp + jb + Arr<T, 4>::slot_index(s)) = v;
-            }
+            // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
+            FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, gbase + Arr<T, 4>::tid_index(tid), N, p, two_p,
+                                                             neg_p, rdp, (flags & kNttCanonical) != 0);
         }
 
         // ----------------------------------------------------------------------------------------
