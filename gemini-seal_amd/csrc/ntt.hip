@@ -551,8 +551,8 @@ namespace sealhip
         // ascending bits) and stores lazy values in [0, 2p). The top layer (gap N/2, with n^{-1} folded
         // in, ntt.cpp:393-402) needs both halves and is applied by ntt_inv_top_kernel, a pure streaming
         // pass (or, inside the pipelines, by the consumer kernel).
-        template <int T, int R, int W>
-        __device__ __forceinline__ void h_layer_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+        template <int T, int R, int W, bool UNIFORM>
+        __device__ __forceinline__ void h_layer_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 neg_p,
                                                     u64 two_p)
         {
             constexpr int gb = Arr<T, R>::slot_bit(W);
@@ -563,24 +563,86 @@ namespace sealhip
             {
                 if (s & bit)
                     continue;
-                const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
+                u64x2 Wv;
+                if (UNIFORM)
+                    Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
+                else
+                    Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
                 const u64 u = x[s], v = x[s | bit];
                 u64 tt = u + v;
                 tt = tt >= two_p ? tt - two_p : tt; // BackwardLazy, ntt.cpp:265-272
                 x[s] = tt;
-                x[s | bit] = mulmod_lazy(u - v + two_p, Wv.x, Wv.y, p);
+                x[s | bit] = mulmod_lazy_np(u - v + two_p, Wv.x, Wv.y, neg_p);
             }
         }
 
-        template <int T, int R>
-        __device__ __forceinline__ void h_round_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
+        template <int T, int R, bool UNIFORM>
+        __device__ __forceinline__ void h_round_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 neg_p,
                                                     u64 two_p)
         {
-            h_layer_inv<T, R, 1>(x, tw, jb, N, p, two_p);
-            h_layer_inv<T, R, 2>(x, tw, jb, N, p, two_p);
-            h_layer_inv<T, R, 3>(x, tw, jb, N, p, two_p);
-            h_layer_inv<T, R, 4>(x, tw, jb, N, p, two_p);
+            h_layer_inv<T, R, 1, UNIFORM>(x, tw, jb, N, neg_p, two_p);
+            h_layer_inv<T, R, 2, UNIFORM>(x, tw, jb, N, neg_p, two_p);
+            h_layer_inv<T, R, 3, UNIFORM>(x, tw, jb, N, neg_p, two_p);
+            h_layer_inv<T, R, 4, UNIFORM>(x, tw, jb, N, neg_p, two_p);
         }
+
+        // first phase of the inverse, one group at a time: load the 2^f consecutive coefficients that share the
+        // filler slot bits G and run their low layers (index bits 0 .. f-1, ascending)
+        template <int T, int G>
+        __device__ __forceinline__ void h_first_group_inv(u64 (&x)[32], const u64 *__restrict__ tw,
+                                                          const u64 *__restrict__ halfp, int jloc, int jb, int N,
+                                                          u64 neg_p, u64 two_p)
+        {
+            constexpr int f = T - 12;
+#pragma unroll
+            for (int e = 0; e < (1 << f); e += 2)
+            {
+                const int s = (G << f) | e;
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jloc + Arr<T, 4>::slot_index(s));
+                x[s] = v.x;
+                x[s + 1] = v.y;
+            }
+#pragma unroll
+            for (int W = 0; W < f; W++)
+            {
+                const int gb = Arr<T, 4>::slot_bit(W);
+                const int tb = (N + jb) >> (gb + 1);
+                const int bit = 1 << W;
+#pragma unroll
+                for (int e = 0; e < (1 << f); e++)
+                {
+                    if (e & bit)
+                        continue;
+                    const int s = (G << f) | e;
+                    const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    const u64 u = x[s], v = x[s | bit];
+                    u64 tt = u + v;
+                    tt = tt >= two_p ? tt - two_p : tt;
+                    x[s] = tt;
+                    x[s | bit] = mulmod_lazy_np(u - v + two_p, Wv.x, Wv.y, neg_p);
+                }
+            }
+        }
+
+        template <int T, int G, int NG>
+        struct FirstGroupsInv
+        {
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw,
+                                                       const u64 *__restrict__ halfp, int jloc, int jb, int N, u64 neg_p,
+                                                       u64 two_p)
+            {
+                h_first_group_inv<T, G>(x, tw, halfp, jloc, jb, N, neg_p, two_p);
+                if ((G & 1) == 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                FirstGroupsInv<T, G + 1, NG>::run(x, tw, halfp, jloc, jb, N, neg_p, two_p);
+            }
+        };
+        template <int T, int NG>
+        struct FirstGroupsInv<T, NG, NG>
+        {
+            __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, const u64 *, int, int, int, u64, u64)
+            {}
+        };
 
         template <int LOGN>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
@@ -605,28 +667,17 @@ namespace sealhip
             const int gbase = half << T;
             u64 *halfp = data + (row << LOGN) + gbase;
             u64 x[32];
+            const u64 neg_p = 0 - p;
             {
-                const int jb = Arr<T, 4>::tid_index(tid);
-#pragma unroll
-                for (int s = 0; s < 32; s += 2)
-                {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jb + Arr<T, 4>::slot_index(s));
-                    x[s] = v.x;
-                    x[s + 1] = v.y;
-                }
-                constexpr int f = T - 12;
-                h_layer_inv<T, 4, 0>(x, tw, gbase + jb, N, p, two_p);
-                if (f >= 2)
-                    h_layer_inv<T, 4, 1>(x, tw, gbase + jb, N, p, two_p);
-                if (f >= 3)
-                    h_layer_inv<T, 4, 2>(x, tw, gbase + jb, N, p, two_p);
+                const int jloc = Arr<T, 4>::tid_index(tid);
+                FirstGroupsInv<T, 0, 1 << (5 - (T - 12))>::run(x, tw, halfp, jloc, gbase + jloc, N, neg_p, two_p);
             }
             h_exchange<T, 4, 3>(x, lds, tid);
-            h_round_inv<T, 3>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p);
+            h_round_inv<T, 3, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, neg_p, two_p);
             h_exchange<T, 3, 2>(x, lds, tid);
-            h_round_inv<T, 2>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p);
+            h_round_inv<T, 2, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, neg_p, two_p);
             h_exchange<T, 2, 1>(x, lds, tid);
-            h_round_inv<T, 1>(x, tw, gbase + Arr<T, 1>::tid_index(tid), N, p, two_p);
+            h_round_inv<T, 1, true>(x, tw, gbase, N, neg_p, two_p); // block-uniform twiddles -> scalar loads
             {
                 const int jb = Arr<T, 1>::tid_index(tid);
 #pragma unroll
