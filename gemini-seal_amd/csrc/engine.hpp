@@ -28,6 +28,18 @@ namespace sealhip
         unsigned short prime[kMaxRows];
     };
 
+    // Optional gather source of the single-pass forward NTT: destination row r of destination polynomial P reads
+    // base[b] + P*poly_stride[b] + src_row*N instead of its own storage (code = b<<15 | reduce<<14 | src_row;
+    // kSkipRow = in place). `reduce` applies barrett_reduce_63 w.r.t. the destination prime on load, which is the
+    // single-prime mod-up rule of multi_special_primes.cpp:99-108.
+    struct NttSource
+    {
+        const u64 *base[2];
+        std::size_t poly_stride[2];
+        unsigned short code[kMaxRows];
+    };
+    constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000;
+
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
 
@@ -203,6 +215,10 @@ namespace sealhip
     // ---- launchers (each enqueues on e.stream) ----
     hipError_t ntt_init_kernels();
     hipError_t launch_ntt(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, bool inverse, int flags);
+    // forward transform whose input rows are gathered from elsewhere (only when ntt_can_gather(e))
+    bool ntt_can_gather(const Engine &e);
+    hipError_t launch_ntt_gather(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, const NttSource &src,
+                                 int flags);
 
     enum class PolyOp
     {

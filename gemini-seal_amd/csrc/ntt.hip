@@ -441,7 +441,8 @@ namespace sealhip
         // load both halves of the row and apply the top layer (gap N/2, twiddle entry 1) on the fly
         template <int T, bool STRICT, int HALF>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
-                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p)
+                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p,
+                                                   bool reduce, u64 cr1)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
             const u64x2 W1 = ((tw_const_t)tw)[1];
@@ -456,6 +457,18 @@ namespace sealhip
                     const int idx = jb + Arr<T, 1>::slot_index(s);
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
+                }
+                if (reduce) // block-uniform: gathered single-prime mod-up (multi_special_primes.cpp:103-107)
+                {
+                    const u64 p = 0 - neg_p;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        lo[i].x = barrett_reduce_63(lo[i].x, p, cr1);
+                        lo[i].y = barrett_reduce_63(lo[i].y, p, cr1);
+                        hi[i].x = barrett_reduce_63(hi[i].x, p, cr1);
+                        hi[i].y = barrett_reduce_63(hi[i].y, p, cr1);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -478,7 +491,7 @@ namespace sealhip
         template <int LOGN, bool STRICT>
         __global__ __launch_bounds__(1 << (LOGN - 6), (LOGN == 16 ? 4 : 4)) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
-            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag)
+            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
@@ -501,10 +514,23 @@ namespace sealhip
 
             // ---- load both halves, top layer on the fly, arrangement 1 (block-uniform branch on the half)
             const u64 neg_p = 0 - p;
+            const u64 *srcp = rowp;
+            bool reduce = false;
+            if (src.base[0])
+            {
+                const unsigned short code = src.code[row % map.rows];
+                if (code != kSkipRow)
+                {
+                    const int b = code >> 15;
+                    srcp = src.base[b] + (row / map.rows) * src.poly_stride[b] +
+                           (static_cast<std::size_t>(code & 0x3FFF) << LOGN);
+                    reduce = (code & kSrcReduce) != 0;
+                }
+            }
             if (half)
-                h_load_top<T, STRICT, 1>(x, rowp, tw, tid, two_p, neg_p);
+                h_load_top<T, STRICT, 1>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
             else
-                h_load_top<T, STRICT, 0>(x, rowp, tw, tid, two_p, neg_p);
+                h_load_top<T, STRICT, 0>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -759,7 +785,8 @@ namespace sealhip
         }
 
         template <int LOGN>
-        hipError_t launch_half(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags)
+        hipError_t launch_half(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags,
+                               const NttSource &src)
         {
             constexpr int T = LOGN - 1;
             const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
@@ -775,10 +802,10 @@ namespace sealhip
             ProfScope prof(e, "ntt_fwd_half", static_cast<double>(nrows));
             if (flags & kNttStrict)
                 ntt_fwd_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets);
+                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src);
             else
                 ntt_fwd_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets);
+                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src);
             return hipGetLastError();
         }
 
@@ -918,6 +945,27 @@ namespace sealhip
         return err;
     }
 
+    bool ntt_can_gather(const Engine &e)
+    {
+        return e.use_half_kernel && e.logn >= 14 && e.logn <= 16;
+    }
+
+    hipError_t launch_ntt_gather(const Engine &e, u64 *data, size_t nrows, const RowMap &map, const NttSource &src,
+                                 int flags)
+    {
+        if (!ntt_can_gather(e))
+            return hipErrorInvalidValue;
+        if (e.mode_strict)
+            flags |= kNttStrict;
+        if (nrows == 0)
+            return hipSuccess;
+        if (e.logn == 14)
+            return launch_half<14>(e, data, nrows, map, flags, src);
+        if (e.logn == 15)
+            return launch_half<15>(e, data, nrows, map, flags, src);
+        return launch_half<16>(e, data, nrows, map, flags, src);
+    }
+
     hipError_t launch_ntt(const Engine &e, u64 *data, size_t nrows, const RowMap &map, bool inverse, int flags)
     {
         if (e.mode_strict)
@@ -925,12 +973,13 @@ namespace sealhip
         if (!inverse && e.use_half_kernel && nrows > 0)
         {
             // single-pass forward transform for the large rings
+            NttSource none{};
             if (e.logn == 14)
-                return launch_half<14>(e, data, nrows, map, flags);
+                return launch_half<14>(e, data, nrows, map, flags, none);
             if (e.logn == 15)
-                return launch_half<15>(e, data, nrows, map, flags);
+                return launch_half<15>(e, data, nrows, map, flags, none);
             if (e.logn == 16)
-                return launch_half<16>(e, data, nrows, map, flags);
+                return launch_half<16>(e, data, nrows, map, flags, none);
         }
         if (inverse && e.use_half_kernel && nrows > 0)
         {

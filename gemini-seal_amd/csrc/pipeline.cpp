@@ -103,16 +103,39 @@ namespace sealhip
                 src = coeff;
                 src_stride = static_cast<std::size_t>(k) * N;
             }
-            // Step 2 (:2310): mod-up of every bundle
-            check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
-            // Step 3a (:2322): lazy forward NTT of every row outside the bundle, per digit
+            // Step 2 (:2310) + 3a (:2322): mod-up of every bundle, then the lazy forward NTT of every row outside
+            // the bundle. With one special prime the mod-up of a row is a copy or a Barrett-63 reduction of the
+            // bundle's single row (multi_special_primes.cpp:99-108): the NTT kernel gathers and reduces it on load,
+            // so the extended polynomial is never written in coefficient form.
+            const bool gather = e.nsp == 1 && ntt_can_gather(e);
+            if (!gather)
+                check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
             for (int j = 0; j < nd; j++)
             {
                 RowMap mj = map_rows;
                 const int r0 = j * e.nsp, r1 = std::min(r0 + e.nsp, k);
                 for (int r = r0; r < r1; r++)
                     mj.prime[r] = kSkipRow;
-                check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
+                if (gather)
+                {
+                    NttSource ns{};
+                    ns.base[0] = src;
+                    ns.poly_stride[0] = src_stride;
+                    const u64 p_src = e.key_moduli[h.row_prime[j]];
+                    for (int r = 0; r < rows; r++)
+                    {
+                        if (r == j)
+                        {
+                            ns.code[r] = kSkipRow;
+                            continue;
+                        }
+                        const u64 p_dst = e.key_moduli[h.row_prime[r]];
+                        ns.code[r] = static_cast<unsigned short>(j | (p_src <= p_dst ? 0 : kSrcReduce));
+                    }
+                    check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, 0), "ntt(ext, gathered)");
+                }
+                else
+                    check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
             }
             // in-bundle rows: the reference multiplies the target rows as they are (:2319-2320);
             // STRICT transforms the coefficient-form BFV rows first
@@ -201,17 +224,43 @@ namespace sealhip
             e.ws_reset();
             u64 *X = e.ws_alloc(w_x * m);
             u64 *D = e.ws_alloc(w_d * m);
-            // steps (1)-(3) (:335-353): copy the q rows, lift to Bsk (fastbconv_m_tilde + sm_mrq), one lazy NTT
+            // steps (1)-(3) (:335-353): lift to Bsk (fastbconv_m_tilde + sm_mrq) and one lazy NTT over all rows;
+            // the q rows are gathered straight from the operands by the NTT kernel (no set_poly copy) when the
+            // single-pass kernel is available
+            const bool gather = ntt_can_gather(e) && sin * kb <= kMaxRows;
             for (int s = 0; s < sin; s++)
             {
                 const bool first = s < sa;
                 const u64 *src = first ? a + off * sa * poly_q + s * poly_q : b + off * sb * poly_q + (s - sa) * poly_q;
                 const std::size_t src_stride = (first ? sa : sb) * poly_q;
                 u64 *dst = X + s * poly_x;
-                check(launch_copy_rows(e, src, src_stride, dst, w_x, m, k), "copy");
+                if (!gather)
+                    check(launch_copy_rows(e, src, src_stride, dst, w_x, m, k), "copy");
                 check(launch_bfv_lift(e, lt.d_rns, h, src, src_stride, dst + poly_q, w_x, m), "bfv_lift");
             }
-            check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
+            if (gather)
+            {
+                // one "polynomial" of the launch = all sin*(k+|Bsk|) rows of an item
+                RowMap big{};
+                NttSource ns{};
+                big.rows = sin * kb;
+                ns.base[0] = a + off * sa * poly_q;
+                ns.base[1] = b + off * sb * poly_q;
+                ns.poly_stride[0] = sa * poly_q;
+                ns.poly_stride[1] = sb * poly_q;
+                for (int s = 0; s < sin; s++)
+                    for (int r = 0; r < kb; r++)
+                    {
+                        big.prime[s * kb + r] = lt.map_qbsk.prime[r];
+                        unsigned short code = kSkipRow; // Bsk rows: in place (written by bfv_lift)
+                        if (r < k)
+                            code = static_cast<unsigned short>((s < sa ? 0 : kSrcSecond) | ((s < sa ? s : s - sa) * k + r));
+                        ns.code[s * kb + r] = code;
+                    }
+                check(launch_ntt_gather(e, X, m * sin * kb, big, ns, 0), "ntt(X, gathered)");
+            }
+            else
+                check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
             // step (4) (:376-420)
             check(launch_tensor_product(e, X, sa, w_x, X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
             // step (5) (:423-424)
