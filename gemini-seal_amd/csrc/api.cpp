@@ -31,9 +31,30 @@ namespace
         return code;
     }
 
+    // Every compute entry point holds the context's operation lock until it returns: entry points may be called
+    // from several host threads, but operations of one context are serialised (they share the workspace arena and
+    // the stream); use one context per worker thread for concurrency.
+    struct OpLock
+    {
+        std::unique_lock<std::recursive_mutex> lock;
+        explicit OpLock(Engine &e) : lock(e.op_mu)
+        {}
+    };
+    thread_local std::vector<std::unique_ptr<OpLock>> g_locks;
+    struct LockScope
+    {
+        std::size_t depth = g_locks.size();
+        ~LockScope()
+        {
+            while (g_locks.size() > depth)
+                g_locks.pop_back();
+        }
+    };
+
     template <class F>
     long guarded(F &&body)
     {
+        LockScope scope;
         try
         {
             body();
@@ -81,6 +102,7 @@ namespace
         Engine &e = *ctx->engine;
         if (e.device < 0)
             throw std::logic_error("host-only context: there is no CPU fallback, create the context on a HIP device");
+        g_locks.push_back(std::make_unique<OpLock>(e));
         SEALHIP_CHECK(hipSetDevice(e.device));
         return e;
     }

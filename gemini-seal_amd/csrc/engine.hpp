@@ -42,6 +42,7 @@ namespace sealhip
 
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
+    constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
 
     struct NttRound
     {
@@ -152,6 +153,7 @@ namespace sealhip
         std::map<int, std::unique_ptr<LevelTools>> levels;
         std::map<std::uint32_t, std::uint32_t *> galois_tables; // elt -> device table (galois.cpp:18-47)
         std::mutex mu;
+        std::recursive_mutex op_mu; // one operation at a time per context (they share the arena and the stream)
         // profiler
         mutable bool prof_on = false;
         mutable std::vector<ProfRecord> prof;
@@ -251,8 +253,12 @@ namespace sealhip
     hipError_t launch_fastbconv_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count);
     // fused (x t) + fast_floor + fastbconv_sk: in (k+|Bsk|) rows -> out k rows
+    // deferred_top != 0: `in` holds the output of the single-pass inverse kernel WITHOUT its top layer; the kernel
+    // applies that layer and the canonicalising subtraction while loading (needs ntt_can_defer_top(e))
     hipError_t launch_bfv_floor_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
-                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count);
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                   int deferred_top = 0);
+    bool ntt_can_defer_top(const Engine &e, int k);
     hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int out_rows);

@@ -774,6 +774,8 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
+            if (flags & kNttDeferTop)
+                return hipSuccess; // the consumer applies the top layer (and the canonicalisation) on load
             const std::size_t npairs = nrows << (LOGN - 2);
             std::size_t grid = (npairs + 255) / 256;
             if (grid > 256u * 32u)
@@ -943,6 +945,11 @@ namespace sealhip
         if (err == hipSuccess)
             err = init_half<16>();
         return err;
+    }
+
+    bool ntt_can_defer_top(const Engine &e, int k)
+    {
+        return e.use_half_kernel && e.logn >= 14 && e.logn <= 16 && k <= 32 && !e.unfused_rns;
     }
 
     bool ntt_can_gather(const Engine &e)

@@ -263,12 +263,14 @@ namespace sealhip
                 check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
             // step (4) (:376-420)
             check(launch_tensor_product(e, X, sa, w_x, X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
-            // step (5) (:423-424)
-            check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, kNttCanonical), "intt(D)");
+            // step (5) (:423-424); with the single-pass kernels the top inverse layer and the canonicalisation are
+            // applied by the consumer while it loads (saves one read+write pass over D)
+            const bool defer = ntt_can_defer_top(e, k);
+            check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, defer ? kNttDeferTop : kNttCanonical), "intt(D)");
             // steps (6)-(8) (:427-444)
             for (int I = 0; I < dest; I++)
                 check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
-                                          dest * poly_q, m),
+                                          dest * poly_q, m, defer ? 1 : 0),
                       "floor_sk");
         }
     }

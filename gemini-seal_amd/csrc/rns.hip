@@ -184,7 +184,26 @@ namespace sealhip
         // Constant-folded variant of bfv_floor_sk_kernel (k <= 32); see RnsDev for the folded constants.
         // Every output is the same canonical residue as the step-by-step version: only exact modular
         // identities are used ((b - c)*g == -c*g, (x*t)*g == x*(t*g), mul_add_mod(a,b,c) == a*b + c (mod q)).
-        template <int KMAX>
+        // One coefficient of an inverse-NTT output whose top layer was deferred (kNttDeferTop): apply
+        // BackwardLazyLast (ntt.cpp:274-281) to the pair (c mod N/2, c mod N/2 + N/2) and the canonicalising
+        // subtraction of ntt.h:328-333, keeping only this lane's side of the butterfly.
+        __device__ __forceinline__ u64 load_after_top(const u64 *__restrict__ row, std::size_t c_lo, std::size_t half,
+                                                      bool is_hi, const PrimeDev &P)
+        {
+            const u64 u = row[c_lo], v = row[c_lo + half];
+            u64 r;
+            if (is_hi)
+                r = mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p);
+            else
+            {
+                u64 tt = u + v;
+                tt = tt >= P.two_p ? tt - P.two_p : tt;
+                r = mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, P.p);
+            }
+            return r >= P.p ? r - P.p : r;
+        }
+
+        template <int KMAX, bool DEFER>
         __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d,
                                                                          const PrimeDev *__restrict__ primes,
                                                                          const u64 *__restrict__ in,
@@ -198,6 +217,9 @@ namespace sealhip
             const int k = d->k, B = d->B;
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
+            const u64 *pitem = in + cc.item * in_stride;
+            const std::size_t half = N >> 1, c_lo = cc.c & (half - 1);
+            const bool is_hi = cc.c >= half; // block-uniform (N/2 is a multiple of the block size)
             u64 *pout = out + cc.item * out_stride + cc.c;
             u64 t[KMAX];
 #pragma unroll
@@ -205,7 +227,8 @@ namespace sealhip
                 if (i < k)
                 {
                     const PrimeDev &Q = primes[d->q_prime[i]];
-                    t[i] = mul_mod(pin[i * N], d->floor_F0[i], Q.p, Q.cr0, Q.cr1);
+                    const u64 xin = DEFER ? load_after_top(pitem + i * N, c_lo, half, is_hi, Q) : pin[i * N];
+                    t[i] = mul_mod(xin, d->floor_F0[i], Q.p, Q.cr0, Q.cr1);
                 }
             u64 tb[KMAX + 1];
             u64 fl_sk = 0;
@@ -215,7 +238,7 @@ namespace sealhip
                 {
                     const PrimeDev &Bp = primes[d->bsk_prime[j]];
                     const u64 *row = d->floor_G2 + j * k;
-                    const u64 x = pin[(k + j) * N];
+                    const u64 x = DEFER ? load_after_top(pitem + (k + j) * N, c_lo, half, is_hi, Bp) : pin[(k + j) * N];
                     u64 lo = x * d->floor_G1[j], hi = mulhi(x, d->floor_G1[j]);
 #pragma unroll
                     for (int i = 0; i < KMAX; i++)
@@ -567,7 +590,8 @@ namespace sealhip
     }
 
     hipError_t launch_bfv_floor_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
-                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count)
+                                   std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
+                                   int deferred_top)
     {
         if (!count)
             return hipSuccess;
@@ -575,16 +599,29 @@ namespace sealhip
         ProfScope prof(e, "bfv_floor_sk", 0);
         if (h.k <= 32 && !e.unfused_rns)
         {
+#define SEALHIP_FLOOR2(KM)                                                                                          \
+    do                                                                                                               \
+    {                                                                                                                \
+        if (deferred_top)                                                                                            \
+            bfv_floor_sk2_kernel<KM, true><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,       \
+                                                                           out_stride, count, e.logn);              \
+        else                                                                                                         \
+            bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,      \
+                                                                            out_stride, count, e.logn);             \
+    } while (0)
             if (h.k <= 4)
-                bfv_floor_sk2_kernel<4><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+                SEALHIP_FLOOR2(4);
             else if (h.k <= 8)
-                bfv_floor_sk2_kernel<8><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+                SEALHIP_FLOOR2(8);
             else if (h.k <= 16)
-                bfv_floor_sk2_kernel<16><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+                SEALHIP_FLOOR2(16);
             else
-                bfv_floor_sk2_kernel<32><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+                SEALHIP_FLOOR2(32);
+#undef SEALHIP_FLOOR2
             return hipGetLastError();
         }
+        if (deferred_top)
+            return hipErrorInvalidValue;
         SEALHIP_DISPATCH_K(h.k, bfv_floor_sk_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
         return hipGetLastError();
     }

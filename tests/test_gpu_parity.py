@@ -575,3 +575,38 @@ def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
                 assert np.array_equal(got[count - 1], exp)
             else:
                 assert np.array_equal(got, want), (count, rep)
+
+
+def test_full_size_batch_indexing_and_threads(sealhip):
+    """cfg3 at full size with a batch of identical ciphertexts: every item must reproduce the compiled reference's
+    digest (exercises item strides / chunking at BASELINE size), also when two host threads drive the same context."""
+    import threading
+
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == 3][0]
+    inp = synth.end_to_end_inputs(row)
+    n, k = inp["n"], inp["k"]
+    ctx = sealhip.Context(row["scheme"], inp["logn"], inp["kmods"], row["nsp"], row["t"])
+    ev = sealhip.Evaluator(ctx)
+    rk = sealhip.KSwitchKeys(ctx, inp["rk"])
+    count = 5
+    a = np.stack([inp["a"]] * count)
+    b = np.stack([inp["b"]] * count)
+    results = {}
+
+    def work(tag):
+        out = ctx.alloc(count * 3 * k * n)
+        ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, out)
+        mul = out.download((count, 3, k, n)).copy()
+        ev.relinearize_inplace(out, 3, k, count, [rk])
+        results[tag] = (mul, out.download((count, 3, k, n))[:, :2].copy())
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(results) == 2
+    for mul, relin in results.values():
+        for c in range(count):
+            assert h(mul[c]) == row["digests"]["mul"]
+            assert h(np.ascontiguousarray(relin[c])) == row["digests"]["relin"]
