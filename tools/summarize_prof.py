@@ -46,14 +46,18 @@ def main(prof_dir, out_dir, rows_per_block_ntt=4 * 512):
             tag = "ntt_fwd_pass" if "<0>" in key[0] else "ntt_inv_pass"
             rows = key[1] / key[2] / 4  # N=2^15: 4 tiles per row
             traffic.setdefault(tag, []).append(total / rows)
+        elif key[0].startswith("ntt_fwd_half_kernel") or key[0].startswith("ntt_inv_half_kernel"):
+            tag = "ntt_fwd_half" if "fwd" in key[0] else "ntt_inv_half"
+            rows = key[1] / key[2] / 2  # two workgroups per row (grid rounded up to 8-row groups)
+            traffic.setdefault(tag, []).append(total / rows)
     out = {k: {"hbm_bytes_per_row_per_launch": sum(v) / len(v)} for k, v in traffic.items()}
     json.dump(out, open(os.path.join(os.path.dirname(out_dir.rstrip("/")), "traffic.json"), "w"), indent=1)
     stats = glob.glob(os.path.join(prof_dir, "stats/*/*_kernel_stats.csv"))
     with open(os.path.join(out_dir, "summary.md"), "w") as fo:
         fo.write("# rocprofv3 summary\n\n## PMC (separate passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE)\n\n")
         fo.write("\n".join(lines) + "\n\n")
-        fo.write("NTT pass kernels, HBM bytes per RNS row per launch (N=2^15; algorithmic = 8*N*... = 262144 B "
-                 "per row per pass launch): %s\n\n" % json.dumps(out))
+        fo.write("NTT kernels, HBM bytes per RNS row per launch (N=2^15; algorithmic = 16*N = 524288 B per row for the "
+                 "single-pass kernels, 8*N = 262144 B per row per launch of the two-pass kernel): %s\n\n" % json.dumps(out))
         if stats:
             fo.write("## kernel-trace --stats (same bench command)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
             for r in csv.DictReader(open(stats[0])):
