@@ -23,6 +23,7 @@ namespace sealhip
         u64 cr0, cr1;   // floor(2^128 / p)          (modulus.cpp:85-96)
         u64 inv_n, inv_n_shoup;
         u64 inv_n_w, inv_n_w_shoup; // top inverse-layer twiddle times n^{-1} (ntt.cpp:97)
+        u64 ninv;                   // -p^{-1} mod 2^64 (Montgomery reduction of 128-bit dot products)
         const u64 *fwd;  // N {w, w'} pairs, bit-reversed exponent order
         const u64 *inv;  // N {w, w'} pairs for psi^{-1}
     };
@@ -73,6 +74,23 @@ namespace sealhip
         u64 q = hi * cr1 + tmp3 + carry2;
         u64 r = lo - q * p;
         return r >= p ? r - p : r;
+    }
+
+    // Montgomery reduction of a 128-bit accumulator: returns t == acc * 2^-64 (mod p) with t < acc/2^64 + p.
+    // Used for dot products against constants that were pre-multiplied by 2^64 mod p on the host, so the
+    // canonical result equals the reference's dot_product_mod / barrett_reduce_128 (exact integer identities);
+    // 7 multiplier ops instead of the 24 of the two-word Barrett reduction.
+    __device__ __forceinline__ u64 redc128(u64 lo, u64 hi, u64 p, u64 ninv)
+    {
+        const u64 m = lo * ninv;
+        return hi + mulhi(m, p) + (lo != 0);
+    }
+    // canonical residue of a REDC result; `small`: the host proved t < 2p for this stage
+    __device__ __forceinline__ u64 redc_finish(u64 t, u64 p, u64 rdp, bool small)
+    {
+        if (!small)
+            t = t - mulhi(t, rdp) * p; // -> [0, 2p)
+        return t >= p ? t - p : t;
     }
 
     // uintarithsmallmod.h:181-207 (x < 2^63)

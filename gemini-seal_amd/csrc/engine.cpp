@@ -108,6 +108,13 @@ namespace sealhip
             d.inv_n_shoup = tb.inv_n_shoup;
             d.inv_n_w = tb.inv_n_w;
             d.inv_n_w_shoup = tb.inv_n_w_shoup;
+            {
+                // -p^{-1} mod 2^64 by Newton iteration (p odd; the even "modulus" 2^32 never uses REDC)
+                u64 inv = tb.p;
+                for (int it = 0; it < 6; it++)
+                    inv *= 2 - tb.p * inv;
+                d.ninv = 0 - inv;
+            }
             d.fwd = tb.fwd.empty() ? nullptr : upload<u64>(*e, e->owned, tb.fwd.data(), tb.fwd.size());
             d.inv = tb.inv.empty() ? nullptr : upload<u64>(*e, e->owned, tb.inv.data(), tb.inv.size());
         }
@@ -295,6 +302,47 @@ namespace sealhip
                 rd.floor_F0[i] = mulmod(t % hr.q[i], hr.q_to_Bsk.inv_punct[i], hr.q[i]);
             rd.lift_L1 = upload<u64>(*this, lt.owned, L1.data(), L1.size());
             rd.floor_G2 = upload<u64>(*this, lt.owned, G2.data(), G2.size());
+            // Montgomery (x 2^64 mod prime) and Shoup companions
+            auto mont = [](u64 c, u64 p) { return static_cast<u64>((static_cast<u128>(c) << 64) % p); };
+            std::vector<u64> L1m(L1.size()), G2m(G2.size()), BQm(hr.B_to_q.matrix.size());
+            u64 max_q = 0, max_b = 0;
+            for (int i = 0; i < k; i++)
+                max_q = std::max(max_q, hr.q[i]);
+            for (int j = 0; j < nB; j++)
+            {
+                const u64 b = hr.Bsk[j];
+                max_b = std::max(max_b, b);
+                rd.lift_L2m[j] = mont(rd.lift_L2[j], b);
+                rd.floor_G1m[j] = mont(rd.floor_G1[j], b);
+                for (int i = 0; i < k; i++)
+                {
+                    L1m[static_cast<std::size_t>(j) * k + i] = mont(L1[static_cast<std::size_t>(j) * k + i], b);
+                    G2m[static_cast<std::size_t>(j) * k + i] = mont(G2[static_cast<std::size_t>(j) * k + i], b);
+                }
+            }
+            for (int i = 0; i < k; i++)
+            {
+                const u64 qi = hr.q[i];
+                rd.q_mt_inv_s[i] = shoup(rd.q_mt_inv[i], qi);
+                rd.floor_F0_s[i] = shoup(rd.floor_F0[i], qi);
+                rd.pBm[i] = mont(hr.prod_B_mod_q[i], qi);
+                rd.nBm[i] = mont(qi - hr.prod_B_mod_q[i], qi);
+                for (int j = 0; j < B; j++)
+                    BQm[static_cast<std::size_t>(i) * B + j] = mont(hr.B_to_q.matrix[static_cast<std::size_t>(i) * B + j], qi);
+            }
+            for (int j = 0; j < B; j++)
+                rd.B_to_mskm[j] = mont(hr.B_to_m_sk.matrix[j], hr.m_sk);
+            rd.inv_prod_B_mod_msk_s = shoup(hr.inv_prod_B_mod_m_sk, hr.m_sk);
+            rd.lift_L1m = upload<u64>(*this, lt.owned, L1m.data(), L1m.size());
+            rd.floor_G2m = upload<u64>(*this, lt.owned, G2m.data(), G2m.size());
+            rd.B_to_qm = upload<u64>(*this, lt.owned, BQm.data(), BQm.size());
+            // REDC lands below 2p iff (sum of the bounds of the variable factors) <= 2^64:
+            //   lift rows:   k terms t_i < q_i plus temp < b_j;  floor Bsk rows: in < b_j plus k terms < q_i;
+            //   conv_sk: B terms < b;  out rows: B terms tb_j < b_j plus alpha-term < m_sk
+            const u128 lim = static_cast<u128>(1) << 64;
+            const u128 s1 = static_cast<u128>(k) * max_q + max_b;
+            const u128 s2 = static_cast<u128>(B + 1) * max_b;
+            rd.redc_small = (s1 <= lim && s2 <= lim) ? 1 : 0;
         }
         lt.h_rns = rd;
         lt.d_rns = upload<RnsDev>(*this, lt.owned, &rd, 1);

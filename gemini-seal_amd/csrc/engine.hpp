@@ -89,6 +89,14 @@ namespace sealhip
         u64 lift_L2[kMaxModuli + 2];  // prod_q * m_tilde^{-1} mod b_j
         u64 floor_G1[kMaxModuli + 2]; // t * (prod q)^{-1} [* B^_j^{-1} for j < B] mod b_j
         u64 floor_F0[kMaxModuli];     // t * (q^_i)^{-1} mod q_i
+        // Montgomery/Shoup companions of the folded constants (suffix m: times 2^64 mod the row's prime; s: Shoup)
+        const u64 *lift_L1m, *floor_G2m, *B_to_qm; // [nB][k], [nB][k], [k][B]
+        u64 lift_L2m[kMaxModuli + 2], floor_G1m[kMaxModuli + 2];
+        u64 q_mt_inv_s[kMaxModuli], floor_F0_s[kMaxModuli];
+        u64 B_to_mskm[kMaxModuli + 1];
+        u64 inv_prod_B_mod_msk_s;
+        u64 pBm[kMaxModuli], nBm[kMaxModuli]; // prod_B_mod_q * 2^64, (q - prod_B_mod_q) * 2^64  (mod q_i)
+        int redc_small;                        // every REDC of the fused kernels provably lands below 2p
         unsigned short q_prime[kMaxModuli];       // prime ids of q rows
         unsigned short bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
     };

@@ -161,23 +161,24 @@ namespace sealhip
                 if (i < k)
                 {
                     const PrimeDev &Q = primes[d->q_prime[i]];
-                    t[i] = mul_mod(pin[i * N], d->q_mt_inv[i], Q.p, Q.cr0, Q.cr1);
+                    t[i] = mulmod_shoup(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], Q.p); // exact canonical product
                     acc += t[i] * d->q_to_mt[i];
                 }
             const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
+            const bool small = d->redc_small != 0;
             for (int j = 0; j < nB; j++)
             {
                 const PrimeDev &Bp = primes[d->bsk_prime[j]];
                 u64 temp = r_mt;
                 if (temp >= (1ull << 31))
                     temp += Bp.p - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
-                const u64 *row = d->lift_L1 + j * k;
-                u64 lo = temp * d->lift_L2[j], hi = mulhi(temp, d->lift_L2[j]);
+                const u64 *row = d->lift_L1m + j * k; // constants carry the factor 2^64: REDC removes it
+                u64 lo = temp * d->lift_L2m[j], hi = mulhi(temp, d->lift_L2m[j]);
 #pragma unroll
                 for (int i = 0; i < KMAX; i++)
                     if (i < k)
                         mac128(lo, hi, t[i], row[i]);
-                pout[j * N] = barrett_reduce_128(lo, hi, Bp.p, Bp.cr0, Bp.cr1);
+                pout[j * N] = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
             }
         }
 
@@ -228,23 +229,24 @@ namespace sealhip
                 {
                     const PrimeDev &Q = primes[d->q_prime[i]];
                     const u64 xin = DEFER ? load_after_top(pitem + i * N, c_lo, half, is_hi, Q) : pin[i * N];
-                    t[i] = mul_mod(xin, d->floor_F0[i], Q.p, Q.cr0, Q.cr1);
+                    t[i] = mulmod_shoup(xin, d->floor_F0[i], d->floor_F0_s[i], Q.p);
                 }
             u64 tb[KMAX + 1];
             u64 fl_sk = 0;
+            const bool small = d->redc_small != 0;
 #pragma unroll
             for (int j = 0; j < KMAX + 2; j++)
                 if (j <= B)
                 {
                     const PrimeDev &Bp = primes[d->bsk_prime[j]];
-                    const u64 *row = d->floor_G2 + j * k;
+                    const u64 *row = d->floor_G2m + j * k;
                     const u64 x = DEFER ? load_after_top(pitem + (k + j) * N, c_lo, half, is_hi, Bp) : pin[(k + j) * N];
-                    u64 lo = x * d->floor_G1[j], hi = mulhi(x, d->floor_G1[j]);
+                    u64 lo = x * d->floor_G1m[j], hi = mulhi(x, d->floor_G1m[j]);
 #pragma unroll
                     for (int i = 0; i < KMAX; i++)
                         if (i < k)
                             mac128(lo, hi, t[i], row[i]);
-                    const u64 v = barrett_reduce_128(lo, hi, Bp.p, Bp.cr0, Bp.cr1);
+                    const u64 v = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
                     if (j < B)
                         tb[j < KMAX + 1 ? j : 0] = v;
                     else
@@ -255,23 +257,22 @@ namespace sealhip
 #pragma unroll
             for (int j = 0; j < KMAX + 1; j++)
                 if (j < B)
-                    mac128(lo, hi, tb[j], d->B_to_msk[j]);
-            const u64 conv_sk = barrett_reduce_128(lo, hi, Msk.p, Msk.cr0, Msk.cr1);
-            const u64 alpha = mul_mod(conv_sk + (Msk.p - fl_sk), d->inv_prod_B_mod_msk, Msk.p, Msk.cr0, Msk.cr1);
+                    mac128(lo, hi, tb[j], d->B_to_mskm[j]);
+            const u64 conv_sk = redc_finish(redc128(lo, hi, Msk.p, Msk.ninv), Msk.p, Msk.rdp, small);
+            const u64 alpha = mulmod_shoup(conv_sk + (Msk.p - fl_sk), d->inv_prod_B_mod_msk, d->inv_prod_B_mod_msk_s, Msk.p);
             const bool neg = alpha > (Msk.p >> 1); // rns.cpp:909
             const u64 a2 = neg ? Msk.p - alpha : alpha;
             for (int i = 0; i < k; i++)
             {
                 const PrimeDev &Q = primes[d->q_prime[i]];
-                const u64 pB = d->prod_B_mod_q[i];
-                const u64 c = neg ? pB : Q.p - pB;
-                const u64 *mrow = d->B_to_q + i * B;
+                const u64 c = neg ? d->pBm[i] : d->nBm[i];
+                const u64 *mrow = d->B_to_qm + i * B;
                 u64 l2 = a2 * c, h2 = mulhi(a2, c);
 #pragma unroll
                 for (int j = 0; j < KMAX + 1; j++)
                     if (j < B)
                         mac128(l2, h2, tb[j], mrow[j]);
-                pout[i * N] = barrett_reduce_128(l2, h2, Q.p, Q.cr0, Q.cr1);
+                pout[i * N] = redc_finish(redc128(l2, h2, Q.p, Q.ninv), Q.p, Q.rdp, small);
             }
         }
 
