@@ -140,6 +140,8 @@ namespace sealhip
         // (rns.cpp:1062-1067 + :960-980) is a composition of exact modular operations, so it equals
         //   out = ( sum_i t_i*(M_ji*m_tilde^{-1}) + temp*(prod_q*m_tilde^{-1}) ) mod b
         // with ONE 128-bit accumulation and ONE Barrett reduction per output instead of three.
+        // KMAX < 0 means "exactly K = -KMAX primes, known at compile time" (no per-iteration guards, constants
+        // fetched with wide scalar loads); KMAX > 0 is the guarded form for any k <= KMAX
         template <int KMAX>
         __global__ __launch_bounds__(kThreads) void bfv_lift2_kernel(const RnsDev *__restrict__ d,
                                                                      const PrimeDev *__restrict__ primes,
@@ -150,15 +152,16 @@ namespace sealhip
             Cols cc;
             if (!column(count, logn, cc))
                 return;
-            const int k = d->k, nB = d->nB;
+            constexpr int KA = KMAX < 0 ? -KMAX : KMAX; // array extent
+            const int k = KMAX < 0 ? KA : d->k, nB = d->nB;
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
             u64 *pout = out + cc.item * out_stride + cc.c;
-            u64 t[KMAX];
+            u64 t[KA];
             u64 acc = 0;
 #pragma unroll
-            for (int i = 0; i < KMAX; i++)
-                if (i < k)
+            for (int i = 0; i < KA; i++)
+                if (KMAX < 0 || i < k)
                 {
                     const PrimeDev &Q = primes[d->q_prime[i]];
                     t[i] = mulmod_shoup(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], Q.p); // exact canonical product
@@ -175,8 +178,8 @@ namespace sealhip
                 const u64 *row = d->lift_L1m + j * k; // constants carry the factor 2^64: REDC removes it
                 u64 lo = temp * d->lift_L2m[j], hi = mulhi(temp, d->lift_L2m[j]);
 #pragma unroll
-                for (int i = 0; i < KMAX; i++)
-                    if (i < k)
+                for (int i = 0; i < KA; i++)
+                    if (KMAX < 0 || i < k)
                         mac128(lo, hi, t[i], row[i]);
                 pout[j * N] = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
             }
@@ -215,27 +218,28 @@ namespace sealhip
             Cols cc;
             if (!column(count, logn, cc))
                 return;
-            const int k = d->k, B = d->B;
+            constexpr int KA = KMAX < 0 ? -KMAX : KMAX;
+            const int k = KMAX < 0 ? KA : d->k, B = d->B; // B is k or k + 1
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
             const u64 *pitem = in + cc.item * in_stride;
             const std::size_t half = N >> 1, c_lo = cc.c & (half - 1);
             const bool is_hi = cc.c >= half; // block-uniform (N/2 is a multiple of the block size)
             u64 *pout = out + cc.item * out_stride + cc.c;
-            u64 t[KMAX];
+            u64 t[KA];
 #pragma unroll
-            for (int i = 0; i < KMAX; i++)
-                if (i < k)
+            for (int i = 0; i < KA; i++)
+                if (KMAX < 0 || i < k)
                 {
                     const PrimeDev &Q = primes[d->q_prime[i]];
                     const u64 xin = DEFER ? load_after_top(pitem + i * N, c_lo, half, is_hi, Q) : pin[i * N];
                     t[i] = mulmod_shoup(xin, d->floor_F0[i], d->floor_F0_s[i], Q.p);
                 }
-            u64 tb[KMAX + 1];
+            u64 tb[KA + 1];
             u64 fl_sk = 0;
             const bool small = d->redc_small != 0;
 #pragma unroll
-            for (int j = 0; j < KMAX + 2; j++)
+            for (int j = 0; j < KA + 2; j++)
                 if (j <= B)
                 {
                     const PrimeDev &Bp = primes[d->bsk_prime[j]];
@@ -243,19 +247,19 @@ namespace sealhip
                     const u64 x = DEFER ? load_after_top(pitem + (k + j) * N, c_lo, half, is_hi, Bp) : pin[(k + j) * N];
                     u64 lo = x * d->floor_G1m[j], hi = mulhi(x, d->floor_G1m[j]);
 #pragma unroll
-                    for (int i = 0; i < KMAX; i++)
-                        if (i < k)
+                    for (int i = 0; i < KA; i++)
+                        if (KMAX < 0 || i < k)
                             mac128(lo, hi, t[i], row[i]);
                     const u64 v = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
                     if (j < B)
-                        tb[j < KMAX + 1 ? j : 0] = v;
+                        tb[j < KA + 1 ? j : 0] = v;
                     else
                         fl_sk = v;
                 }
             const PrimeDev &Msk = primes[d->bsk_prime[B]];
             u64 lo = 0, hi = 0;
 #pragma unroll
-            for (int j = 0; j < KMAX + 1; j++)
+            for (int j = 0; j < KA + 1; j++)
                 if (j < B)
                     mac128(lo, hi, tb[j], d->B_to_mskm[j]);
             const u64 conv_sk = redc_finish(redc128(lo, hi, Msk.p, Msk.ninv), Msk.p, Msk.rdp, small);
@@ -269,7 +273,7 @@ namespace sealhip
                 const u64 *mrow = d->B_to_qm + i * B;
                 u64 l2 = a2 * c, h2 = mulhi(a2, c);
 #pragma unroll
-                for (int j = 0; j < KMAX + 1; j++)
+                for (int j = 0; j < KA + 1; j++)
                     if (j < B)
                         mac128(l2, h2, tb[j], mrow[j]);
                 pout[i * N] = redc_finish(redc128(l2, h2, Q.p, Q.ninv), Q.p, Q.rdp, small);
@@ -553,14 +557,28 @@ namespace sealhip
         ProfScope prof(e, "bfv_lift", 0);
         if (h.k <= 32 && !e.unfused_rns)
         {
-            if (h.k <= 4)
-                bfv_lift2_kernel<4><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
-            else if (h.k <= 8)
-                bfv_lift2_kernel<8><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
-            else if (h.k <= 16)
-                bfv_lift2_kernel<16><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
-            else
-                bfv_lift2_kernel<32><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+#define SEALHIP_LIFT2(KM) bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn)
+            switch (h.k)
+            {
+            case 1: SEALHIP_LIFT2(-1); break;
+            case 2: SEALHIP_LIFT2(-2); break;
+            case 3: SEALHIP_LIFT2(-3); break;
+            case 4: SEALHIP_LIFT2(-4); break;
+            case 5: SEALHIP_LIFT2(-5); break;
+            case 6: SEALHIP_LIFT2(-6); break;
+            case 7: SEALHIP_LIFT2(-7); break;
+            case 8: SEALHIP_LIFT2(-8); break;
+            case 9: SEALHIP_LIFT2(-9); break;
+            case 10: SEALHIP_LIFT2(-10); break;
+            case 11: SEALHIP_LIFT2(-11); break;
+            case 12: SEALHIP_LIFT2(-12); break;
+            case 13: SEALHIP_LIFT2(-13); break;
+            case 14: SEALHIP_LIFT2(-14); break;
+            case 15: SEALHIP_LIFT2(-15); break;
+            case 16: SEALHIP_LIFT2(-16); break;
+            default: SEALHIP_LIFT2(32); break;
+            }
+#undef SEALHIP_LIFT2
             return hipGetLastError();
         }
         SEALHIP_DISPATCH_K(h.k, bfv_lift_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
@@ -610,14 +628,26 @@ namespace sealhip
             bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,      \
                                                                             out_stride, count, e.logn);             \
     } while (0)
-            if (h.k <= 4)
-                SEALHIP_FLOOR2(4);
-            else if (h.k <= 8)
-                SEALHIP_FLOOR2(8);
-            else if (h.k <= 16)
-                SEALHIP_FLOOR2(16);
-            else
-                SEALHIP_FLOOR2(32);
+            switch (h.k)
+            {
+            case 1: SEALHIP_FLOOR2(-1); break;
+            case 2: SEALHIP_FLOOR2(-2); break;
+            case 3: SEALHIP_FLOOR2(-3); break;
+            case 4: SEALHIP_FLOOR2(-4); break;
+            case 5: SEALHIP_FLOOR2(-5); break;
+            case 6: SEALHIP_FLOOR2(-6); break;
+            case 7: SEALHIP_FLOOR2(-7); break;
+            case 8: SEALHIP_FLOOR2(-8); break;
+            case 9: SEALHIP_FLOOR2(-9); break;
+            case 10: SEALHIP_FLOOR2(-10); break;
+            case 11: SEALHIP_FLOOR2(-11); break;
+            case 12: SEALHIP_FLOOR2(-12); break;
+            case 13: SEALHIP_FLOOR2(-13); break;
+            case 14: SEALHIP_FLOOR2(-14); break;
+            case 15: SEALHIP_FLOOR2(-15); break;
+            case 16: SEALHIP_FLOOR2(-16); break;
+            default: SEALHIP_FLOOR2(32); break;
+            }
 #undef SEALHIP_FLOOR2
             return hipGetLastError();
         }
