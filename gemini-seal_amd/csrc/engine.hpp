@@ -183,9 +183,10 @@ namespace sealhip
         LevelTools &level(int k);       // builds host + device constants on first use
         LevelTools &level_host(int k);  // host constants only
         const std::uint32_t *galois_table(std::uint32_t elt);
+        std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
         void ws_reset()
         {
-            ws_used = 0;
+            ws_used = ws_floor;
         }
         u64 *ws_alloc(std::size_t words);
         void ws_reserve(std::size_t bytes);

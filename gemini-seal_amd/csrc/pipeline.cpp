@@ -35,7 +35,7 @@ namespace sealhip
             const std::size_t budget = workspace_budget_bytes();
             std::size_t chunk = budget / (bytes_per_item ? bytes_per_item : 1);
             chunk = std::max<std::size_t>(1, std::min(chunk, count));
-            e.ws_reserve(chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
+            e.ws_reserve(e.ws_floor + chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
             return chunk;
         }
 
@@ -54,6 +54,19 @@ namespace sealhip
             return m;
         }
     } // namespace
+
+    // bytes of arena one item of op_switch_key needs (shared with op_apply_galois, which must size the arena
+    // before it parks its own scratch at the front)
+    static std::size_t switch_key_item_bytes(Engine &e, int k)
+    {
+        LevelTools &lt = e.level(k);
+        const std::size_t N = e.n;
+        const std::size_t rows = static_cast<std::size_t>(k + e.nsp), nd = static_cast<std::size_t>(lt.h_ks.nd);
+        const bool ckks = e.scheme == 2;
+        const bool strict_bfv = e.mode_strict && !ckks;
+        const std::size_t w_coeff = (ckks || strict_bfv) ? static_cast<std::size_t>(k) * N : 0;
+        return (w_coeff + nd * rows * N + 2 * rows * N + 2 * static_cast<std::size_t>(k) * N) * sizeof(u64);
+    }
 
     // ------------------------------------------------------------------------------------------
     // switch_key_inplace (evaluator.cpp:2259-2368)
@@ -76,7 +89,9 @@ namespace sealhip
         const std::size_t w_ext = static_cast<std::size_t>(nd) * rows * N;
         const std::size_t w_prod = 2ull * rows * N;
         const std::size_t w_temp = 2ull * k * N;
-        const std::size_t per_item = (w_coeff + w_ext + w_prod + w_temp) * sizeof(u64);
+        const std::size_t per_item = switch_key_item_bytes(e, k);
+        if (per_item != (w_coeff + w_ext + w_prod + w_temp) * sizeof(u64))
+            throw std::logic_error("internal: arena accounting mismatch");
         const std::size_t chunk = plan_chunk(e, count, per_item, 4);
         const RowMap map_q = lt.map_q;
         const RowMap map_rows = lt.map_key;
@@ -360,32 +375,42 @@ namespace sealhip
         LevelTools &lt = e.level(k);
         const std::size_t N = e.n, poly = static_cast<std::size_t>(k) * N;
         const std::uint32_t *table = e.scheme == 2 ? e.galois_table(elt) : nullptr;
-        // the Galois image of both components needs count * 2 polys of scratch *outside* the arena that
-        // op_switch_key re-plans, so it is carved from the front of the arena after reserving both needs
+        // The Galois image of both components (2 polys per item) must survive op_switch_key, which re-plans the
+        // arena: it is carved from the FRONT of the arena (ws_floor) for the duration of this operation.
         const std::size_t per_item = 2 * poly * sizeof(u64);
-        const std::size_t budget_items = std::max<std::size_t>(1, std::min<std::size_t>(count, (512ull << 20) / per_item));
-        u64 *scratch = nullptr;
-        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&scratch), budget_items * per_item));
-        try
+        const std::size_t items = std::max<std::size_t>(1, std::min<std::size_t>(count, (1024ull << 20) / per_item));
+        const std::size_t scratch_bytes = (items * per_item + 255) & ~static_cast<std::size_t>(255);
+        // the arena must hold the scratch plus at least one item of the key switch; growing it may move it
+        e.ws_reserve(scratch_bytes + 256);
+        struct FloorGuard
         {
-            for (std::size_t off = 0; off < count; off += budget_items)
+            Engine &e;
+            std::size_t saved;
+            ~FloorGuard()
             {
-                const std::size_t m = std::min(budget_items, count - off);
-                u64 *c = ct + off * 2 * poly;
-                check(launch_galois(e, c, scratch, m * 2 * k, lt.map_q, elt, table), "galois");
-                check(launch_copy_rows(e, scratch, 2 * poly, c, 2 * poly, m, k), "copy(c0)"); // :1903 / :1917
-                SEALHIP_CHECK(hipMemset2DAsync(c + poly, 2 * poly * sizeof(u64), 0, poly * sizeof(u64), m,
-                                               e.stream)); // :1928
-                op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
+                e.ws_floor = saved;
             }
-            SEALHIP_CHECK(hipStreamSynchronize(e.stream));
-        }
-        catch (...)
+        } guard{ e, e.ws_floor };
+        e.ws_floor = guard.saved + scratch_bytes;
+        for (std::size_t off = 0; off < count; off += items)
         {
-            (void)hipStreamSynchronize(e.stream);
-            (void)hipFree(scratch);
-            throw;
+            const std::size_t m = std::min(items, count - off);
+            u64 *c = ct + off * 2 * poly;
+            // (re-derive the pointer every iteration: a nested ws_reserve may have re-allocated the arena, but only
+            //  while no scratch contents are live, i.e. before the first launch of this iteration)
+            {
+                // size the arena now exactly as the nested op_switch_key will ask for, so that it cannot move
+                // while the scratch is live
+                const std::size_t ks_item = switch_key_item_bytes(e, k);
+                const std::size_t ks_chunk = std::max<std::size_t>(1, std::min(workspace_budget_bytes() / ks_item, m));
+                e.ws_reserve(e.ws_floor + ks_chunk * ks_item + 4 * 256);
+            }
+            u64 *scratch = reinterpret_cast<u64 *>(static_cast<char *>(e.ws) + guard.saved);
+            check(launch_galois(e, c, scratch, m * 2 * k, lt.map_q, elt, table), "galois");
+            check(launch_copy_rows(e, scratch, 2 * poly, c, 2 * poly, m, k), "copy(c0)"); // :1903 / :1917
+            SEALHIP_CHECK(hipMemset2DAsync(c + poly, 2 * poly * sizeof(u64), 0, poly * sizeof(u64), m,
+                                           e.stream)); // :1928
+            op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
         }
-        SEALHIP_CHECK(hipFree(scratch));
     }
 } // namespace sealhip
