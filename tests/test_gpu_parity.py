@@ -610,3 +610,36 @@ def test_full_size_batch_indexing_and_threads(sealhip):
         for c in range(count):
             assert h(mul[c]) == row["digests"]["mul"]
             assert h(np.ascontiguousarray(relin[c])) == row["digests"]["relin"]
+
+
+def test_small_vectors_full_words(sealhip):
+    """Committed full vectors (tests/golden/small_vectors.json): every output word of the HIP path."""
+    SV = json.load(open(os.path.join(HERE, "golden", "small_vectors.json")))
+    for case in SV["ntt"]:
+        logn, p = case["logn"], case["p"]
+        n = 1 << logn
+        ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, [p, O.get_primes(n, 20, 1)[0]], 1, 0)
+        x = np.array(case["x"], dtype=np.uint64)
+        for name, fn in (("fwd_lazy", ctx.ntt_negacyclic_harvey_lazy), ("fwd", ctx.ntt_negacyclic_harvey),
+                         ("inv_lazy", ctx.inverse_ntt_negacyclic_harvey_lazy), ("inv", ctx.inverse_ntt_negacyclic_harvey)):
+            d = ctx.upload(x)
+            fn(d, 1, 1)
+            assert d.download().tolist() == case[name], (logn, name)
+    for ch in SV["chains"]:
+        n, k = 1 << ch["logn"], ch["k"]
+        ctx = sealhip.Context(ch["scheme"], ch["logn"], ch["key_moduli"], ch["nsp"], ch["t"])
+        ev = sealhip.Evaluator(ctx)
+        key = sealhip.KSwitchKeys(ctx, np.array(ch["key"], dtype=np.uint64))
+        a, b = np.array(ch["a"], dtype=np.uint64), np.array(ch["b"], dtype=np.uint64)
+        c = ctx.alloc(3 * k * n)
+        ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, 1, c)
+        assert c.download((3, k, n)).tolist() == ch["multiply"]
+        ev.relinearize_inplace(c, 3, k, 1, [key])
+        c2 = c.download((3, k, n))[:2].copy()
+        assert c2.tolist() == ch["relinearize"]
+        o = ctx.alloc(2 * (k - 1) * n)
+        (ev.mod_switch_to_next if ch["scheme"] == 1 else ev.rescale_to_next)(ctx.upload(c2), 2, k, 1, o)
+        assert o.download((2, k - 1, n)).tolist() == ch["mod_switch_scale_to_next"]
+        g = ctx.upload(c2)
+        ev.rotate_vector_inplace(g, k, 1, 3, {ch["galois_elt_step3"]: key})
+        assert g.download((2, k, n)).tolist() == ch["apply_galois"]

@@ -335,3 +335,14 @@ def test_digest_end_to_end(row):
 
     got = synth.run_reference_chain(row)
     assert got == row["digests"]
+
+
+def test_small_vectors_regression():
+    """The committed full small-N vectors (made by the pinned oracle) still come out of the oracle word for word."""
+    import subprocess
+    import sys
+
+    path = os.path.join(HERE, "golden", "small_vectors.json")
+    before = open(path).read()
+    subprocess.check_call([sys.executable, os.path.join(HERE, "golden", "make_small_vectors.py")], stdout=subprocess.DEVNULL)
+    assert open(path).read() == before
