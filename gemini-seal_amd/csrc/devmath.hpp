@@ -138,4 +138,111 @@ namespace sealhip
     {
         return a ? p - a : 0;
     }
+
+    // ---------------------------------------------------------------------------------------------
+    // Hand-selected instruction sequences for the NTT butterflies. The compiler's expansion of a 64-bit
+    // mulhi / mullo spends 4 moves per product on zero-extending 32-bit halves into the 64-bit addend of
+    // v_mad_u64_u32 and splits the middle sum; here the middle sum keeps its carry (one v_cndmask) and the
+    // low products are chained through the 64-bit accumulator of v_mad_u64_u32, whose upper half is
+    // don't-care for them. 16 VALU instructions per lazy forward butterfly instead of 21 (10 multiplier
+    // ops in both); bit-identical results (everything is arithmetic mod 2^64). tools/ubench_intmul.hip:
+    // 1.69 -> 2.04 T butterflies/s with per-lane twiddles.
+    // SU = the second factor is wave-uniform (kept in SGPRs; one scalar operand per VOP3 is allowed).
+    using u32 = unsigned;
+    template <bool SU>
+    __device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) // a*b + c  (mod 2^64)
+    {
+        u64 d, cy;
+        if (SU)
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b), "v"(c));
+        else
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
+    template <bool SU>
+    __device__ __forceinline__ u64 mul64(u32 a, u32 b) // a*b
+    {
+        u64 d, cy;
+        if (SU)
+            asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "s"(b));
+        else
+            asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+        return d;
+    }
+    // floor(x*s / 2^64), exact. The carry of x0*s1 + (x1*s0 + hi32(x0*s0)) is turned into a register inside
+    // the same asm statement (gfx950 needs two wait states between a VALU carry write and its VALU read).
+    template <bool SU>
+    __device__ __forceinline__ u64 mulhi_c(u64 x, u64 s)
+    {
+        const u32 x0 = static_cast<u32>(x), x1 = static_cast<u32>(x >> 32);
+        const u32 s0 = static_cast<u32>(s), s1 = static_cast<u32>(s >> 32);
+        const u32 h = __umulhi(x0, s0);
+        const u64 A = mad64<SU>(x1, s0, static_cast<u64>(h));
+        u64 B;
+        u32 cb;
+        if (SU)
+            asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, vcc"
+                : "=&v"(B), "=&v"(cb)
+                : "v"(x0), "s"(s1), "v"(A)
+                : "vcc");
+        else
+            asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, vcc"
+                : "=&v"(B), "=&v"(cb)
+                : "v"(x0), "v"(s1), "v"(A)
+                : "vcc");
+        const u64 addend = static_cast<u64>(static_cast<u32>(B >> 32)) | (static_cast<u64>(cb) << 32);
+        return mad64<SU>(x1, s1, addend);
+    }
+    __device__ __forceinline__ u64 add_hi32(u64 v, u64 e) // v + (e << 32)
+    {
+        u32 vh;
+        asm("v_add_u32 %0, %1, %2" : "=v"(vh) : "v"(static_cast<u32>(v >> 32)), "v"(static_cast<u32>(e)));
+        return static_cast<u64>(static_cast<u32>(v)) | (static_cast<u64>(vh) << 32);
+    }
+    // lo64(acc + x*w + q*np); np (= 2^64 - p) is always wave-uniform
+    template <bool WU>
+    __device__ __forceinline__ u64 mullo2_acc(u64 acc, u64 x, u64 w, u64 q, u64 np)
+    {
+        const u32 x0 = static_cast<u32>(x), x1 = static_cast<u32>(x >> 32);
+        const u32 w0 = static_cast<u32>(w), w1 = static_cast<u32>(w >> 32);
+        const u32 q0 = static_cast<u32>(q), q1 = static_cast<u32>(q >> 32);
+        const u32 n0 = static_cast<u32>(np), n1 = static_cast<u32>(np >> 32);
+        u64 E = mul64<WU>(x0, w1);
+        E = mad64<WU>(x1, w0, E);
+        E = mad64<true>(q0, n1, E);
+        E = mad64<true>(q1, n0, E);
+        u64 V = mad64<WU>(x0, w0, acc);
+        V = mad64<true>(q0, n0, V);
+        return add_hi32(V, E);
+    }
+    // lo64(acc + q*np)
+    __device__ __forceinline__ u64 mullo1_acc(u64 acc, u64 q, u64 np)
+    {
+        const u32 q0 = static_cast<u32>(q), q1 = static_cast<u32>(q >> 32);
+        const u32 n0 = static_cast<u32>(np), n1 = static_cast<u32>(np >> 32);
+        u64 E = mul64<true>(q0, n1);
+        E = mad64<true>(q1, n0, E);
+        return add_hi32(mad64<true>(q0, n0, acc), E);
+    }
+    // mulmod_lazy_np with the sequences above
+    template <bool WU>
+    __device__ __forceinline__ u64 mulmod_lazy_hs(u64 x, u64 y, u64 yshoup, u64 neg_p)
+    {
+        return mullo2_acc<WU>(0, x, y, mulhi_c<WU>(x, yshoup), neg_p);
+    }
+    // barrett_lazy with the sequences above: x + q*(2^64-p); rdp is wave-uniform
+    __device__ __forceinline__ u64 barrett_lazy_hs(u64 x, u64 rdp, u64 neg_p)
+    {
+        return mullo1_acc(x, mulhi_c<true>(x, rdp), neg_p);
+    }
+    // forward lazy butterfly (ntt.cpp:245-252): X = u + v, Y = u - v + 2p with v = y*w - q*p.
+    // X falls out of the multiply-accumulate chain (u is its initial accumulator); Y = (2u + 2p) - X.
+    template <bool WU>
+    __device__ __forceinline__ void butterfly_fwd_hs(u64 &xu, u64 &xy, u64 w, u64 wshoup, u64 neg_p, u64 two_p)
+    {
+        const u64 u = xu;
+        const u64 X = mullo2_acc<WU>(u, xy, w, mulhi_c<WU>(xy, wshoup), neg_p);
+        xu = X;
+        xy = (u << 1) + two_p - X;
+    }
 } // namespace sealhip

@@ -331,6 +331,13 @@ namespace sealhip
         typedef const __attribute__((address_space(1))) u64x2 *tw_global_t;
         typedef const __attribute__((address_space(4))) u64x2 *tw_const_t;
 
+        // sched_barrier mask: only VMEM reads and SALU may move across (twiddle loads keep hoisting, the
+        // multiply chains of different butterfly groups do not interleave -> bounded register pressure)
+        constexpr int kSchedLoadsOnly = 0x0020 | 0x0004;
+#ifndef SEALHIP_FWD_GROUP_MASK
+#define SEALHIP_FWD_GROUP_MASK 3
+#endif
+        constexpr int kFwdGroupMask = SEALHIP_FWD_GROUP_MASK;
         // all butterflies of one layer (slot bit W) on the 32 registers; PARITY/STRICT as in ntt_pass_kernel.
         // UNIFORM: the twiddle index does not depend on the lane (round 1) -> scalar loads.
         template <int T, int R, int W, bool STRICT, bool UNIFORM>
@@ -350,19 +357,26 @@ namespace sealhip
                     Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
                 else
                     Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
-                u64 u = x[s];
                 if (STRICT)
-                    u = u >= two_p ? u - two_p : u;
+                    x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                 else if (gb == 0)
-                    u = barrett_lazy(u, rdp, p); // ForwardLazyLast, ntt.cpp:254-261
-                const u64 v = mulmod_lazy_np(x[s | bit], Wv.x, Wv.y, neg_p);
-                x[s] = u + v; // ForwardLazy, ntt.cpp:245-252
-                x[s | bit] = u - v + two_p;
+                    x[s] = barrett_lazy_hs(x[s], rdp, neg_p); // ForwardLazyLast, ntt.cpp:254-261
+                butterfly_fwd_hs<UNIFORM>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
+                if ((s & kFwdGroupMask) == kFwdGroupMask)
+                    __builtin_amdgcn_sched_barrier(kSchedLoadsOnly); // bound the number of butterflies in flight
             }
         }
 
         // final round, one group at a time: the low f index bits of the 2^f registers that share the filler
         // slot bits G are finished (layers f-1 .. 0) and stored right away, which bounds the live twiddles
+        // Measurement-only hooks (compiled with -DSEALHIP_NTT_EXPERIMENT, driven by SEALHIP_NTT_SKIP): drop the
+        // arithmetic (0x100), the LDS exchanges (0x200) or the top-layer products (0x400) to time the rest.
+#ifdef SEALHIP_NTT_EXPERIMENT
+#define NTT_EXP(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define NTT_EXP(flags, bit) false
+#endif
+
         template <int T, bool STRICT, int G>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
@@ -371,8 +385,10 @@ namespace sealhip
 #pragma unroll
             for (int W = f - 1; W >= 0; W--)
             {
+                if (NTT_EXP(N, 0x100 << 20))
+                    break;
                 const int gb = Arr<T, 4>::slot_bit(W);
-                const int tb = (N + jb) >> (gb + 1);
+                const int tb = ((N & 0xFFFFF) + jb) >> (gb + 1); // (the experiment build carries its hooks in N's top bits)
                 const int bit = 1 << W;
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
@@ -381,14 +397,11 @@ namespace sealhip
                         continue;
                     const int s = (G << f) | e;
                     const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
-                    u64 u = x[s];
                     if (STRICT)
-                        u = u >= two_p ? u - two_p : u;
+                        x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0)
-                        u = barrett_lazy(u, rdp, p);
-                    const u64 v = mulmod_lazy_np(x[s | bit], Wv.x, Wv.y, neg_p);
-                    x[s] = u + v;
-                    x[s | bit] = u - v + two_p;
+                        x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
+                    butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
                 }
             }
 #pragma unroll
@@ -405,6 +418,8 @@ namespace sealhip
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
+                if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
+                    continue;
                 *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
             }
         }
@@ -508,8 +523,23 @@ namespace sealhip
             return true;
         }
 
+#ifdef SEALHIP_NTT_EXPERIMENT
+        __device__ unsigned long long *g_ntt_trace = nullptr; // [block][8] timestamps (wall clock, 100 MHz)
+#define NTT_STAMP(i)                                                                  \
+    do                                                                                \
+    {                                                                                 \
+        if ((flags & 0x2000) && tid == 0 && g_ntt_trace)                              \
+            g_ntt_trace[static_cast<std::size_t>(blockIdx.x) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define NTT_STAMP(i) \
+    do               \
+    {                \
+    } while (0)
+#endif
+
         template <int LOGN, bool STRICT>
-        __global__ __launch_bounds__(1 << (LOGN - 6), (LOGN == 16 ? 4 : 4)) void ntt_fwd_half_kernel(
+        __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
             unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src, std::size_t chunk)
         {
@@ -545,7 +575,19 @@ namespace sealhip
                     reduce = (code & kSrcReduce) != 0;
                 }
             }
-            if (half)
+            NTT_STAMP(0);
+            if (NTT_EXP(flags, 0x1000) && (blockIdx.x >> 3) >= 32 && (blockIdx.x >> 3) < 64)
+            {
+                for (int i = 0; i < ((flags >> 16) & 0xFF); i++)
+                    __builtin_amdgcn_s_sleep(127);
+            }
+            if (NTT_EXP(flags, 0x400))
+            {
+#pragma unroll
+                for (int i = 0; i < 32; i++)
+                    x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
+            }
+            else if (half)
                 h_load_top<T, STRICT, 1>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
             else
                 h_load_top<T, STRICT, 0>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
@@ -557,15 +599,23 @@ namespace sealhip
             // The signal is sent after the first LDS exchange: its barriers are only passed once every wave of
             // the workgroup has consumed all of its loaded values in round 1, so no extra wait or barrier is needed.
             const int gbase = half << T;
+            NTT_STAMP(1);
             // round 1: every lane index bit lies below the processed bits -> block-uniform twiddles
-            h_round<T, 1, STRICT, true>(x, tw, gbase, N, p, two_p, neg_p, rdp);
-            h_exchange<T, 1, 2>(x, lds, tid);
+            if (!NTT_EXP(flags, 0x100))
+                h_round<T, 1, STRICT, true>(x, tw, gbase, N, p, two_p, neg_p, rdp);
+            if (!NTT_EXP(flags, 0x200))
+                h_exchange<T, 1, 2>(x, lds, tid);
             if (tid == 0 && tickets)
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h_round<T, 2, STRICT, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p, neg_p, rdp);
-            h_exchange<T, 2, 3>(x, lds, tid);
-            h_round<T, 3, STRICT, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p, neg_p, rdp);
-            h_exchange<T, 3, 4>(x, lds, tid);
+            if (!NTT_EXP(flags, 0x100))
+                h_round<T, 2, STRICT, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p, neg_p, rdp);
+            if (!NTT_EXP(flags, 0x200))
+                h_exchange<T, 2, 3>(x, lds, tid);
+            if (!NTT_EXP(flags, 0x100))
+                h_round<T, 3, STRICT, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p, neg_p, rdp);
+            if (!NTT_EXP(flags, 0x200))
+                h_exchange<T, 3, 4>(x, lds, tid);
+            NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
             {
@@ -583,9 +633,22 @@ namespace sealhip
             }
             // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
             //  that both workgroups of the row have finished reading)
+            NTT_STAMP(3);
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
-            FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, gbase + Arr<T, 4>::tid_index(tid), N, p, two_p,
+            FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, gbase + Arr<T, 4>::tid_index(tid),
+                                                             NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N, p, two_p,
                                                              neg_p, rdp, (flags & kNttCanonical) != 0);
+            NTT_STAMP(4);
+#ifdef SEALHIP_NTT_EXPERIMENT
+            if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
+            {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_ntt_trace[static_cast<std::size_t>(blockIdx.x) * 8 + 5] = (static_cast<u64>(xcc) << 32) | hw;
+            }
+#endif
         }
 
         // ----------------------------------------------------------------------------------------
@@ -824,6 +887,40 @@ namespace sealhip
             unsigned *tickets = no_ticket ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
             if (!tickets && !no_ticket)
                 return hipErrorOutOfMemory;
+#ifdef SEALHIP_NTT_EXPERIMENT
+            if (const char *sk = std::getenv("SEALHIP_NTT_SKIP"))
+                flags |= static_cast<int>(std::strtol(sk, nullptr, 0));
+            unsigned long long *trace = nullptr;
+            const char *trace_path = std::getenv("SEALHIP_NTT_TRACE");
+            if (trace_path)
+            {
+                flags |= 0x2000;
+                if (hipMalloc(&trace, blocks * 64) != hipSuccess || hipMemset(trace, 0, blocks * 64) != hipSuccess ||
+                    hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_trace), &trace, sizeof(trace)) != hipSuccess)
+                    return hipErrorOutOfMemory;
+            }
+            struct TraceDump
+            {
+                unsigned long long *trace;
+                const char *path;
+                std::size_t blocks;
+                hipStream_t stream;
+                ~TraceDump()
+                {
+                    if (!trace)
+                        return;
+                    (void)hipStreamSynchronize(stream);
+                    std::vector<unsigned long long> h(blocks * 8);
+                    (void)hipMemcpy(h.data(), trace, blocks * 64, hipMemcpyDeviceToHost);
+                    if (FILE *f = std::fopen(path, "wb"))
+                    {
+                        std::fwrite(h.data(), 8, h.size(), f);
+                        std::fclose(f);
+                    }
+                    (void)hipFree(trace);
+                }
+            } trace_dump{trace, trace_path, blocks, e.stream};
+#endif
             ProfScope prof(e, "ntt_fwd_half", static_cast<double>(nrows));
             if (flags & kNttStrict)
                 ntt_fwd_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(

@@ -15,7 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsealhip.so")
+# SEALHIP_LIBRARY selects another build of the same HIP library (tools/: the measurement-only build); there is no
+# non-HIP implementation to select.
+LIB_PATH = os.environ.get("SEALHIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libsealhip.so")
 
 S_OK = 0
 E_POINTER = 0x80004003
