@@ -4,7 +4,11 @@
 // everything else -> E_UNEXPECTED), nothing thrown across the boundary.
 #include "../../include/sealhip.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
 #include <cstring>
 #include <new>
 
@@ -139,6 +143,24 @@ namespace
         check_launch(launch_poly_op(e, op, reinterpret_cast<const u64 *>(a), reinterpret_cast<const u64 *>(b), scalar,
                                     reinterpret_cast<u64 *>(r), count * map.rows, map),
                      "poly op");
+    }
+
+    // GaloisTool::get_elt_from_step (galois.cpp:49-91), generator 5 (util/galois.h:169)
+    std::uint32_t host_galois_elt_from_step(std::size_t n_, int step)
+    {
+        const uint32_t n = static_cast<uint32_t>(n_);
+        const uint64_t m = static_cast<uint64_t>(n) * 2;
+        if (step == 0)
+            return static_cast<uint32_t>(m - 1);
+        const bool negative = step < 0;
+        const uint32_t pos = static_cast<uint32_t>(negative ? -static_cast<int64_t>(step) : step);
+        if (pos >= (n >> 1))
+            throw std::invalid_argument("step count too large");
+        uint32_t s = negative ? (n >> 1) - pos : pos;
+        uint64_t elt = 1;
+        while (s--)
+            elt = (elt * 5) & (m - 1);
+        return static_cast<uint32_t>(elt);
     }
 
     LevelTools &bfv_level(Engine &e, uint32_t k)
@@ -569,23 +591,7 @@ long sealhip_galois_elt_from_step(const sealhip_context *ctx, int32_t step, uint
     REQUIRE_PTR(ctx);
     REQUIRE_PTR(galois_elt);
     return guarded([&] {
-        // galois.cpp:49-91, generator 5 (util/galois.h:169)
-        const uint32_t n = static_cast<uint32_t>(ctx->engine->n);
-        const uint64_t m = static_cast<uint64_t>(n) * 2;
-        if (step == 0)
-        {
-            *galois_elt = static_cast<uint32_t>(m - 1);
-            return;
-        }
-        const bool negative = step < 0;
-        const uint32_t pos = static_cast<uint32_t>(negative ? -static_cast<int64_t>(step) : step);
-        if (pos >= (n >> 1))
-            throw std::invalid_argument("step count too large");
-        uint32_t s = negative ? (n >> 1) - pos : pos;
-        uint64_t elt = 1;
-        while (s--)
-            elt = (elt * 5) & (m - 1);
-        *galois_elt = static_cast<uint32_t>(elt);
+        *galois_elt = host_galois_elt_from_step(ctx->engine->n, step);
     });
 }
 
@@ -840,6 +846,189 @@ long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint
     REQUIRE_PTR(ctx);
     REQUIRE_PTR(ct);
     return guarded([&] { ntt_entry(ctx, ct, count * size, k, SEALHIP_BASE_Q, true, kNttCanonical); });
+}
+
+/* ------------------------------------------------------------------ Evaluator surface beyond the hot path */
+
+long sealhip_evaluator_negate(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                              uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        check_launch(launch_ct_linear(e, CtLinearOp::Negate, reinterpret_cast<const u64 *>(ct), static_cast<int>(size),
+                                      nullptr, 0, 0, reinterpret_cast<u64 *>(out), count,
+                                      e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
+                     "negate");
+    });
+}
+
+static long add_sub_entry(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                          uint32_t size_b, size_t count, uint64_t *out, bool sub)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(b);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size_a < 1 || size_b < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        // in place (out == a) is only well defined when the result is not larger than a (the reference resizes
+        // encrypted1 first, evaluator.cpp:131-132; a raw buffer cannot grow)
+        if (out == a && size_b > size_a)
+            throw std::invalid_argument("in-place result needs a destination of max(size_a, size_b) polynomials");
+        check_launch(launch_ct_linear(e, sub ? CtLinearOp::Sub : CtLinearOp::Add, reinterpret_cast<const u64 *>(a),
+                                      static_cast<int>(size_a), reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), 0,
+                                      reinterpret_cast<u64 *>(out), count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
+                     sub ? "sub" : "add");
+    });
+}
+
+long sealhip_evaluator_add(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                           uint32_t size_b, size_t count, uint64_t *out)
+{
+    return add_sub_entry(ctx, k, a, size_a, b, size_b, count, out, false);
+}
+
+long sealhip_evaluator_sub(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                           uint32_t size_b, size_t count, uint64_t *out)
+{
+    return add_sub_entry(ctx, k, a, size_a, b, size_b, count, out, true);
+}
+
+long sealhip_evaluator_multiply_plain_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                          const uint64_t *plain_ntt, size_t plain_stride)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(plain_ntt);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (plain_stride != 0 && plain_stride < static_cast<size_t>(k) * e.n)
+            throw std::invalid_argument("plain_stride is smaller than one plaintext");
+        check_launch(launch_ct_linear(e, CtLinearOp::MulPlain, reinterpret_cast<const u64 *>(ct), static_cast<int>(size),
+                                      reinterpret_cast<const u64 *>(plain_ntt), 0, plain_stride, reinterpret_cast<u64 *>(ct),
+                                      count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
+                     "multiply_plain_ntt");
+    });
+}
+
+long sealhip_evaluator_multiply_plain(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                      const uint64_t *plain, size_t plain_stride)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(plain);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (plain_stride != 0 && plain_stride < e.n)
+            throw std::invalid_argument("plain_stride is smaller than one plaintext");
+        op_multiply_plain(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), static_cast<int>(size), count,
+                          reinterpret_cast<const u64 *>(plain), plain_stride);
+    });
+}
+
+long sealhip_is_transparent(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                            uint8_t *transparent)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(transparent);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (count == 0)
+            return;
+        if (size < 2) // ciphertext.h:474: fewer than SEAL_CIPHERTEXT_SIZE_MIN polynomials
+        {
+            std::fill(transparent, transparent + count, static_cast<uint8_t>(1));
+            return;
+        }
+        const std::size_t poly_words = static_cast<std::size_t>(k) * e.n;
+        e.ws_reserve(e.ws_floor + count * sizeof(unsigned) + 512);
+        e.ws_reset();
+        unsigned *flags = reinterpret_cast<unsigned *>(e.ws_alloc((count * sizeof(unsigned) + 7) / 8));
+        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.stream));
+        check_launch(launch_nonzero_tail(e, reinterpret_cast<const u64 *>(ct), poly_words * size, poly_words, count, flags),
+                     "is_transparent");
+        std::vector<unsigned> host(count);
+        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        for (size_t i = 0; i < count; i++)
+            transparent[i] = host[i] ? 0 : 1;
+    });
+}
+
+long sealhip_modulo_poly_coeffs_63(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k, uint32_t base,
+                                   uint64_t *result)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a);
+    REQUIRE_PTR(result);
+    return guarded([&] { poly_entry(ctx, PolyOp::Mod63, a, nullptr, 0, result, count, k, base); });
+}
+
+long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t *ct, size_t count, int32_t steps,
+                                     const uint32_t *galois_elts, const sealhip_kswitch_key *const *galois_keys,
+                                     uint32_t n_keys)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    if (n_keys)
+    {
+        REQUIRE_PTR(galois_elts);
+        REQUIRE_PTR(galois_keys);
+    }
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        // rotate_internal (evaluator.cpp:1945-2000)
+        std::function<void(int)> rotate = [&](int st) {
+            if (st == 0)
+                return;
+            const std::uint32_t elt = host_galois_elt_from_step(e.n, st);
+            for (uint32_t i = 0; i < n_keys; i++)
+                if (galois_elts[i] == elt)
+                {
+                    if (!galois_keys[i])
+                        throw std::invalid_argument("Galois key not present");
+                    op_apply_galois(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), count, elt, galois_keys[i]->key);
+                    return;
+                }
+            // non-adjacent form, util/numth.h:22-42
+            std::vector<int> naf;
+            {
+                const bool sign = st < 0;
+                int value = std::abs(st);
+                for (int i = 0; value; i++)
+                {
+                    const int zi = (value % 2) ? 2 - (value % 4) : 0;
+                    value = (value - zi) / 2;
+                    if (zi)
+                        naf.push_back((sign ? -zi : zi) * (1 << i));
+                }
+            }
+            if (naf.size() == 1)
+                throw std::invalid_argument("Galois key not present");
+            for (int s : naf)
+                if (static_cast<std::size_t>(std::abs(s)) != (e.n >> 1))
+                    rotate(s);
+        };
+        rotate(steps);
+    });
 }
 
 } // extern "C"

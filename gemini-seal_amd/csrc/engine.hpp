@@ -237,7 +237,8 @@ namespace sealhip
         Add,
         Sub,
         Negate,
-        Scalar
+        Scalar,
+        Mod63 // modulo_poly_coeffs_63, polyarithsmallmod.h:98-120
     };
     hipError_t launch_poly_op(const Engine &e, PolyOp op, const u64 *a, const u64 *b, u64 scalar, u64 *r,
                               std::size_t nrows, const RowMap &map);
@@ -279,6 +280,20 @@ namespace sealhip
                                    std::size_t out_stride, std::size_t count);
 
     // Galois
+    enum class CtLinearOp
+    {
+        Add,
+        Sub,
+        Negate,
+        MulPlain
+    };
+    // batches of ciphertexts [count][size][k][N]; b_item_stride only for MulPlain (0 = one plaintext for all)
+    hipError_t launch_ct_linear(const Engine &e, CtLinearOp op, const u64 *a, int sa, const u64 *b, int sb,
+                                std::size_t b_item_stride, u64 *out, std::size_t count, const RowMap &map);
+    hipError_t launch_nonzero_tail(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t skip_words,
+                                   std::size_t count, unsigned *flags);
+    hipError_t launch_plain_lift(const Engine &e, const u64 *plain, std::size_t plain_stride, u64 *out, std::size_t nplains,
+                                 const RowMap &map, u64 t);
     hipError_t launch_galois(const Engine &e, const u64 *in, u64 *out, std::size_t nrows, const RowMap &map,
                              std::uint32_t elt, const std::uint32_t *table /* null: coefficient form */);
 
@@ -307,6 +322,8 @@ namespace sealhip
     void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count);
     void op_rescale_special_inplace(Engine &e, int k, u64 *poly, std::size_t count);
     void op_apply_galois(Engine &e, int k, u64 *ct, std::size_t count, std::uint32_t elt, const KSwitchKey &key);
+    void op_multiply_plain(Engine &e, int k, u64 *ct, int size, std::size_t count, const u64 *plain,
+                           std::size_t plain_stride);
 
     std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
                                         bool strict, int device);

@@ -875,7 +875,15 @@ namespace sealhip
                                const NttSource &src)
         {
             constexpr int T = LOGN - 1;
-            const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
+            std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
+#ifdef SEALHIP_NTT_EXPERIMENT
+            if (const char *ex = std::getenv("SEALHIP_NTT_LDS_EXTRA")) // lower the occupancy on purpose
+            {
+                lds_bytes += std::strtoul(ex, nullptr, 0);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+            }
+#endif
             if (nrows % map.rows != 0)
                 return hipErrorInvalidValue;
             const std::size_t chunk = (nrows + 7) / 8; // rows per XCD

@@ -413,4 +413,31 @@ namespace sealhip
             op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
         }
     }
+    // multiply_plain_normal (evaluator.cpp:1475-1603) for parameters with fast plain lift (every q_i > t): lift the
+    // plaintext into the RNS base, canonical NTT, then per ciphertext polynomial lazy NTT -> dyadic product ->
+    // canonical inverse NTT, in place. The monomial shortcut (:1516-1553) computes the same negacyclic product
+    // exactly, so its canonical residues are identical to the generic path's; one path serves both.
+    void op_multiply_plain(Engine &e, int k, u64 *ct, int size, std::size_t count, const u64 *plain,
+                           std::size_t plain_stride)
+    {
+        if (e.scheme != 1)
+            throw std::logic_error("unsupported operation for scheme type");
+        const RowMap map_q = e.level_host(k).map_q;
+        for (int r = 0; r < k; r++)
+            if (e.key_moduli[r] <= e.t)
+                throw std::logic_error("multiply_plain: parameters without fast plain lift are not supported");
+        const std::size_t N = e.n;
+        const std::size_t nplains = plain_stride ? count : 1;
+        const std::size_t bytes = nplains * k * N * sizeof(u64);
+        e.ws_reserve(e.ws_floor + bytes + 256);
+        e.ws_reset();
+        u64 *temp = e.ws_alloc(nplains * k * N);
+        check(launch_plain_lift(e, plain, plain_stride, temp, nplains, map_q, e.t), "plain_lift");
+        check(launch_ntt(e, temp, nplains * k, map_q, false, kNttCanonical), "ntt(plain)");
+        check(launch_ntt(e, ct, count * size * k, map_q, false, 0), "ntt(ct)");
+        check(launch_ct_linear(e, CtLinearOp::MulPlain, ct, size, temp, 0, plain_stride ? static_cast<std::size_t>(k) * N : 0,
+                               ct, count, map_q),
+              "dyadic(plain)");
+        check(launch_ntt(e, ct, count * size * k, map_q, true, kNttCanonical), "intt(ct)");
+    }
 } // namespace sealhip

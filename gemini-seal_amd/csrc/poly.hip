@@ -27,6 +27,8 @@ namespace sealhip
                 return sub_mod(a, b, P.p);
             if (OP == 3)
                 return neg_mod(a, P.p);
+            if (OP == 5)
+                return barrett_reduce_63(a, P.p, P.cr1); // modulo_poly_coeffs_63, polyarithsmallmod.h:98-120
             return mul_mod(a, scalar, P.p, P.cr0, P.cr1); // multiply_poly_scalar_coeffmod, :15-61
         }
 
@@ -162,6 +164,112 @@ namespace sealhip
                 }
             }
         }
+
+        // Evaluator-level linear operations on batches of ciphertexts whose sizes may differ
+        // (evaluator.cpp:65-232: negate_inplace, add_inplace, sub_inplace) and multiply_plain_ntt (:1605-1646).
+        // OP 0: a + b (missing polynomials of the shorter operand count as absent: the tail of the longer one is
+        // copied), OP 1: a - b (tail of b negated, :216-220), OP 2: -a, OP 3: a (.) plain, the plaintext rows
+        // broadcast over the polynomials of the ciphertext.
+        template <int OP>
+        __global__ __launch_bounds__(kThreads) void ct_linear_kernel(const u64 *__restrict__ a, int sa,
+                                                                     const u64 *__restrict__ b, int sb,
+                                                                     std::size_t b_item_stride, u64 *__restrict__ out,
+                                                                     const PrimeDev *__restrict__ primes, RowMap map,
+                                                                     int logn, std::size_t pairs_per_poly,
+                                                                     std::size_t count)
+        {
+            const int so = OP <= 1 ? (sa > sb ? sa : sb) : sa;
+            const std::size_t total = pairs_per_poly * so * count;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t poly_words = pairs_per_poly * 2;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t item = i / (pairs_per_poly * so);
+                const std::size_t rem = i - item * pairs_per_poly * so;
+                const int j = static_cast<int>(rem / pairs_per_poly);
+                const std::size_t off = 2 * (rem - j * pairs_per_poly);
+                const PrimeDev &P = primes[map.prime[off >> logn]];
+                ulonglong2 va, vb, r;
+                va.x = va.y = vb.x = vb.y = 0;
+                const bool has_a = j < sa;
+                if (has_a)
+                    va = *reinterpret_cast<const ulonglong2 *>(a + (item * sa + j) * poly_words + off);
+                if (OP <= 1)
+                {
+                    const bool has_b = j < sb;
+                    if (has_b)
+                        vb = *reinterpret_cast<const ulonglong2 *>(b + (item * sb + j) * poly_words + off);
+                    if (has_a && has_b)
+                    {
+                        r.x = OP == 0 ? add_mod(va.x, vb.x, P.p) : sub_mod(va.x, vb.x, P.p);
+                        r.y = OP == 0 ? add_mod(va.y, vb.y, P.p) : sub_mod(va.y, vb.y, P.p);
+                    }
+                    else if (has_a)
+                        r = va;
+                    else
+                    {
+                        r.x = OP == 0 ? vb.x : neg_mod(vb.x, P.p);
+                        r.y = OP == 0 ? vb.y : neg_mod(vb.y, P.p);
+                    }
+                }
+                else if (OP == 2)
+                {
+                    r.x = neg_mod(va.x, P.p);
+                    r.y = neg_mod(va.y, P.p);
+                }
+                else
+                {
+                    vb = *reinterpret_cast<const ulonglong2 *>(b + item * b_item_stride + off);
+                    r.x = mul_mod(va.x, vb.x, P.p, P.cr0, P.cr1);
+                    r.y = mul_mod(va.y, vb.y, P.p, P.cr0, P.cr1);
+                }
+                *reinterpret_cast<ulonglong2 *>(out + (item * so + j) * poly_words + off) = r;
+            }
+        }
+
+        // Ciphertext::is_transparent (ciphertext.h:471-476): flag[item] != 0 iff some word of polynomials 1.. is non-zero
+        __global__ __launch_bounds__(kThreads) void nonzero_tail_kernel(const u64 *__restrict__ ct,
+                                                                        std::size_t item_words,
+                                                                        std::size_t skip_words, std::size_t count,
+                                                                        unsigned *__restrict__ flag)
+        {
+            const std::size_t tail_pairs = (item_words - skip_words) / 2;
+            const std::size_t total = tail_pairs * count;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t item = i / tail_pairs;
+                const std::size_t off = 2 * (i - item * tail_pairs);
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(ct + item * item_words + skip_words + off);
+                if ((v.x | v.y) != 0 && flag[item] == 0)
+                    flag[item] = 1; // benign race: every writer stores the same value
+            }
+        }
+
+        // multiply_plain_normal's lift of a plaintext into the RNS base when every q_i > t (fast plain lift,
+        // evaluator.cpp:1583-1592): temp_r[i] = plain[i] + (plain[i] >= threshold ? q_r - t : 0)
+        __global__ __launch_bounds__(kThreads) void plain_lift_kernel(const u64 *__restrict__ plain,
+                                                                      std::size_t plain_stride, u64 *__restrict__ out,
+                                                                      const PrimeDev *__restrict__ primes, RowMap map,
+                                                                      int logn, u64 t, u64 threshold,
+                                                                      std::size_t nplains)
+        {
+            const std::size_t n = static_cast<std::size_t>(1) << logn;
+            const std::size_t total = nplains * map.rows * n;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t c = i & (n - 1);
+                const std::size_t row = i >> logn;
+                const std::size_t item = row / map.rows;
+                const u64 p = primes[map.prime[row % map.rows]].p;
+                const u64 v = plain[item * plain_stride + c];
+                out[i] = v + (v >= threshold ? p - t : 0);
+            }
+        }
     } // namespace
 
     hipError_t launch_poly_op(const Engine &e, PolyOp op, const u64 *a, const u64 *b, u64 scalar, u64 *r,
@@ -188,6 +296,9 @@ namespace sealhip
             break;
         case PolyOp::Scalar:
             poly_op_kernel<4><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            break;
+        case PolyOp::Mod63:
+            poly_op_kernel<5><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         }
         return hipGetLastError();
@@ -226,6 +337,59 @@ namespace sealhip
             return hipSuccess;
         ProfScope prof(e, "galois", 0);
         galois_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(in, out, e.d_primes, map, e.logn, total, elt, table);
+        return hipGetLastError();
+    }
+    hipError_t launch_ct_linear(const Engine &e, CtLinearOp op, const u64 *a, int sa, const u64 *b, int sb,
+                                std::size_t b_item_stride, u64 *out, std::size_t count, const RowMap &map)
+    {
+        const std::size_t pairs = (static_cast<std::size_t>(map.rows) << e.logn) / 2;
+        const int so = (op == CtLinearOp::Add || op == CtLinearOp::Sub) ? (sa > sb ? sa : sb) : sa;
+        if (pairs * so * count == 0)
+            return hipSuccess;
+        ProfScope prof(e, "ct_linear", 0);
+        const unsigned grid = grid_for(pairs * so * count);
+        switch (op)
+        {
+        case CtLinearOp::Add:
+            ct_linear_kernel<0><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+                                                                pairs, count);
+            break;
+        case CtLinearOp::Sub:
+            ct_linear_kernel<1><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+                                                                pairs, count);
+            break;
+        case CtLinearOp::Negate:
+            ct_linear_kernel<2><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+                                                                pairs, count);
+            break;
+        case CtLinearOp::MulPlain:
+            ct_linear_kernel<3><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+                                                                pairs, count);
+            break;
+        }
+        return hipGetLastError();
+    }
+
+    hipError_t launch_nonzero_tail(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t skip_words,
+                                   std::size_t count, unsigned *flags)
+    {
+        if (item_words <= skip_words || count == 0)
+            return hipSuccess;
+        ProfScope prof(e, "nonzero_tail", 0);
+        nonzero_tail_kernel<<<grid_for((item_words - skip_words) / 2 * count), kThreads, 0, e.stream>>>(
+            ct, item_words, skip_words, count, flags);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_plain_lift(const Engine &e, const u64 *plain, std::size_t plain_stride, u64 *out, std::size_t nplains,
+                                 const RowMap &map, u64 t)
+    {
+        const std::size_t total = (nplains * map.rows) << e.logn;
+        if (total == 0)
+            return hipSuccess;
+        ProfScope prof(e, "plain_lift", 0);
+        plain_lift_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(plain, plain_stride, out, e.d_primes, map, e.logn, t,
+                                                                    (t + 1) >> 1, nplains);
         return hipGetLastError();
     }
 } // namespace sealhip

@@ -250,7 +250,65 @@ namespace sealhip_host
                     rotate_vector_inplace(encrypted, s, galois_keys);
         }
 
+        // ---- the rest of the Evaluator surface
+        // Evaluator::negate_inplace (evaluator.cpp:65-88)
+        void negate_inplace(CT &encrypted)
+        {
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n(), size = encrypted.size();
+            Staged c(ctx_, size * k * n);
+            c.up(encrypted.data(), size * k * n);
+            throw_on(sealhip_evaluator_negate(ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, c.ptr()));
+            c.down(encrypted.data(), size * k * n);
+        }
+        // Evaluator::add_inplace (evaluator.cpp:90-151) / sub_inplace (:174-233)
+        void add_inplace(CT &encrypted1, const CT &encrypted2) { add_sub(encrypted1, encrypted2, false); }
+        void sub_inplace(CT &encrypted1, const CT &encrypted2) { add_sub(encrypted1, encrypted2, true); }
+        // Evaluator::multiply_plain_inplace (evaluator.cpp:1438-1473). plain: NTT form -> k*N words (multiply_plain_ntt,
+        // :1605-1646), coefficient form -> N coefficients below t (multiply_plain_normal, :1475-1603).
+        void multiply_plain_inplace(CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form)
+        {
+            if (encrypted.is_ntt_form() != plain_is_ntt_form)
+                throw std::invalid_argument("NTT form mismatch"); // :1449-1452
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n(), size = encrypted.size();
+            const std::size_t pw = plain_is_ntt_form ? k * n : n;
+            Staged c(ctx_, size * k * n), p(ctx_, pw);
+            c.up(encrypted.data(), size * k * n);
+            p.up(plain, pw);
+            throw_on((plain_is_ntt_form ? sealhip_evaluator_multiply_plain_ntt : sealhip_evaluator_multiply_plain)(
+                ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, p.ptr(), 0));
+            c.down(encrypted.data(), size * k * n);
+        }
+        // Ciphertext::is_transparent (ciphertext.h:471-476) evaluated on the device copy
+        bool is_transparent(const CT &encrypted)
+        {
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n(), size = encrypted.size();
+            Staged c(ctx_, size * k * n);
+            c.up(encrypted.data(), size * k * n);
+            std::uint8_t flag = 0;
+            throw_on(sealhip_is_transparent(ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, &flag));
+            return flag != 0;
+        }
+
     private:
+        void add_sub(CT &a, const CT &b, bool sub)
+        {
+            if (a.poly_modulus_degree() != ctx_.n() || b.poly_modulus_degree() != ctx_.n() || a.size() < 1 || b.size() < 1)
+                throw std::invalid_argument("encrypted1 is not valid for encryption parameters"); // :93-100
+            if (a.coeff_modulus_size() != b.coeff_modulus_size())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch"); // :101-104
+            if (a.is_ntt_form() != b.is_ntt_form())
+                throw std::invalid_argument("NTT form mismatch"); // :105-108
+            const std::size_t k = a.coeff_modulus_size(), n = ctx_.n(), sa = a.size(), sb = b.size();
+            const std::size_t so = sa > sb ? sa : sb;
+            Staged x(ctx_, sa * k * n), y(ctx_, sb * k * n), o(ctx_, so * k * n);
+            x.up(a.data(), sa * k * n);
+            y.up(b.data(), sb * k * n);
+            throw_on((sub ? sealhip_evaluator_sub : sealhip_evaluator_add)(ctx_.get(), std::uint32_t(k), x.ptr(),
+                                                                           std::uint32_t(sa), y.ptr(), std::uint32_t(sb), 1,
+                                                                           o.ptr()));
+            a.resize_raw(so, k); // :131-132
+            o.down(a.data(), so * k * n);
+        }
         void check_pair(const CT &a, const CT &b) const
         {
             if (a.poly_modulus_degree() != ctx_.n() || b.poly_modulus_degree() != ctx_.n() || a.size() < 2 || b.size() < 2)

@@ -100,6 +100,14 @@ SYMBOLS = {
     "sealhip_evaluator_apply_galois": [_vp, _u32, _vp, _sz, _u32, _vp],
     "sealhip_evaluator_transform_to_ntt": [_vp, _u32, _vp, _u32, _sz],
     "sealhip_evaluator_transform_from_ntt": [_vp, _u32, _vp, _u32, _sz],
+    "sealhip_evaluator_negate": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_add": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_sub": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_multiply_plain_ntt": [_vp, _u32, _vp, _u32, _sz, _vp, _sz],
+    "sealhip_evaluator_multiply_plain": [_vp, _u32, _vp, _u32, _sz, _vp, _sz],
+    "sealhip_is_transparent": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_modulo_poly_coeffs_63": [_vp, _vp, _sz, _u32, _u32, _vp],
+    "sealhip_evaluator_rotate_vector": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
 }
 
 
@@ -306,6 +314,15 @@ class Context:
     def sub_poly_coeffmod(self, a, b, count, k, result, base=BASE_Q):
         _check(lib().sealhip_sub_poly_coeffmod(self.handle, _ptr(a), _ptr(b), count, k, base, _ptr(result)))
 
+    def modulo_poly_coeffs_63(self, a, count, k, result, base=BASE_Q):
+        _check(lib().sealhip_modulo_poly_coeffs_63(self.handle, _ptr(a), count, k, base, _ptr(result)))
+
+    def is_transparent(self, ct, size, k, count):
+        """Ciphertext::is_transparent (ciphertext.h:471-476) for each ciphertext of the batch -> numpy bool array"""
+        flags = np.zeros(count, dtype=np.uint8)
+        _check(lib().sealhip_is_transparent(self.handle, k, _ptr(ct), size, count, flags.ctypes.data))
+        return flags.astype(bool)
+
     def negate_poly_coeffmod(self, a, count, k, result, base=BASE_Q):
         _check(lib().sealhip_negate_poly_coeffmod(self.handle, _ptr(a), count, k, base, _ptr(result)))
 
@@ -398,6 +415,39 @@ class Evaluator:
                 self.rotate_vector_inplace(ct, k, count, s, galois_keys)
 
     rotate_rows_inplace = rotate_vector_inplace
+
+    def rotate_vector_native(self, ct, k, count, steps, galois_keys):
+        """The same rotate_internal logic behind the C ABI (sealhip_evaluator_rotate_vector)."""
+        elts = list(galois_keys.keys())
+        ea = (_u32 * max(1, len(elts)))(*elts)
+        ka = (_vp * max(1, len(elts)))(*[galois_keys[g].handle for g in elts])
+        _check(lib().sealhip_evaluator_rotate_vector(self.ctx.handle, k, _ptr(ct), count, steps, ea, ka, len(elts)))
+
+    # ---- SURVEY 8(f1): the rest of the Evaluator surface on device-resident batches
+    def negate(self, ct, size, k, count, out):
+        """Evaluator::negate (evaluator.cpp:65-88)"""
+        _check(lib().sealhip_evaluator_negate(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
+
+    def add(self, a, size_a, b, size_b, k, count, out):
+        """Evaluator::add (evaluator.cpp:90-151)"""
+        _check(lib().sealhip_evaluator_add(self.ctx.handle, k, _ptr(a), size_a, _ptr(b), size_b, count, _ptr(out)))
+
+    def sub(self, a, size_a, b, size_b, k, count, out):
+        """Evaluator::sub (evaluator.cpp:174-233)"""
+        _check(lib().sealhip_evaluator_sub(self.ctx.handle, k, _ptr(a), size_a, _ptr(b), size_b, count, _ptr(out)))
+
+    def multiply_plain_inplace(self, ct, size, k, count, plain, plain_stride=0, ntt_form=None):
+        """Evaluator::multiply_plain_inplace (evaluator.cpp:1438-1473): NTT form -> multiply_plain_ntt (plain = k x N in
+        NTT form), coefficient form (BFV) -> multiply_plain_normal (plain = N coefficients < t)."""
+        if ntt_form is None:
+            ntt_form = self.ctx.scheme == SCHEME_CKKS
+        fn = lib().sealhip_evaluator_multiply_plain_ntt if ntt_form else lib().sealhip_evaluator_multiply_plain
+        _check(fn(self.ctx.handle, k, _ptr(ct), size, count, _ptr(plain), plain_stride))
+
+    def check_not_transparent(self, ct, size, k, count):
+        """evaluator.cpp:265-271 (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT)"""
+        if self.ctx.is_transparent(ct, size, k, count).any():
+            raise LogicError("result ciphertext is transparent")
 
     def transform_to_ntt_inplace(self, ct, size, k, count):
         _check(lib().sealhip_evaluator_transform_to_ntt(self.ctx.handle, k, _ptr(ct), size, count))

@@ -192,6 +192,43 @@ long sealhip_evaluator_transform_to_ntt(sealhip_context *ctx, uint32_t k, uint64
 long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size,
                                           size_t count);
 
+/* ---------------------------------------------------------------- Evaluator surface beyond the hot path */
+/* Ciphertext batches [count][size][k][N]. Evaluator::negate_inplace (evaluator.cpp:65-88); out may alias ct. */
+long sealhip_evaluator_negate(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                              uint64_t *out);
+/* Evaluator::add_inplace (evaluator.cpp:90-151) / sub_inplace (:174-233): out has max(size_a, size_b) polynomials per
+   ciphertext; the tail of the longer operand is copied (add) or, when it is b's, negated (sub, :216-220).
+   out may alias a when size_a >= size_b. */
+long sealhip_evaluator_add(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                           uint32_t size_b, size_t count, uint64_t *out);
+long sealhip_evaluator_sub(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, const uint64_t *b,
+                           uint32_t size_b, size_t count, uint64_t *out);
+/* Evaluator::multiply_plain_ntt (evaluator.cpp:1605-1646): every polynomial of every ciphertext times a plaintext in
+   NTT form (k x N), in place. plain_stride = words between the plaintexts of consecutive ciphertexts, 0 = one
+   plaintext for the whole batch. */
+long sealhip_evaluator_multiply_plain_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                          const uint64_t *plain_ntt, size_t plain_stride);
+/* Evaluator::multiply_plain_normal (evaluator.cpp:1475-1603), BFV, coefficient form, in place. plain = N coefficients
+   in [0, t) per plaintext (plain_stride as above). Requires every q_i > t ("fast plain lift", context.cpp:297-301);
+   otherwise COR_E_INVALIDOPERATION. */
+long sealhip_evaluator_multiply_plain(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                      const uint64_t *plain, size_t plain_stride);
+/* Ciphertext::is_transparent (ciphertext.h:471-476) per ciphertext of the batch: transparent[i] = 1 when polynomials
+   1.. are identically zero (or size < 2). `transparent` is HOST memory (count bytes); the call synchronises.
+   The reference throws logic_error("result ciphertext is transparent") after every operation when built with
+   SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:265-271); the adapter does the same with this flag. */
+long sealhip_is_transparent(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                            uint8_t *transparent);
+/* modulo_poly_coeffs_63 (polyarithsmallmod.h:98-120): Barrett-63 reduction of rows with values < 2^63 */
+long sealhip_modulo_poly_coeffs_63(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k, uint32_t base,
+                                   uint64_t *result);
+/* Evaluator::rotate_vector_inplace / rotate_rows_inplace -> rotate_internal (evaluator.cpp:1945-2000): the key for
+   the step's Galois element if the caller holds it, else the non-adjacent-form decomposition (util/numth.h:22-42).
+   galois_elts[i] is the Galois element of galois_keys[i]. */
+long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t *ct, size_t count, int32_t steps,
+                                     const uint32_t *galois_elts, const sealhip_kswitch_key *const *galois_keys,
+                                     uint32_t n_keys);
+
 #ifdef __cplusplus
 }
 #endif

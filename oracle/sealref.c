@@ -1463,6 +1463,100 @@ int ref_apply_galois_inplace(ref_context *c, size_t k, uint64_t *ct, uint32_t ga
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluator negate / add / sub / multiply_plain, is_transparent
+ * ---------------------------------------------------------------------------------------- */
+void ref_evaluator_negate(const ref_context *c, size_t k, const uint64_t *ct, size_t size, uint64_t *out)
+{
+    const size_t n = c->n;
+    for (size_t j = 0; j < size; j++)
+        for (size_t r = 0; r < k; r++) /* evaluator.cpp:80 */
+            ref_negate_poly_coeffmod(ct + (j * k + r) * n, n, &c->key_mod[r], out + (j * k + r) * n);
+}
+
+static void add_sub(const ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                    uint64_t *out, int sub)
+{
+    const size_t n = c->n, pw = k * n;
+    const size_t mn = sa < sb ? sa : sb, mx = sa < sb ? sb : sa;
+    for (size_t j = 0; j < mn; j++)
+        for (size_t r = 0; r < k; r++) /* evaluator.cpp:135 / :213 */
+        {
+            if (sub)
+                ref_sub_poly_coeffmod(a + j * pw + r * n, b + j * pw + r * n, n, &c->key_mod[r], out + j * pw + r * n);
+            else
+                ref_add_poly_coeffmod(a + j * pw + r * n, b + j * pw + r * n, n, &c->key_mod[r], out + j * pw + r * n);
+        }
+    for (size_t j = mn; j < mx; j++)
+    {
+        if (sa > sb) /* encrypted1 keeps its own tail */
+            memmove(out + j * pw, a + j * pw, sizeof(uint64_t) * pw);
+        else if (!sub) /* :138-143 */
+            memmove(out + j * pw, b + j * pw, sizeof(uint64_t) * pw);
+        else /* :216-220 */
+            for (size_t r = 0; r < k; r++)
+                ref_negate_poly_coeffmod(b + j * pw + r * n, n, &c->key_mod[r], out + j * pw + r * n);
+    }
+}
+
+void ref_evaluator_add(const ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                       uint64_t *out)
+{
+    add_sub(c, k, a, sa, b, sb, out, 0);
+}
+
+void ref_evaluator_sub(const ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                       uint64_t *out)
+{
+    add_sub(c, k, a, sa, b, sb, out, 1);
+}
+
+void ref_multiply_plain_ntt(const ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *plain_ntt)
+{
+    const size_t n = c->n;
+    for (size_t j = 0; j < size; j++) /* evaluator.cpp:1638-1641 */
+        for (size_t r = 0; r < k; r++)
+            ref_dyadic_product_coeffmod(ct + (j * k + r) * n, plain_ntt + r * n, n, &c->key_mod[r], ct + (j * k + r) * n);
+}
+
+int ref_multiply_plain(const ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *plain)
+{
+    const size_t n = c->n;
+    for (size_t r = 0; r < k; r++)
+        if (c->key_mod[r].value <= c->t) /* context.cpp:297-301: using_fast_plain_lift */
+            return -1;
+    const uint64_t threshold = (c->t + 1) >> 1; /* context.cpp:322 */
+    uint64_t *temp = (uint64_t *)malloc(sizeof(uint64_t) * n * k);
+    for (size_t r = 0; r < k; r++)
+    {
+        const uint64_t inc = c->key_mod[r].value - c->t; /* context.cpp:331 */
+        for (size_t i = 0; i < n; i++) /* evaluator.cpp:1583-1592 */
+            temp[r * n + i] = plain[i] + (inc & (uint64_t)(-(int64_t)(plain[i] >= threshold)));
+        ref_ntt_forward(temp + r * n, &c->key_tables[r], 0); /* :1596-1597 */
+    }
+    for (size_t j = 0; j < size; j++) /* :1599-1606 */
+        for (size_t r = 0; r < k; r++)
+        {
+            uint64_t *row = ct + (j * k + r) * n;
+            ref_ntt_forward_lazy(row, &c->key_tables[r], c->mode == REF_MODE_STRICT);
+            ref_dyadic_product_coeffmod(row, temp + r * n, n, &c->key_mod[r], row);
+            ref_ntt_inverse(row, &c->key_tables[r]);
+        }
+    free(temp);
+    return 0;
+}
+
+int ref_is_transparent(const ref_context *c, size_t k, const uint64_t *ct, size_t size)
+{
+    if (size < 2)
+        return 1;
+    const size_t pw = k * c->n;
+    for (size_t i = pw; i < size * pw; i++)
+        if (ct[i])
+            return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic data helpers
  * ---------------------------------------------------------------------------------------- */
 uint64_t ref_splitmix64(uint64_t *state)

@@ -180,6 +180,25 @@ int ref_mod_switch_drop_to_next(ref_context *c, size_t k, const uint64_t *ct, si
 /* evaluator.cpp:1841-1943; ct = 2 polys in place */
 int ref_apply_galois_inplace(ref_context *c, size_t k, uint64_t *ct, uint32_t galois_elt, const uint64_t *key);
 
+/* ---- compositions of the primitives above. The reference holds no fixture for these at
+   Evaluator level that can be restated without an Encryptor (its tests encrypt first), so they are pinned only
+   through their primitives (add/sub/negate/dyadic KATs, NTT KATs) and, for multiply_plain, by an independent
+   schoolbook negacyclic product in tests/test_oracle.py. ---- */
+/* evaluator.cpp:65-88 */
+void ref_evaluator_negate(const ref_context *c, size_t k, const uint64_t *ct, size_t size, uint64_t *out);
+/* evaluator.cpp:90-151 / :174-233; out has max(sa, sb) polys */
+void ref_evaluator_add(const ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                       uint64_t *out);
+void ref_evaluator_sub(const ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
+                       uint64_t *out);
+/* evaluator.cpp:1605-1646; plain_ntt = k x N, in place */
+void ref_multiply_plain_ntt(const ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *plain_ntt);
+/* evaluator.cpp:1475-1603, generic path with fast plain lift; plain = N coefficients < t; returns -1 when some
+   q_i <= t (the multi-precision lift is not restated) */
+int ref_multiply_plain(const ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *plain);
+/* ciphertext.h:471-476 */
+int ref_is_transparent(const ref_context *c, size_t k, const uint64_t *ct, size_t size);
+
 /* ---- synthetic data helpers shared by tests ---- */
 uint64_t ref_splitmix64(uint64_t *state);
 uint64_t ref_fnv1a64(const uint64_t *words, size_t count);

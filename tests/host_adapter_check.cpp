@@ -60,6 +60,20 @@ int main(int argc, char **argv)
                 h *= 0x100000001b3ULL;
             }
         std::printf("modswitch digest %016llx\n", (unsigned long long)h);
+        // SURVEY 8(f1) methods: algebraic identities through the adapter
+        HostCiphertext c = b, d = b;
+        ev.add_inplace(c, b);
+        ev.sub_inplace(c, b); // (b + b) - b == b
+        ev.negate_inplace(d);
+        ev.negate_inplace(d); // -(-b) == b
+        std::vector<std::uint64_t> one(n, 0);
+        one[0] = 1;
+        HostCiphertext m = b;
+        ev.multiply_plain_inplace(m, one.data(), false); // b * 1 == b
+        const bool ok = c.words == b.words && d.words == b.words && m.words == b.words && !ev.is_transparent(b);
+        std::printf("f1 identities %s\n", ok ? "ok" : "FAILED");
+        if (!ok)
+            return 1;
     }
     catch (const std::exception &e)
     {

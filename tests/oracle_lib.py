@@ -171,6 +171,15 @@ def lib():
     L.ref_mod_switch_scale_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_mod_switch_drop_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_apply_galois_inplace.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ref_evaluator_negate.restype = None
+    L.ref_evaluator_negate.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
+    for fn in (L.ref_evaluator_add, L.ref_evaluator_sub):
+        fn.restype = None
+        fn.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_multiply_plain_ntt.restype = None
+    L.ref_multiply_plain_ntt.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_multiply_plain.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
+    L.ref_is_transparent.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]

@@ -547,6 +547,7 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     want = [r for r in DIG["end_to_end"] if r["cfg"] == 1][0]["digests"]["modswitch"]
     assert "modswitch digest " + want in out.stdout, out.stdout
+    assert "f1 identities ok" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("logn", [14, 15, 16])
@@ -643,3 +644,120 @@ def test_small_vectors_full_words(sealhip):
         g = ctx.upload(c2)
         ev.rotate_vector_inplace(g, k, 1, 3, {ch["galois_elt_step3"]: key})
         assert g.download((2, k, n)).tolist() == ch["apply_galois"]
+
+
+# ---------------------------------------------------------------- the rest of the Evaluator surface
+def _rand_ct(rng, mods, size, n, count):
+    return np.stack([rng.integers(0, p, size=(count, size, n), dtype=np.uint64) for p in mods], axis=2).copy()
+
+
+@pytest.mark.parametrize("logn,sa,sb", [(5, 2, 2), (12, 3, 2), (12, 2, 3), (15, 2, 2)])
+def test_f1_add_sub_negate(sealhip, logn, sa, sb):
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, [40, 40, 41])
+    k, count = 2, 3
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    rng = np.random.default_rng(logn * 10 + sa)
+    a, b = _rand_ct(rng, kmods[:k], sa, n, count), _rand_ct(rng, kmods[:k], sb, n, count)
+    so = max(sa, sb)
+    da, db, do = ctx.upload(a), ctx.upload(b), ctx.alloc(count * so * k * n)
+    for name, gfn, rfn in (("add", ev.add, L.ref_evaluator_add), ("sub", ev.sub, L.ref_evaluator_sub)):
+        gfn(da, sa, db, sb, k, count, do)
+        got = do.download((count, so, k, n))
+        exp = np.zeros_like(got)
+        for i in range(count):
+            rfn(C.byref(ref.c), k, O.ptr(a[i]), sa, O.ptr(b[i]), sb, O.ptr(exp[i]))
+        assert np.array_equal(got, exp), name
+    ev.negate(da, sa, k, count, da)  # in place
+    exp = np.zeros_like(a)
+    for i in range(count):
+        L.ref_evaluator_negate(C.byref(ref.c), k, O.ptr(a[i]), sa, O.ptr(exp[i]))
+    assert np.array_equal(da.download(a.shape), exp)
+    if sa >= sb:  # in place on the first operand, as Evaluator::add_inplace
+        da.upload(a)
+        ev.add(da, sa, db, sb, k, count, da)
+        exp = np.zeros_like(a)
+        for i in range(count):
+            L.ref_evaluator_add(C.byref(ref.c), k, O.ptr(a[i]), sa, O.ptr(b[i]), sb, O.ptr(exp[i]))
+        assert np.array_equal(da.download(a.shape), exp)
+    else:
+        with pytest.raises(ValueError):
+            ev.add(da, sa, db, sb, k, count, da)
+
+
+@pytest.mark.parametrize("logn", [5, 12, 15])
+def test_f1_multiply_plain(sealhip, logn):
+    n, t = 1 << logn, 786433 if logn > 10 else 257
+    kmods = O.coeff_modulus_create(n, [40, 40, 41])
+    k, count, size = 2, 3, 2
+    rng = np.random.default_rng(logn)
+    # BFV, coefficient form: multiply_plain_normal (one plaintext per ciphertext, then one for all)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    ct = _rand_ct(rng, kmods[:k], size, n, count)
+    plains = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    plains[1] = 0
+    plains[1, 5] = t - 3  # a monomial in the upper half: the reference takes its shortcut here (evaluator.cpp:1516-1553)
+    for stride, pl in ((n, plains), (0, plains[:1])):
+        d = ctx.upload(ct)
+        ev.multiply_plain_inplace(d, size, k, count, ctx.upload(pl), stride, ntt_form=False)
+        exp = ct.copy()
+        for i in range(count):
+            assert L.ref_multiply_plain(C.byref(ref.c), k, O.ptr(exp[i]), size, O.ptr(pl[i if stride else 0])) == 0
+        assert np.array_equal(d.download(ct.shape), exp), stride
+    # CKKS, NTT form: multiply_plain_ntt
+    c2 = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    e2 = sealhip.Evaluator(c2)
+    r2 = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    pn = np.stack([rng.integers(0, p, size=(count, n), dtype=np.uint64) for p in kmods[:k]], axis=1).copy()
+    for stride, pl in ((k * n, pn), (0, pn[:1])):
+        d = c2.upload(ct)
+        e2.multiply_plain_inplace(d, size, k, count, c2.upload(pl), stride)
+        exp = ct.copy()
+        for i in range(count):
+            L.ref_multiply_plain_ntt(C.byref(r2.c), k, O.ptr(exp[i]), size, O.ptr(pl[i if stride else 0]))
+        assert np.array_equal(d.download(ct.shape), exp), stride
+    # unsupported: CKKS context for the coefficient-form product, and a plain modulus above a prime
+    with pytest.raises(sealhip.LogicError):
+        e2.multiply_plain_inplace(c2.upload(ct), size, k, count, c2.upload(plains), n, ntt_form=False)
+
+
+def test_f1_transparent_mod63_and_native_rotate(sealhip):
+    logn, n = 12, 4096
+    kmods = O.coeff_modulus_create(n, [40, 40, 40, 41])
+    k, count = 3, 4
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(77)
+    ct = _rand_ct(rng, kmods[:k], 2, n, count)
+    ct[1, 1:] = 0
+    ct[3, 1, 2, 4095] = 0
+    ct[2, 1] = 0
+    ct[2, 1, k - 1, n - 1] = 1  # a single non-zero word at the very end
+    d = ctx.upload(ct)
+    assert ctx.is_transparent(d, 2, k, count).tolist() == [False, True, False, False]
+    assert ctx.is_transparent(d, 1, k, 2 * count).all()  # size < 2
+    with pytest.raises(sealhip.LogicError):
+        ev.check_not_transparent(d, 2, k, count)
+    # modulo_poly_coeffs_63
+    x = rng.integers(0, 1 << 63, size=(5, k, n), dtype=np.uint64)
+    dx = ctx.upload(x)
+    ctx.modulo_poly_coeffs_63(dx, 5, k, dx)
+    assert np.array_equal(dx.download(x.shape), np.stack([x[:, r] % np.uint64(kmods[r]) for r in range(k)], axis=1))
+    # rotate_vector behind the C ABI == the host-side NAF walk (and the direct key when present)
+    krng = np.random.default_rng(3)
+    keys = {}
+    for step in (1, 2, 4, 8, -1, -4):
+        elt = ctx.galois_elt_from_step(step)
+        keys[elt] = sealhip.KSwitchKeys(ctx, np.stack([_rand_ct(krng, kmods, 2, n, 1)[0] for _ in range(k)]))
+    src = _rand_ct(rng, kmods[:k], 2, n, count)
+    for steps in (1, 3, 7, -3, 0):
+        a, b = ctx.upload(src), ctx.upload(src)
+        ev.rotate_vector_inplace(a, k, count, steps, keys)
+        ev.rotate_vector_native(b, k, count, steps, keys)
+        assert np.array_equal(a.download(src.shape), b.download(src.shape)), steps
+    with pytest.raises(ValueError):
+        ev.rotate_vector_native(ctx.upload(src), k, count, 16, keys)  # power of two without a key

@@ -346,3 +346,64 @@ def test_small_vectors_regression():
     before = open(path).read()
     subprocess.check_call([sys.executable, os.path.join(HERE, "golden", "make_small_vectors.py")], stdout=subprocess.DEVNULL)
     assert open(path).read() == before
+
+
+# ---------------------------------------------------------------- SURVEY 8(f1) rows (compositions; see oracle/sealref.h)
+def _negacyclic_schoolbook(a, b, p):
+    """independent O(N^2) product in Z_p[x]/(x^N+1) with Python integers"""
+    n = len(a)
+    out = [0] * n
+    for i in range(n):
+        ai = int(a[i])
+        if not ai:
+            continue
+        for j in range(n):
+            v = ai * int(b[j])
+            if i + j < n:
+                out[i + j] += v
+            else:
+                out[i + j - n] -= v
+    return [v % p for v in out]
+
+
+def test_f1_multiply_plain_against_schoolbook():
+    logn, n, t = 5, 32, 257
+    kmods = O.coeff_modulus_create(n, [30, 30, 31])
+    k = 2
+    ctx = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    rng = np.random.default_rng(5)
+    ct = np.stack([rng.integers(0, p, size=(2, n), dtype=np.uint64) for p in kmods[:k]], axis=1).copy()
+    for plain in (rng.integers(0, t, size=n, dtype=np.uint64), np.eye(1, n, 7, dtype=np.uint64)[0] * np.uint64(200)):
+        work = ct.copy()
+        assert L.ref_multiply_plain(C.byref(ctx.c), k, O.ptr(work), 2, O.ptr(plain)) == 0
+        for r, p in enumerate(kmods[:k]):
+            lifted = [int(v) + (p - t if int(v) >= (t + 1) // 2 else 0) for v in plain]
+            for j in range(2):
+                assert work[j, r].tolist() == _negacyclic_schoolbook(ct[j, r], lifted, p)
+
+
+def test_f1_add_sub_negate_sizes_and_transparent():
+    logn, n = 4, 16
+    kmods = O.coeff_modulus_create(n, [30, 30, 31])
+    k = 2
+    ctx = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    rng = np.random.default_rng(6)
+    mk = lambda size: np.stack([rng.integers(0, p, size=(size, n), dtype=np.uint64) for p in kmods[:k]], axis=1).copy()
+    a3, b2 = mk(3), mk(2)
+    mods = np.array(kmods[:k], dtype=object)[None, :, None]
+    out = np.zeros((3, k, n), dtype=np.uint64)
+    L.ref_evaluator_add(C.byref(ctx.c), k, O.ptr(a3), 3, O.ptr(b2), 2, O.ptr(out))
+    exp = a3.astype(object)
+    exp[:2] = (a3[:2].astype(object) + b2.astype(object)) % mods
+    assert (out.astype(object) == exp).all()
+    L.ref_evaluator_sub(C.byref(ctx.c), k, O.ptr(b2), 2, O.ptr(a3), 3, O.ptr(out))
+    exp = (-a3.astype(object)) % mods
+    exp[:2] = (b2.astype(object) - a3[:2].astype(object)) % mods
+    assert (out.astype(object) == exp).all()
+    L.ref_evaluator_negate(C.byref(ctx.c), k, O.ptr(a3), 3, O.ptr(out))
+    assert (out.astype(object) == (-a3.astype(object)) % mods).all()
+    assert L.ref_is_transparent(C.byref(ctx.c), k, O.ptr(a3), 3) == 0
+    z = a3.copy()
+    z[1:] = 0
+    assert L.ref_is_transparent(C.byref(ctx.c), k, O.ptr(z), 3) == 1
+    assert L.ref_is_transparent(C.byref(ctx.c), k, O.ptr(z), 1) == 1

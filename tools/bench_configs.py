@@ -124,6 +124,31 @@ def main():
         dt = timed(step, 3)
         out.append({"config": "cfg5 BFV N=2^16 16 primes (k=15, |Bsk|=16, 15 digits): multiply+relinearize+mod_switch, batch 256",
                     "pipeline_per_s": B / dt})
+    if want("f1"):
+        # SURVEY 8(f1) rows at cfg3 size: streaming kernels, priced against the HBM roofline with their algorithmic bytes
+        logn, n = 15, 1 << 15
+        pr = bench.CFG3_PRIMES
+        ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 1024, 7
+        x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
+        o = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
+        rows = B * 2 * k
+        dt_add = timed(lambda: ev.add(x, 2, y, 2, k, B, o), 10)
+        dt_neg = timed(lambda: ev.negate(x, 2, k, B, o), 10)
+        pn = mk(ctx, (k, n), pr[:k], dev)
+        dt_mpn = timed(lambda: ev.multiply_plain_inplace(o, 2, k, B, pn, 0, ntt_form=True), 10)
+        plain = torch.randint(0, 786433, (n,), dtype=torch.int64, device=dev)
+        dt_mp = timed(lambda: ev.multiply_plain_inplace(o, 2, k, B, plain, 0, ntt_form=False), 5)
+        dt_tr = timed(lambda: ctx.is_transparent(o, 2, k, B), 10)
+        out.append({"config": "f1 rows at cfg3 size (BFV N=2^15, k=7), batch 1024 size-2 ciphertexts",
+                    "add_ct_per_s": B / dt_add, "add_hbm_roofline_frac": rows * 24 * n / dt_add / 8e12,
+                    "negate_ct_per_s": B / dt_neg, "negate_hbm_roofline_frac": rows * 16 * n / dt_neg / 8e12,
+                    "multiply_plain_ntt_ct_per_s": B / dt_mpn, "multiply_plain_ntt_hbm_roofline_frac": rows * 16 * n / dt_mpn / 8e12,
+                    "multiply_plain_ct_per_s": B / dt_mp,
+                    "multiply_plain_ntt_equiv_frac": rows * 2 * 16 * n / dt_mp / 8e12,
+                    "is_transparent_ct_per_s": B / dt_tr, "is_transparent_hbm_roofline_frac": (rows // 2) * 8 * n / dt_tr / 8e12})
     if want("pcie"):
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES

@@ -240,6 +240,14 @@ int main()
         double m1 = time_ms([&] { k_butterfly_lane<1><<<blocks, threads>>>(out, w, ws, p); });
         printf("per-lane twiddles, compiler   : %8.2f G butterflies/s (%.3f ms)\n", bf / m0 / 1e6, m0);
         printf("per-lane twiddles, hand mads  : %8.2f G butterflies/s (%.3f ms)\n", bf / m1 / 1e6, m1);
+        // occupancy sweep: one block of T threads per CU
+        for (int t = 256; t <= 1024; t *= 2)
+        {
+            double a0 = time_ms([&] { k_butterfly_lane<0><<<256, t>>>(out, w, ws, p); });
+            double a1 = time_ms([&] { k_butterfly_lane<1><<<256, t>>>(out, w, ws, p); });
+            printf("  %d wave(s)/SIMD: compiler %8.2f, hand %8.2f G butterflies/s\n", t / 256, 256.0 * t * ITERS / a0 / 1e6,
+                   256.0 * t * ITERS / a1 / 1e6);
+        }
     }
     printf("  -> N=2^15 row = 245760 butterflies: ALU bound %.2f M NTT/s = %.1f%% of the 15.26 M/s HBM roofline\n",
            bf / ms / 1e6 * 1e9 / 245760 / 1e6, bf / ms / 1e6 * 1e9 / 245760 / 15.26e6 * 100);
