@@ -679,7 +679,7 @@ namespace sealhip
                 u64 tt = u + v;
                 tt = tt >= two_p ? tt - two_p : tt; // BackwardLazy, ntt.cpp:265-272
                 x[s] = tt;
-                x[s | bit] = mulmod_lazy_np(u - v + two_p, Wv.x, Wv.y, neg_p);
+                x[s | bit] = mulmod_lazy_hs<UNIFORM>(u - v + two_p, Wv.x, Wv.y, neg_p);
             }
         }
 
@@ -726,7 +726,7 @@ namespace sealhip
                     u64 tt = u + v;
                     tt = tt >= two_p ? tt - two_p : tt;
                     x[s] = tt;
-                    x[s | bit] = mulmod_lazy_np(u - v + two_p, Wv.x, Wv.y, neg_p);
+                    x[s | bit] = mulmod_lazy_hs<false>(u - v + two_p, Wv.x, Wv.y, neg_p);
                 }
             }
         }

@@ -22,7 +22,10 @@ def short(name):
 
 def pmc(path):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(path)[0])):
+    files = glob.glob(path, recursive=True)
+    if not files:
+        raise SystemExit("no rocprofv3 csv under " + path)
+    for r in csv.DictReader(open(files[0])):
         s = short(r["Kernel_Name"])
         if s:
             agg[(s, int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(float(r["Counter_Value"]))
@@ -31,8 +34,8 @@ def pmc(path):
 
 def main(prof_dir, out_dir, rows_per_block_ntt=4 * 512):
     os.makedirs(out_dir, exist_ok=True)
-    fetch = pmc(os.path.join(prof_dir, "pmc_fetch/*/*_counter_collection.csv"))
-    write = pmc(os.path.join(prof_dir, "pmc_write/*/*_counter_collection.csv"))
+    fetch = pmc(os.path.join(prof_dir, "pmc_fetch/**/*_counter_collection.csv"))
+    write = pmc(os.path.join(prof_dir, "pmc_write/**/*_counter_collection.csv"))
     lines = ["| kernel | grid | launches | FETCH_SIZE KB (raw) | read bytes (x2, gfx950) | WRITE_SIZE KB | HBM bytes / launch |",
              "|---|---|---|---|---|---|---|"]
     traffic = {}
@@ -45,14 +48,16 @@ def main(prof_dir, out_dir, rows_per_block_ntt=4 * 512):
         if key[0].startswith("ntt_pass_kernel"):
             tag = "ntt_fwd_pass" if "<0>" in key[0] else "ntt_inv_pass"
             rows = key[1] / key[2] / 4  # N=2^15: 4 tiles per row
-            traffic.setdefault(tag, []).append(total / rows)
+            traffic.setdefault(tag, []).append((rows, total / rows))
         elif key[0].startswith("ntt_fwd_half_kernel") or key[0].startswith("ntt_inv_half_kernel"):
             tag = "ntt_fwd_half" if "fwd" in key[0] else "ntt_inv_half"
             rows = key[1] / key[2] / 2  # two workgroups per row (grid rounded up to 8-row groups)
-            traffic.setdefault(tag, []).append(total / rows)
-    out = {k: {"hbm_bytes_per_row_per_launch": sum(v) / len(v)} for k, v in traffic.items()}
+            traffic.setdefault(tag, []).append((rows, total / rows))
+    # launches that skip rows (key-switch mod-down: only the special-prime rows are transformed) would dilute the
+    # per-row figure: take it from the largest launch of each kernel, where every row is transformed
+    out = {k: {"hbm_bytes_per_row_per_launch": max(v)[1], "rows_in_that_launch": max(v)[0]} for k, v in traffic.items()}
     json.dump(out, open(os.path.join(os.path.dirname(out_dir.rstrip("/")), "traffic.json"), "w"), indent=1)
-    stats = glob.glob(os.path.join(prof_dir, "stats/*/*_kernel_stats.csv"))
+    stats = glob.glob(os.path.join(prof_dir, "stats/**/*_kernel_stats.csv"), recursive=True)
     with open(os.path.join(out_dir, "summary.md"), "w") as fo:
         fo.write("# rocprofv3 summary\n\n## PMC (separate passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE)\n\n")
         fo.write("\n".join(lines) + "\n\n")
