@@ -245,4 +245,91 @@ namespace sealhip
         xu = X;
         xy = (u << 1) + two_p - X;
     }
+    // IL forward lazy butterflies in lock step: the multiply chain of one butterfly is a string of dependent
+    // instructions (a wave issues a dependent VALU instruction only every ~9 cycles, an independent one every
+    // ~5.7: tools/ubench_latency.hip), and the compiler, which has no latency model for inline asm, emits each
+    // chain back to back. The volatile statements below keep program order, so consecutive instructions belong to
+    // different butterflies.
+    // `cy` is the (unused) carry-out pair of the chain this instruction belongs to. One pair per chain, passed in
+    // and out: were every instruction to get the same scratch pair, the compiler's inline-asm hazard handling
+    // (it assumes any two neighbouring asm statements that name a common register need a wait state) would put an
+    // s_nop between all of them.
+    template <bool SU>
+    __device__ __forceinline__ u64 mad64v(u32 a, u32 b, u64 c, u64 &cy)
+    {
+        u64 d;
+        if (SU)
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "+s"(cy) : "v"(a), "s"(b), "v"(c));
+        else
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "+s"(cy) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
+    template <bool SU>
+    __device__ __forceinline__ u64 mul64v(u32 a, u32 b, u64 &cy)
+    {
+        u64 d;
+        if (SU)
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "+s"(cy) : "v"(a), "s"(b));
+        else
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "+s"(cy) : "v"(a), "v"(b));
+        return d;
+    }
+    template <bool WU, int IL>
+    __device__ __forceinline__ void butterflies_fwd_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
+                                                       u64 neg_p, u64 two_p)
+    {
+        static_assert(IL >= 2, "the carry of step 3 is read in step 5: at least two other instructions in between");
+        const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
+        u64 A[IL], B[IL], E[IL], V[IL], q[IL], carry[IL];
+        u32 cb[IL];
+        u64 cy[IL] = {};
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 1: A = y1*s0 + hi32(y0*s0)
+            A[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]),
+                              static_cast<u64>(__umulhi(static_cast<u32>(y[j]), static_cast<u32>(ws[j]))), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 2: E = y0*w1
+            E[j] = mul64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j] >> 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 3: B = y0*s1 + A, carry kept in an SGPR pair
+        {
+            if (WU)
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4"
+                             : "=v"(B[j]), "=s"(carry[j])
+                             : "v"(static_cast<u32>(y[j])), "s"(static_cast<u32>(ws[j] >> 32)), "v"(A[j]));
+            else
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4"
+                             : "=v"(B[j]), "=s"(carry[j])
+                             : "v"(static_cast<u32>(y[j])), "v"(static_cast<u32>(ws[j] >> 32)), "v"(A[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 4: E += y1*w0
+            E[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 5: carry -> register (>= IL + 1 >= 3 instructions after its producer)
+            asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(cb[j]) : "s"(carry[j]));
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 6: V = u + y0*w0
+            V[j] = mad64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j]), u[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 7: q = y1*s1 + (B >> 32) + (carry << 32) = floor(y*ws / 2^64)
+            q[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j] >> 32),
+                              static_cast<u64>(static_cast<u32>(B[j] >> 32)) | (static_cast<u64>(cb[j]) << 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 8..10: + q*(2^64 - p)
+            E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mad64v<true>(static_cast<u32>(q[j]), n0, V[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j] >> 32), n0, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+        {
+            const u64 X = add_hi32(V[j], E[j]);
+            y[j] = (u[j] << 1) + two_p - X;
+            u[j] = X;
+        }
+    }
 } // namespace sealhip

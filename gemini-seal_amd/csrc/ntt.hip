@@ -340,6 +340,11 @@ namespace sealhip
         constexpr int kFwdGroupMask = SEALHIP_FWD_GROUP_MASK;
         // all butterflies of one layer (slot bit W) on the 32 registers; PARITY/STRICT as in ntt_pass_kernel.
         // UNIFORM: the twiddle index does not depend on the lane (round 1) -> scalar loads.
+#ifndef SEALHIP_NTT_IL
+#define SEALHIP_NTT_IL 4
+#endif
+        constexpr int kIL = SEALHIP_NTT_IL; // butterflies advanced in lock step (devmath.hpp: butterflies_fwd_hs)
+
         template <int T, int R, int W, bool STRICT, bool UNIFORM>
         __device__ __forceinline__ void h_layer(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
                                                 u64 two_p, u64 neg_p, u64 rdp)
@@ -348,22 +353,36 @@ namespace sealhip
             const int tb = (N + jb) >> (gb + 1);
             constexpr int bit = 1 << W;
 #pragma unroll
-            for (int s = 0; s < 32; s++)
+            for (int c = 0; c < 16; c += kIL)
             {
-                if (s & bit)
-                    continue;
-                u64x2 Wv;
-                if (UNIFORM)
-                    Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
-                else
-                    Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
-                if (STRICT)
-                    x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
-                else if (gb == 0)
-                    x[s] = barrett_lazy_hs(x[s], rdp, neg_p); // ForwardLazyLast, ntt.cpp:254-261
-                butterfly_fwd_hs<UNIFORM>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
-                if ((s & kFwdGroupMask) == kFwdGroupMask)
-                    __builtin_amdgcn_sched_barrier(kSchedLoadsOnly); // bound the number of butterflies in flight
+                u64 u[kIL], y[kIL], w[kIL], ws[kIL];
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    // the (c+j)-th slot with bit W clear
+                    const int s = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
+                    u64x2 Wv;
+                    if (UNIFORM)
+                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
+                    else
+                        Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
+                    w[j] = Wv.x;
+                    ws[j] = Wv.y;
+                    u[j] = x[s];
+                    y[j] = x[s | bit];
+                    if (STRICT)
+                        u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
+                    else if (gb == 0)
+                        u[j] = barrett_lazy_hs(u[j], rdp, neg_p); // ForwardLazyLast, ntt.cpp:254-261
+                }
+                butterflies_fwd_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    const int s = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
+                    x[s] = u[j];
+                    x[s | bit] = y[j];
+                }
             }
         }
 
@@ -441,6 +460,191 @@ namespace sealhip
         {
             __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
             {}
+        };
+
+        // ---- pipelined final round. A stage = SG groups; the twiddles of stage k+1 are requested before stage k is
+        // computed and stored, so their L2 latency is covered by a stage of arithmetic instead of being exposed at
+        // every sched_barrier. Twiddles of one group, in the order used: layer W = f-1 (1 entry), f-2 (2), ... 0.
+        template <int T>
+        struct FinalStage
+        {
+            static constexpr int f = T - 12;
+            static constexpr int NTW = (1 << f) - 1;            // twiddles per group
+            static constexpr int SG = f == 1 ? 4 : (f == 2 ? 2 : 1); // groups per stage
+            static constexpr int NG = 1 << (5 - f);
+            static constexpr int NS = NG / SG;
+            static constexpr bool PIPE = f <= 2; // f = 3: two stages of 28 twiddle registers do not fit
+        };
+
+        template <int T, int G>
+        __device__ __forceinline__ void h_final_tw(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
+        {
+            constexpr int f = T - 12;
+#pragma unroll
+            for (int W = f - 1; W >= 0; W--)
+            {
+                const int tb = ((N & 0xFFFFF) + jb) >> (Arr<T, 4>::slot_bit(W) + 1);
+#pragma unroll
+                for (int o = 0; o < (1 << (f - 1 - W)); o++)
+                {
+                    const int s = (G << f) | (o << (W + 1));
+                    tg[(1 << (f - 1 - W)) - 1 + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                }
+            }
+        }
+
+        template <int T, bool STRICT, int G>
+        __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
+                                                           int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+        {
+            constexpr int f = T - 12;
+#pragma unroll
+            for (int W = f - 1; W >= 0; W--)
+            {
+                if (NTT_EXP(N, 0x100 << 20))
+                    break;
+                const int gb = Arr<T, 4>::slot_bit(W);
+                const int bit = 1 << W;
+#pragma unroll
+                for (int e = 0; e < (1 << f); e++)
+                {
+                    if (e & bit)
+                        continue;
+                    const int s = (G << f) | e;
+                    const u64x2 Wv = tg[(1 << (f - 1 - W)) - 1 + (e >> (W + 1))];
+                    if (STRICT)
+                        x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
+                    else if (gb == 0)
+                        x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
+                    butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < (1 << f); e += 2)
+            {
+                const int s = (G << f) | e;
+                ulonglong2 v;
+                v.x = x[s];
+                v.y = x[s + 1];
+                if (canon)
+                {
+                    v.x = v.x >= two_p ? v.x - two_p : v.x;
+                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    v.x = v.x >= p ? v.x - p : v.x;
+                    v.y = v.y >= p ? v.y - p : v.y;
+                }
+                if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
+                    continue;
+                *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
+            }
+        }
+
+        template <int T, int ST, int I = 0>
+        struct StageTw // twiddle loads of stage ST
+        {
+            __device__ static __forceinline__ void load(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
+            {
+                h_final_tw<T, ST * FinalStage<T>::SG + I>(tg + I * FinalStage<T>::NTW, tw, jb, N);
+                if constexpr (I + 1 < FinalStage<T>::SG)
+                    StageTw<T, ST, I + 1>::load(tg, tw, jb, N);
+            }
+        };
+        template <int T, bool STRICT, int ST, int I = 0>
+        struct StageRun
+        {
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
+                                                       u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+            {
+                h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
+                                                                         two_p, neg_p, rdp, canon);
+                if constexpr (I + 1 < FinalStage<T>::SG)
+                    StageRun<T, STRICT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+            }
+        };
+        template <int T, bool STRICT, int ST>
+        struct FinalPipe
+        {
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
+                                                       u64 *__restrict__ rowp, int jb, int N, u64 p, u64 two_p, u64 neg_p,
+                                                       u64 rdp, bool canon)
+            {
+                u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
+                if constexpr (ST + 1 < FinalStage<T>::NS)
+                    StageTw<T, ST + 1>::load(next, tw, jb, N);
+                __builtin_amdgcn_sched_barrier(0);
+                StageRun<T, STRICT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST + 1 < FinalStage<T>::NS)
+                    FinalPipe<T, STRICT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+            }
+        };
+
+        // ---- a compute round as a pipeline of stages. Stage K = kIL butterflies of one layer (layers W = 4, 3, 2, 1,
+        // 16 / kIL stages each). The twiddles of stage K+1 are requested before stage K is computed (pinned with
+        // sched_barrier), the first stage's before the preceding LDS exchange: no twiddle latency is exposed.
+        template <int T, int R, bool STRICT, bool UNIFORM, int K>
+        struct RoundStage
+        {
+            static constexpr int PER = 16 / kIL;
+            static constexpr int W = 4 - K / PER;
+            static constexpr int C = (K % PER) * kIL;
+            static constexpr int bit = 1 << W;
+            static constexpr int slot(int j)
+            {
+                return (((C + j) >> W) << (W + 1)) | ((C + j) & (bit - 1)); // the (C+j)-th slot with bit W clear
+            }
+            __device__ static __forceinline__ void load(u64 (&w)[kIL], u64 (&ws)[kIL], const u64 *__restrict__ tw, int jb,
+                                                        int N)
+            {
+                const int tb = (N + jb) >> (Arr<T, R>::slot_bit(W) + 1);
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    u64x2 Wv;
+                    if (UNIFORM)
+                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
+                    else
+                        Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                    w[j] = Wv.x;
+                    ws[j] = Wv.y;
+                }
+            }
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
+                                                       u64 neg_p)
+            {
+                u64 u[kIL], y[kIL];
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    u[j] = x[slot(j)];
+                    y[j] = x[slot(j) | bit];
+                    if (STRICT)
+                        u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
+                }
+                butterflies_fwd_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    x[slot(j)] = u[j];
+                    x[slot(j) | bit] = y[j];
+                }
+            }
+        };
+        template <int T, int R, bool STRICT, bool UNIFORM, int K = 0>
+        struct RoundPipe
+        {
+            static constexpr int NST = 4 * (16 / kIL);
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
+                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p)
+            {
+                u64 wn[kIL], wsn[kIL];
+                if constexpr (K + 1 < NST)
+                    RoundStage<T, R, STRICT, UNIFORM, K + 1>::load(wn, wsn, tw, jb, N);
+                __builtin_amdgcn_sched_barrier(0);
+                RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
+                if constexpr (K + 1 < NST)
+                    RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
+            }
         };
 
         template <int T, int R, bool STRICT, bool UNIFORM>
@@ -576,6 +780,10 @@ namespace sealhip
                 }
             }
             NTT_STAMP(0);
+#ifdef SEALHIP_NTT_EXPERIMENT
+            if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
+                g_ntt_trace[static_cast<std::size_t>(blockIdx.x) * 8 + 6] = __builtin_readcyclecounter();
+#endif
             if (NTT_EXP(flags, 0x1000) && (blockIdx.x >> 3) >= 32 && (blockIdx.x >> 3) < 64)
             {
                 for (int i = 0; i < ((flags >> 16) & 0xFF); i++)
@@ -601,18 +809,32 @@ namespace sealhip
             const int gbase = half << T;
             NTT_STAMP(1);
             // round 1: every lane index bit lies below the processed bits -> block-uniform twiddles
+            u64 w0[kIL], ws0[kIL];
+            RoundStage<T, 1, STRICT, true, 0>::load(w0, ws0, tw, gbase, N);
             if (!NTT_EXP(flags, 0x100))
-                h_round<T, 1, STRICT, true>(x, tw, gbase, N, p, two_p, neg_p, rdp);
+                RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
+            const int jb2 = gbase + Arr<T, 2>::tid_index(tid), jb3 = gbase + Arr<T, 3>::tid_index(tid);
+            RoundStage<T, 2, STRICT, false, 0>::load(w0, ws0, tw, jb2, N); // lands while the exchange runs
+            __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 1, 2>(x, lds, tid);
             if (tid == 0 && tickets)
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!NTT_EXP(flags, 0x100))
-                h_round<T, 2, STRICT, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, p, two_p, neg_p, rdp);
+                RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
+            RoundStage<T, 3, STRICT, false, 0>::load(w0, ws0, tw, jb3, N);
+            __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 2, 3>(x, lds, tid);
             if (!NTT_EXP(flags, 0x100))
-                h_round<T, 3, STRICT, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, p, two_p, neg_p, rdp);
+                RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
+            const int jb4 = gbase + Arr<T, 4>::tid_index(tid);
+            u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
+            if constexpr (FinalStage<T>::PIPE)
+            {
+                StageTw<T, 0>::load(tg0, tw, jb4, N); // lands while the last exchange runs
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 3, 4>(x, lds, tid);
             NTT_STAMP(2);
@@ -635,9 +857,12 @@ namespace sealhip
             //  that both workgroups of the row have finished reading)
             NTT_STAMP(3);
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
-            FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, gbase + Arr<T, 4>::tid_index(tid),
-                                                             NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N, p, two_p,
-                                                             neg_p, rdp, (flags & kNttCanonical) != 0);
+            const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
+            if constexpr (FinalStage<T>::PIPE)
+                FinalPipe<T, STRICT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, (flags & kNttCanonical) != 0);
+            else
+                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp,
+                                                                 (flags & kNttCanonical) != 0);
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
             if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
@@ -647,6 +872,7 @@ namespace sealhip
                 unsigned xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 g_ntt_trace[static_cast<std::size_t>(blockIdx.x) * 8 + 5] = (static_cast<u64>(xcc) << 32) | hw;
+                g_ntt_trace[static_cast<std::size_t>(blockIdx.x) * 8 + 7] = __builtin_readcyclecounter();
             }
 #endif
         }

@@ -19,6 +19,11 @@ for i, nme in enumerate(names):
     print("  %-18s mean %6.2f us  p10 %6.2f  p50 %6.2f  p90 %6.2f" % (nme, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
 life = (t[:, 4] - t[:, 0]) * us
 print("  %-18s mean %6.2f us  p10 %6.2f  p50 %6.2f  p90 %6.2f" % ("lifetime", life.mean(), *np.percentile(life, [10, 50, 90])))
+if a[:, 7].any():
+    cyc = (a[:, 7] - a[:, 6]).astype(np.float64)
+    wall = (t[:, 4] - t[:, 0]).astype(np.float64) * 10e-9
+    print("  shader clock seen by the workgroups: mean %.0f MHz (p10 %.0f, p90 %.0f)" % (
+        (cyc / wall).mean() / 1e6, *np.percentile(cyc / wall / 1e6, [10, 90])))
 hw = a[:, 5]
 cu = ((hw >> 32) << 16) | ((hw & 0xFFFFFFFF) >> 8 & 0xFF)
 ids, inv = np.unique(cu, return_inverse=True)
