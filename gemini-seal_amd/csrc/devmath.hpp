@@ -332,4 +332,53 @@ namespace sealhip
             u[j] = X;
         }
     }
+    // ---------------------------------------------------------------------------------------------
+    // Carry-free 128-bit dot product  sum_i t_i * c_i  for operands below 2^61 (SEAL_MOD_BIT_COUNT_MAX,
+    // util/defines.h:33; checked when the context is built). The reference accumulates 128-bit products lazily
+    // (multiply_accumulate_uint64, uintarith.h:942-958) and reduces once; the integer sum is what matters, not
+    // how it is accumulated. A 64x64 multiply-accumulate into (lo, hi) costs the compiler ~20 VALU instructions
+    // (4 multiplies, carry chains, register moves). Here every partial product goes to a 64-bit accumulator that
+    // cannot overflow, each with ONE v_mad_u64_u32 and no carry handling:
+    //   t = t1*2^32 + t0 (t1 < 2^29),  t0 = t01*2^16 + t00,  c = c1*2^32 + c0 (c1 < 2^29)
+    //   L0 += t00*c0 (< 2^48)   L1 += t01*c0 (< 2^48)   H += t1*c1 (< 2^58)
+    //   M[.] += t0*c1, t1*c0 (< 2^61 each; at most 8 products per accumulator)
+    // and sum = L0 + L1*2^16 + (M...)*2^32 + H*2^64 is assembled once per dot product.
+    struct SplitT // the per-lane factor, split once and reused by every dot product it takes part in
+    {
+        u32 t0, t1, t00, t01;
+        __device__ __forceinline__ SplitT() : t0(0), t1(0), t00(0), t01(0) {}
+        __device__ __forceinline__ explicit SplitT(u64 t)
+            : t0(static_cast<u32>(t)), t1(static_cast<u32>(t >> 32)), t00(static_cast<u32>(t) & 0xFFFFu),
+              t01(static_cast<u32>(t) >> 16)
+        {}
+    };
+    template <int NTERMS>
+    struct DotAcc
+    {
+        static constexpr int NM = (2 * NTERMS + 7) / 8;
+        u64 l0 = 0, l1 = 0, h = 0;
+        u64 m[NM] = {};
+        // c is the wave-uniform constant (its halves are used whole: one scalar operand per v_mad_u64_u32)
+        template <int IDX>
+        __device__ __forceinline__ void add(const SplitT &t, u64 c)
+        {
+            static_assert(IDX >= 0 && IDX < NTERMS, "term index");
+            const u32 c0 = static_cast<u32>(c), c1 = static_cast<u32>(c >> 32);
+            l0 += static_cast<u64>(t.t00) * c0;
+            l1 += static_cast<u64>(t.t01) * c0;
+            m[(2 * IDX) % NM] += static_cast<u64>(t.t0) * c1;
+            m[(2 * IDX + 1) % NM] += static_cast<u64>(t.t1) * c0;
+            h += static_cast<u64>(t.t1) * c1;
+        }
+        __device__ __forceinline__ void finish(u64 &lo, u64 &hi) const
+        {
+            typedef unsigned __int128 u128;
+            u128 acc = (static_cast<u128>(h) << 64) + l0 + (static_cast<u128>(l1) << 16);
+#pragma unroll
+            for (int i = 0; i < NM; i++)
+                acc += static_cast<u128>(m[i]) << 32;
+            lo = static_cast<u64>(acc);
+            hi = static_cast<u64>(acc >> 64);
+        }
+    };
 } // namespace sealhip

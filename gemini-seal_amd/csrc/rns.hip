@@ -3,13 +3,35 @@
 // so every global access is a coalesced row segment; the per-prime constants are wave-uniform
 // (scalar loads). All outputs are canonical residues, so constants are fused where the reference
 // multiplies twice (e.g. m_tilde * q^_i^{-1}).
+#include <type_traits>
+
 #include "engine.hpp"
 
 namespace sealhip
 {
     namespace
     {
+        // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1
+        template <int N, int I = 0, class F>
+        __device__ __forceinline__ void static_for(F &&f)
+        {
+            if constexpr (I < N)
+            {
+                f(std::integral_constant<int, I>{});
+                static_for<N, I + 1>(f);
+            }
+        }
+
         constexpr int kThreads = 256;
+
+        // The level constants never change after the context is built. Reading them through the constant address
+        // space tells the compiler so: scalar loads that can be merged and hoisted above the kernel's own stores
+        // (through a plain pointer every constant is re-fetched, and waited for, right before its use).
+        template <class T>
+        __device__ __forceinline__ const __attribute__((address_space(4))) T *kc(const T *p)
+        {
+            return (const __attribute__((address_space(4))) T *)p;
+        }
 
         struct Cols
         {
@@ -77,7 +99,8 @@ namespace sealhip
             return mul_mod(mul_add_mod(d->prod_q_mod_Bsk[j], temp, in_b, Bp.p, Bp.cr0, Bp.cr1), d->inv_mt_mod_Bsk[j],
                            Bp.p, Bp.cr0, Bp.cr1);
         }
-        __device__ __forceinline__ u64 r_m_tilde(u64 in_mt, const RnsDev *d)
+        template <class DP>
+        __device__ __forceinline__ u64 r_m_tilde(u64 in_mt, DP d)
         {
             const u64 temp = (in_mt * d->inv_prod_q_mod_mt) & 0xFFFFFFFFull;
             return temp ? (1ull << 32) - temp : 0;
@@ -143,8 +166,8 @@ namespace sealhip
         // KMAX < 0 means "exactly K = -KMAX primes, known at compile time" (no per-iteration guards, constants
         // fetched with wide scalar loads); KMAX > 0 is the guarded form for any k <= KMAX
         template <int KMAX>
-        __global__ __launch_bounds__(kThreads) void bfv_lift2_kernel(const RnsDev *__restrict__ d,
-                                                                     const PrimeDev *__restrict__ primes,
+        __global__ __launch_bounds__(kThreads) void bfv_lift2_kernel(const RnsDev *__restrict__ d_,
+                                                                     const PrimeDev *__restrict__ primes_,
                                                                      const u64 *__restrict__ in, std::size_t in_stride,
                                                                      u64 *__restrict__ out, std::size_t out_stride,
                                                                      std::size_t count, int logn)
@@ -153,6 +176,8 @@ namespace sealhip
             if (!column(count, logn, cc))
                 return;
             constexpr int KA = KMAX < 0 ? -KMAX : KMAX; // array extent
+            const auto *d = kc(d_);           // read-only for the lifetime of the context: constant address space
+            const auto *primes = kc(primes_); // (scalar loads the compiler may merge and hoist)
             const int k = KMAX < 0 ? KA : d->k, nB = d->nB;
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
@@ -163,25 +188,43 @@ namespace sealhip
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
-                    const PrimeDev &Q = primes[d->q_prime[i]];
-                    t[i] = mulmod_shoup(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], Q.p); // exact canonical product
+                    const u64 qp = primes[d->q_prime[i]].p;
+                    t[i] = mulmod_shoup(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
                     acc += t[i] * d->q_to_mt[i];
                 }
             const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
             const bool small = d->redc_small != 0;
+            SplitT ts[KA];
+            if constexpr (KMAX < 0)
+                static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
+            const auto *L1m = kc(d->lift_L1m);
+            const auto *L2m = kc(d->lift_L2m);
             for (int j = 0; j < nB; j++)
             {
-                const PrimeDev &Bp = primes[d->bsk_prime[j]];
+                const auto *Bp = primes + d->bsk_prime[j];
+                const u64 bp = Bp->p;
                 u64 temp = r_mt;
                 if (temp >= (1ull << 31))
-                    temp += Bp.p - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
-                const u64 *row = d->lift_L1m + j * k; // constants carry the factor 2^64: REDC removes it
-                u64 lo = temp * d->lift_L2m[j], hi = mulhi(temp, d->lift_L2m[j]);
+                    temp += bp - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
+                const auto *row = L1m + j * k; // constants carry the factor 2^64: REDC removes it
+                u64 lo, hi;
+                if constexpr (KMAX < 0)
+                {
+                    DotAcc<KA + 1> acc2; // carry-free accumulation (devmath.hpp), same integer sum
+                    acc2.template add<0>(SplitT(temp), L2m[j]);
+                    static_for<KA>([&](auto I) { acc2.template add<I.value + 1>(ts[I.value], row[I.value]); });
+                    acc2.finish(lo, hi);
+                }
+                else
+                {
+                    lo = temp * L2m[j];
+                    hi = mulhi(temp, L2m[j]);
 #pragma unroll
-                for (int i = 0; i < KA; i++)
-                    if (KMAX < 0 || i < k)
-                        mac128(lo, hi, t[i], row[i]);
-                pout[j * N] = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
+                    for (int i = 0; i < KA; i++)
+                        if (i < k)
+                            mac128(lo, hi, t[i], row[i]);
+                }
+                pout[j * N] = redc_finish(redc128(lo, hi, bp, Bp->ninv), bp, Bp->rdp, small);
             }
         }
 
@@ -191,25 +234,25 @@ namespace sealhip
         // One coefficient of an inverse-NTT output whose top layer was deferred (kNttDeferTop): apply
         // BackwardLazyLast (ntt.cpp:274-281) to the pair (c mod N/2, c mod N/2 + N/2) and the canonicalising
         // subtraction of ntt.h:328-333, keeping only this lane's side of the butterfly.
-        __device__ __forceinline__ u64 load_after_top(const u64 *__restrict__ row, std::size_t c_lo, std::size_t half,
-                                                      bool is_hi, const PrimeDev &P)
+        template <class PP>
+        __device__ __forceinline__ u64 after_top(u64 u, u64 v, bool is_hi, PP P)
         {
-            const u64 u = row[c_lo], v = row[c_lo + half];
+            const u64 p = P->p, two_p = P->two_p;
             u64 r;
             if (is_hi)
-                r = mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p);
+                r = mulmod_lazy(u - v + two_p, P->inv_n_w, P->inv_n_w_shoup, p);
             else
             {
                 u64 tt = u + v;
-                tt = tt >= P.two_p ? tt - P.two_p : tt;
-                r = mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, P.p);
+                tt = tt >= two_p ? tt - two_p : tt;
+                r = mulmod_lazy(tt, P->inv_n, P->inv_n_shoup, p);
             }
-            return r >= P.p ? r - P.p : r;
+            return r >= p ? r - p : r;
         }
 
         template <int KMAX, bool DEFER>
-        __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d,
-                                                                         const PrimeDev *__restrict__ primes,
+        __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d_,
+                                                                         const PrimeDev *__restrict__ primes_,
                                                                          const u64 *__restrict__ in,
                                                                          std::size_t in_stride, u64 *__restrict__ out,
                                                                          std::size_t out_stride, std::size_t count,
@@ -219,6 +262,8 @@ namespace sealhip
             if (!column(count, logn, cc))
                 return;
             constexpr int KA = KMAX < 0 ? -KMAX : KMAX;
+            const auto *d = kc(d_);           // read-only for the lifetime of the context: constant address space
+            const auto *primes = kc(primes_); // (scalar loads the compiler may merge and hoist)
             const int k = KMAX < 0 ? KA : d->k, B = d->B; // B is k or k + 1
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
@@ -226,57 +271,131 @@ namespace sealhip
             const std::size_t half = N >> 1, c_lo = cc.c & (half - 1);
             const bool is_hi = cc.c >= half; // block-uniform (N/2 is a multiple of the block size)
             u64 *pout = out + cc.item * out_stride + cc.c;
+            // every input word of this column is requested before any arithmetic: one exposed memory latency per
+            // thread instead of one per output row (the loads used to sit in the row loops)
+            u64 ru[2 * KA + 2], rv[2 * KA + 2];
+#pragma unroll
+            for (int i = 0; i < KA; i++)
+                if (KMAX < 0 || i < k)
+                {
+                    ru[i] = DEFER ? pitem[i * N + c_lo] : pin[i * N];
+                    rv[i] = DEFER ? pitem[i * N + c_lo + half] : 0;
+                }
+#pragma unroll
+            for (int j = 0; j < KA + 2; j++)
+                if (j <= B)
+                {
+                    ru[KA + j] = DEFER ? pitem[(k + j) * N + c_lo] : pin[(k + j) * N];
+                    rv[KA + j] = DEFER ? pitem[(k + j) * N + c_lo + half] : 0;
+                }
+            __builtin_amdgcn_sched_barrier(0);
             u64 t[KA];
 #pragma unroll
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
-                    const PrimeDev &Q = primes[d->q_prime[i]];
-                    const u64 xin = DEFER ? load_after_top(pitem + i * N, c_lo, half, is_hi, Q) : pin[i * N];
-                    t[i] = mulmod_shoup(xin, d->floor_F0[i], d->floor_F0_s[i], Q.p);
+                    const auto *Q = primes + d->q_prime[i];
+                    const u64 xin = DEFER ? after_top(ru[i], rv[i], is_hi, Q) : ru[i];
+                    t[i] = mulmod_shoup(xin, kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
                 }
             u64 tb[KA + 1];
             u64 fl_sk = 0;
             const bool small = d->redc_small != 0;
+            SplitT ts[KA], tbs[KA + 1];
+            if constexpr (KMAX < 0)
+                static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
+            const auto *G1m = kc(d->floor_G1m);
+            const auto *G2m = kc(d->floor_G2m);
 #pragma unroll
             for (int j = 0; j < KA + 2; j++)
                 if (j <= B)
                 {
-                    const PrimeDev &Bp = primes[d->bsk_prime[j]];
-                    const u64 *row = d->floor_G2m + j * k;
-                    const u64 x = DEFER ? load_after_top(pitem + (k + j) * N, c_lo, half, is_hi, Bp) : pin[(k + j) * N];
-                    u64 lo = x * d->floor_G1m[j], hi = mulhi(x, d->floor_G1m[j]);
+                    const auto *Bp = primes + d->bsk_prime[j];
+                    const auto *row = G2m + j * k;
+                    const u64 x = DEFER ? after_top(ru[KA + j], rv[KA + j], is_hi, Bp) : ru[KA + j];
+                    u64 lo, hi;
+                    if constexpr (KMAX < 0)
+                    {
+                        DotAcc<KA + 1> acc2;
+                        acc2.template add<0>(SplitT(x), G1m[j]);
+                        static_for<KA>([&](auto I) { acc2.template add<I.value + 1>(ts[I.value], row[I.value]); });
+                        acc2.finish(lo, hi);
+                    }
+                    else
+                    {
+                        lo = x * G1m[j];
+                        hi = mulhi(x, G1m[j]);
 #pragma unroll
-                    for (int i = 0; i < KA; i++)
-                        if (KMAX < 0 || i < k)
-                            mac128(lo, hi, t[i], row[i]);
-                    const u64 v = redc_finish(redc128(lo, hi, Bp.p, Bp.ninv), Bp.p, Bp.rdp, small);
+                        for (int i = 0; i < KA; i++)
+                            if (i < k)
+                                mac128(lo, hi, t[i], row[i]);
+                    }
+                    const u64 bp = Bp->p;
+                    const u64 v = redc_finish(redc128(lo, hi, bp, Bp->ninv), bp, Bp->rdp, small);
                     if (j < B)
                         tb[j < KA + 1 ? j : 0] = v;
                     else
                         fl_sk = v;
                 }
-            const PrimeDev &Msk = primes[d->bsk_prime[B]];
+            const auto *Msk = primes + d->bsk_prime[B];
+            const u64 mp = Msk->p;
+            const auto *BtoMsk = kc(d->B_to_mskm);
             u64 lo = 0, hi = 0;
-#pragma unroll
-            for (int j = 0; j < KA + 1; j++)
-                if (j < B)
-                    mac128(lo, hi, tb[j], d->B_to_mskm[j]);
-            const u64 conv_sk = redc_finish(redc128(lo, hi, Msk.p, Msk.ninv), Msk.p, Msk.rdp, small);
-            const u64 alpha = mulmod_shoup(conv_sk + (Msk.p - fl_sk), d->inv_prod_B_mod_msk, d->inv_prod_B_mod_msk_s, Msk.p);
-            const bool neg = alpha > (Msk.p >> 1); // rns.cpp:909
-            const u64 a2 = neg ? Msk.p - alpha : alpha;
-            for (int i = 0; i < k; i++)
+            if constexpr (KMAX < 0)
             {
-                const PrimeDev &Q = primes[d->q_prime[i]];
-                const u64 c = neg ? d->pBm[i] : d->nBm[i];
-                const u64 *mrow = d->B_to_qm + i * B;
-                u64 l2 = a2 * c, h2 = mulhi(a2, c);
+                static_for<KA + 1>([&](auto J) {
+                    if (J.value < B)
+                        tbs[J.value] = SplitT(tb[J.value]);
+                });
+                DotAcc<KA + 1> acc2;
+                static_for<KA + 1>([&](auto J) {
+                    if (J.value < B)
+                        acc2.template add<J.value>(tbs[J.value], BtoMsk[J.value]);
+                });
+                acc2.finish(lo, hi);
+            }
+            else
+            {
 #pragma unroll
                 for (int j = 0; j < KA + 1; j++)
                     if (j < B)
-                        mac128(l2, h2, tb[j], mrow[j]);
-                pout[i * N] = redc_finish(redc128(l2, h2, Q.p, Q.ninv), Q.p, Q.rdp, small);
+                        mac128(lo, hi, tb[j], BtoMsk[j]);
+            }
+            const u64 conv_sk = redc_finish(redc128(lo, hi, mp, Msk->ninv), mp, Msk->rdp, small);
+            const u64 alpha = mulmod_shoup(conv_sk + (mp - fl_sk), d->inv_prod_B_mod_msk, d->inv_prod_B_mod_msk_s, mp);
+            const bool neg = alpha > (mp >> 1); // rns.cpp:909
+            const u64 a2 = neg ? mp - alpha : alpha;
+            const SplitT a2s(a2);
+            const auto *pBm = kc(d->pBm);
+            const auto *nBm = kc(d->nBm);
+            const auto *BtoQ = kc(d->B_to_qm);
+            for (int i = 0; i < k; i++)
+            {
+                const auto *Q = primes + d->q_prime[i];
+                const u64 c = neg ? pBm[i] : nBm[i];
+                const auto *mrow = BtoQ + i * B;
+                u64 l2, h2;
+                if constexpr (KMAX < 0)
+                {
+                    DotAcc<KA + 2> acc2;
+                    acc2.template add<0>(a2s, c);
+                    static_for<KA + 1>([&](auto J) {
+                        if (J.value < B)
+                            acc2.template add<J.value + 1>(tbs[J.value], mrow[J.value]);
+                    });
+                    acc2.finish(l2, h2);
+                }
+                else
+                {
+                    l2 = a2 * c;
+                    h2 = mulhi(a2, c);
+#pragma unroll
+                    for (int j = 0; j < KA + 1; j++)
+                        if (j < B)
+                            mac128(l2, h2, tb[j], mrow[j]);
+                }
+                const u64 qp = Q->p;
+                pout[i * N] = redc_finish(redc128(l2, h2, qp, Q->ninv), qp, Q->rdp, small);
             }
         }
 
