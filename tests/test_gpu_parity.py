@@ -761,3 +761,30 @@ def test_f1_transparent_mod63_and_native_rotate(sealhip):
         assert np.array_equal(a.download(src.shape), b.download(src.shape)), steps
     with pytest.raises(ValueError):
         ev.rotate_vector_native(ctx.upload(src), k, count, 16, keys)  # power of two without a key
+
+
+@pytest.mark.parametrize("k_first", [3, 7, 9])
+def test_bfv_multiply_extreme_values_59bit(sealhip, k_first):
+    """Largest user primes the fork admits (59 bits, util/defines.h:40) and operands that are all p-1 / all zero /
+    alternating: worst case for the carry-free dot-product accumulators of the fused BEHZ kernels (devmath.hpp DotAcc)."""
+    logn, n, t = 12, 4096, 786433
+    kmods = O.coeff_modulus_create(n, [59] * (k_first + 1))
+    k = k_first
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    top = np.stack([np.full((2, n), p - 1, dtype=np.uint64) for p in kmods[:k]], axis=1)
+    alt = top.copy()
+    alt[:, :, ::2] = 0
+    rng = np.random.default_rng(k_first)
+    rnd = _rand_ct(rng, kmods[:k], 2, n, 1)[0]
+    cases = [(top, top), (top, alt), (alt, rnd), (np.zeros_like(top), top)]
+    a = np.stack([c[0] for c in cases])
+    b = np.stack([c[1] for c in cases])
+    out = ctx.alloc(len(cases) * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, len(cases), out)
+    got = out.download((len(cases), 3, k, n))
+    for i in range(len(cases)):
+        exp = np.zeros((3, k, n), dtype=np.uint64)
+        assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(exp)) == 0
+        assert np.array_equal(got[i], exp), i
