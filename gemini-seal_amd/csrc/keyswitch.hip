@@ -146,6 +146,74 @@ namespace sealhip
             pp[static_cast<std::size_t>(rows) * N] = barrett_reduce_128(lo1, hi1, P.p, P.cr0, P.cr1);
         }
 
+        // The same inner product with the key words of a lane's (row, coefficient) kept in registers across
+        // kItems consecutive ciphertexts: the key slice (2 * nd words per lane, 29 MB per pass at cfg3) is read once
+        // per kItems ciphertexts instead of once per ciphertext (it made up two thirds of this kernel's read traffic).
+        // The digit words of the next ciphertext are requested before the current one is accumulated.
+        constexpr int kMacItems = 8;
+        template <int ND>
+        __global__ __launch_bounds__(kThreads) void ks_mac_items_kernel(const KsDev *__restrict__ d,
+                                                                        const PrimeDev *__restrict__ primes,
+                                                                        const u64 *__restrict__ target,
+                                                                        std::size_t target_stride,
+                                                                        const u64 *__restrict__ ext,
+                                                                        std::size_t ext_stride,
+                                                                        std::size_t ext_digit_stride,
+                                                                        const u64 *__restrict__ key,
+                                                                        u64 *__restrict__ prod, std::size_t prod_stride,
+                                                                        std::size_t count, int logn)
+        {
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const int k = d->k, nsp = d->nsp, rows = k + nsp, n_total = d->n_total;
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t c = i & (N - 1);
+            const std::size_t rr = i >> logn;
+            const int r = static_cast<int>(rr % rows);
+            const std::size_t item0 = (rr / rows) * kMacItems;
+            if (item0 >= count)
+                return;
+            const std::size_t item1 = item0 + kMacItems < count ? item0 + kMacItems : count;
+            const int rns_idx = d->row_prime[r];
+            const int my_digit = r < k ? r / nsp : -1;
+            const std::size_t row_off = static_cast<std::size_t>(r) * N + c;
+            const u64 *pkey = key + static_cast<std::size_t>(rns_idx) * N + c;
+            const std::size_t key_comp = static_cast<std::size_t>(n_total) * N;
+            u64 k0[ND], k1[ND], x[ND], xn[ND];
+#pragma unroll
+            for (int j = 0; j < ND; j++)
+            {
+                k0[j] = pkey[(2 * static_cast<std::size_t>(j)) * key_comp];
+                k1[j] = pkey[(2 * static_cast<std::size_t>(j) + 1) * key_comp];
+            }
+            auto load_x = [&](u64(&dst)[ND], std::size_t item) {
+#pragma unroll
+                for (int j = 0; j < ND; j++)
+                    dst[j] = j == my_digit ? target[item * target_stride + row_off]
+                                           : ext[item * ext_stride + static_cast<std::size_t>(j) * ext_digit_stride + row_off];
+            };
+            load_x(x, item0);
+            const PrimeDev &P = primes[rns_idx];
+            const u64 p = P.p, cr0 = P.cr0, cr1 = P.cr1;
+            for (std::size_t item = item0; item < item1; item++)
+            {
+                if (item + 1 < item1)
+                    load_x(xn, item + 1);
+                u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+                for (int j = 0; j < ND; j++)
+                {
+                    mac128(lo0, hi0, x[j], k0[j]);
+                    mac128(lo1, hi1, x[j], k1[j]);
+                }
+                u64 *pp = prod + item * prod_stride + row_off;
+                pp[0] = barrett_reduce_128(lo0, hi0, p, cr0, cr1);
+                pp[static_cast<std::size_t>(rows) * N] = barrett_reduce_128(lo1, hi1, p, cr0, cr1);
+#pragma unroll
+                for (int j = 0; j < ND; j++)
+                    x[j] = xn[j];
+            }
+        }
+
         // rescale_special_rns_inplace, steps 1-2 (multi_special_primes.cpp:253-282): from the (coefficient
         // form) special rows of one polynomial compute temp_i for every ciphertext prime i.
         __global__ __launch_bounds__(kThreads) void ks_moddown_pre_kernel(const KsDev *__restrict__ d,
@@ -253,9 +321,38 @@ namespace sealhip
         const u64 *tg = target;
         const std::size_t lanes = (count * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
         ProfScope prof(e, "ks_mac", 0);
-        ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
-                                                                    ext_digit_stride, key, prod, prod_stride, count,
-                                                                    e.logn);
+        const std::size_t groups = (count + kMacItems - 1) / kMacItems;
+        const std::size_t glanes = (groups * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
+#define SEALHIP_KS_MAC(ND)                                                                                          \
+    case ND:                                                                                                        \
+        ks_mac_items_kernel<ND><<<blocks_for(glanes), kThreads, 0, e.stream>>>(                                     \
+            d, e.d_primes, tg, target_stride, ext, ext_stride, ext_digit_stride, key, prod, prod_stride, count,    \
+            e.logn);                                                                                                \
+        break;
+        switch (count >= 2 * kMacItems ? h.nd : 0)
+        {
+            SEALHIP_KS_MAC(1)
+            SEALHIP_KS_MAC(2)
+            SEALHIP_KS_MAC(3)
+            SEALHIP_KS_MAC(4)
+            SEALHIP_KS_MAC(5)
+            SEALHIP_KS_MAC(6)
+            SEALHIP_KS_MAC(7)
+            SEALHIP_KS_MAC(8)
+            SEALHIP_KS_MAC(9)
+            SEALHIP_KS_MAC(10)
+            SEALHIP_KS_MAC(11)
+            SEALHIP_KS_MAC(12)
+            SEALHIP_KS_MAC(13)
+            SEALHIP_KS_MAC(14)
+            SEALHIP_KS_MAC(15)
+            SEALHIP_KS_MAC(16)
+        default: // small batches or more than 16 digits: one lane per (ciphertext, row, coefficient)
+            ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
+                                                                        ext_digit_stride, key, prod, prod_stride, count,
+                                                                        e.logn);
+        }
+#undef SEALHIP_KS_MAC
         return hipGetLastError();
     }
 

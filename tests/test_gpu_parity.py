@@ -788,3 +788,38 @@ def test_bfv_multiply_extreme_values_59bit(sealhip, k_first):
         exp = np.zeros((3, k, n), dtype=np.uint64)
         assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(exp)) == 0
         assert np.array_equal(got[i], exp), i
+
+
+@pytest.mark.parametrize("scheme,nsp,count", [(1, 1, 19), (1, 2, 16), (2, 1, 27)])
+def test_key_switch_large_batch_key_reuse(sealhip, scheme, nsp, count):
+    """Batches of >= 16 ciphertexts take the inner-product kernel that keeps the key words in registers across eight
+    ciphertexts (ks_mac_items_kernel); ragged last groups included. relinearize + apply_galois against the oracle."""
+    logn, n = 11, 2048
+    kmods = O.coeff_modulus_create(n, [45] * (4 + nsp))
+    k = 4
+    d = (k + nsp - 1) // nsp
+    t = 65537 if scheme == 1 else 0
+    ctx = sealhip.Context(scheme, logn, kmods, nsp, t)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t)
+    rng = np.random.default_rng(100 * scheme + nsp)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(d)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    ct3 = _rand_ct(rng, kmods[:k], 3, n, count)
+    dct = ctx.upload(ct3)
+    ev.relinearize_inplace(dct, 3, k, count, [dkey])
+    got = dct.download(ct3.shape)
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    for i in range(count):
+        exp = ct3[i].copy()
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp), 3, keys) == 0
+        assert np.array_equal(got[i, :2], exp[:2]), i
+    ct2 = _rand_ct(rng, kmods[:k], 2, n, count)
+    elt = ctx.galois_elt_from_step(3)
+    g = ctx.upload(ct2)
+    ev.apply_galois_inplace(g, k, count, elt, dkey)
+    got = g.download(ct2.shape)
+    for i in range(count):
+        exp = ct2[i].copy()
+        assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(exp), elt, O.ptr(key)) == 0
+        assert np.array_equal(got[i], exp), i
