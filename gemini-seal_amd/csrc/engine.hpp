@@ -308,6 +308,11 @@ namespace sealhip
                              std::size_t count);
     hipError_t launch_ks_moddown_pre(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
                                      std::size_t prod_stride, u64 *temp, std::size_t temp_stride, std::size_t npolys);
+    // BFV only: steps 1-4 of the rescale + the add into the ciphertext in one kernel; top_deferred = the rows of prod
+    // come from an inverse NTT launched with kNttDeferTop
+    hipError_t launch_ks_moddown_bfv(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
+                                     std::size_t prod_stride, u64 *ct, std::size_t ct_item_stride, std::size_t npolys,
+                                     bool top_deferred);
     hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
                                       std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
                                       std::size_t ct_item_stride, std::size_t npolys, int add_into_ct);

@@ -293,6 +293,77 @@ namespace sealhip
                 *pp = v;
         }
 
+        // BFV: rescale_special_rns_inplace (multi_special_primes.cpp:237-304) + the final add (evaluator.cpp:2363-2366)
+        // in one kernel. In BFV nothing happens between steps 2 and 4 of the rescale (the q rows are simply brought
+        // to coefficient form), so temp_q is recomputed per lane from the special rows instead of being written
+        // by one kernel and read by the next (2*k row transfers per polynomial), and with DEFER the top inverse-NTT
+        // layer of every row read here is applied on load (kNttDeferTop: no ntt_inv_top pass over the 2*(k+nsp) rows).
+        // Every value that leaves this kernel is a canonical residue of an exact modular expression, so the
+        // representatives chosen for the intermediates do not matter.
+        template <bool DEFER>
+        __device__ __forceinline__ u64 row_value(const u64 *__restrict__ row, std::size_t c, std::size_t half,
+                                                 const PrimeDev &P)
+        {
+            if (!DEFER)
+                return row[c];
+            const std::size_t c_lo = c & (half - 1);
+            const u64 u = row[c_lo], v = row[c_lo + half];
+            if (c >= half)
+                return mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p); // BackwardLazyLast, ntt.cpp:274-281
+            u64 tt = u + v;
+            tt = tt >= P.two_p ? tt - P.two_p : tt;
+            return mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, P.p);
+        }
+
+        template <bool DEFER>
+        __global__ __launch_bounds__(kThreads) void ks_moddown_bfv_kernel(const KsDev *__restrict__ d,
+                                                                          const PrimeDev *__restrict__ primes,
+                                                                          const u64 *__restrict__ prod,
+                                                                          std::size_t prod_stride, u64 *__restrict__ ct,
+                                                                          std::size_t ct_item_stride, std::size_t npolys,
+                                                                          int logn)
+        {
+            const std::size_t N = static_cast<std::size_t>(1) << logn, half = N >> 1;
+            const int k = d->k, nsp = d->nsp;
+            const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
+            const std::size_t c = i & (N - 1);
+            const std::size_t rr = i >> logn;
+            const int q = static_cast<int>(rr % k);
+            const std::size_t poly = rr / k;
+            if (poly >= npolys)
+                return;
+            const PrimeDev &Q = primes[d->row_prime[q]];
+            const u64 *pp = prod + poly * prod_stride;
+            // steps 1-2 for this lane's prime (multi_special_primes.cpp:253-282)
+            u64 temp;
+            if (nsp == 1)
+            {
+                const PrimeDev &S = primes[d->row_prime[k]];
+                const u64 sv = row_value<DEFER>(pp + static_cast<std::size_t>(k) * N, c, half, S);
+                const u64 v = neg_mod(barrett_reduce_63(sv, S.p, S.cr1), S.p); // :270-273
+                temp = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
+            }
+            else
+            {
+                u64 lo = 0, hi = 0;
+                for (int j = 0; j < nsp; j++)
+                {
+                    const PrimeDev &S = primes[d->row_prime[k + j]];
+                    u64 sv = row_value<DEFER>(pp + static_cast<std::size_t>(k + j) * N, c, half, S);
+                    if (DEFER)
+                        sv = sv >= S.p ? sv - S.p : sv; // the step-by-step path feeds the lazy value; same residue
+                    const u64 y = mulmod_shoup(sv, d->inv_hat[j], d->inv_hat_shoup[j], S.p); // :262-267
+                    mac128(lo, hi, y, d->neg_hat[q * nsp + j]);
+                }
+                temp = barrett_reduce_128(lo, hi, Q.p, Q.cr0, Q.cr1);
+            }
+            // step 4 (:291-302) and the add into the ciphertext
+            const u64 pv = row_value<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q);
+            const u64 v = mulmod_shoup(pv + temp, d->invP[q], d->invP_shoup[q], Q.p);
+            u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
+            *pc = add_mod(v, *pc, Q.p);
+        }
+
         inline unsigned blocks_for(std::size_t lanes)
         {
             return static_cast<unsigned>((lanes + kThreads - 1) / kThreads);
@@ -364,6 +435,23 @@ namespace sealhip
         ProfScope prof(e, "ks_moddown_pre", 0);
         ks_moddown_pre_kernel<<<blocks_for(npolys << e.logn), kThreads, 0, e.stream>>>(
             d, e.d_primes, prod, prod_stride, temp, temp_stride, npolys, e.logn);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_ks_moddown_bfv(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
+                                     std::size_t prod_stride, u64 *ct, std::size_t ct_item_stride, std::size_t npolys,
+                                     bool top_deferred)
+    {
+        if (!npolys)
+            return hipSuccess;
+        const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
+        ProfScope prof(e, "ks_moddown_bfv", 0);
+        if (top_deferred)
+            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, prod, prod_stride, ct,
+                                                                                     ct_item_stride, npolys, e.logn);
+        else
+            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, prod, prod_stride, ct,
+                                                                                      ct_item_stride, npolys, e.logn);
         return hipGetLastError();
     }
 

@@ -166,6 +166,16 @@ namespace sealhip
             // Step 3b + 4 (:2326-2349): 128-bit inner product over the digits, reduced
             check(launch_ks_mac(e, lt.d_ks, h, inb, inb_stride, ext, ext_item, ext_digit, key.d_data, prod, w_prod, m),
                   "mac");
+            if (!ckks && !e.unfused_rns)
+            {
+                // BFV: every row of both products goes back to coefficient form in one launch (the reference does the
+                // special rows first, :2351-2355, and the others inside rescale_special_rns_inplace, :286-289 -- the
+                // order of independent row transforms does not matter), then one fused mod-down kernel
+                const bool defer = ntt_can_defer_top(e, k);
+                check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, defer ? kNttDeferTop : 0), "intt(prod)");
+                check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer), "moddown_bfv");
+                continue;
+            }
             // (:2351-2355) special rows back to coefficient form (lazy)
             check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, 0), "intt(special)");
             // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
