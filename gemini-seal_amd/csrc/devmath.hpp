@@ -381,4 +381,67 @@ namespace sealhip
             hi = static_cast<u64>(acc >> 64);
         }
     };
+    // IL inverse (Gentleman-Sande) lazy butterflies in lock step (BackwardLazy, ntt.cpp:265-272):
+    // x' = u + v - (2p if >= 2p), y' = (u - v + 2p) * w lazily. Same instruction discipline as butterflies_fwd_hs.
+    template <bool WU, int IL>
+    __device__ __forceinline__ void butterflies_inv_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
+                                                       u64 neg_p, u64 two_p)
+    {
+        static_assert(IL >= 2, "the carry of step 3 is read in step 5: at least two other instructions in between");
+        const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
+        u64 dlt[IL], A[IL], B[IL], E[IL], V[IL], q[IL], carry[IL];
+        u32 cb[IL];
+        u64 cy[IL] = {};
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+        {
+            dlt[j] = u[j] - y[j] + two_p;
+            u64 tt = u[j] + y[j];
+            u[j] = tt >= two_p ? tt - two_p : tt;
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            A[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j]),
+                              static_cast<u64>(__umulhi(static_cast<u32>(dlt[j]), static_cast<u32>(ws[j]))), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mul64v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(w[j] >> 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+        {
+            if (WU)
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4"
+                             : "=v"(B[j]), "=s"(carry[j])
+                             : "v"(static_cast<u32>(dlt[j])), "s"(static_cast<u32>(ws[j] >> 32)), "v"(A[j]));
+            else
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4"
+                             : "=v"(B[j]), "=s"(carry[j])
+                             : "v"(static_cast<u32>(dlt[j])), "v"(static_cast<u32>(ws[j] >> 32)), "v"(A[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(cb[j]) : "s"(carry[j]));
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mul64v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(w[j]), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            q[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j] >> 32),
+                              static_cast<u64>(static_cast<u32>(B[j] >> 32)) | (static_cast<u64>(cb[j]) << 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mad64v<true>(static_cast<u32>(q[j]), n0, V[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j] >> 32), n0, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            y[j] = add_hi32(V[j], E[j]);
+    }
 } // namespace sealhip

@@ -884,62 +884,100 @@ namespace sealhip
         // ascending bits) and stores lazy values in [0, 2p). The top layer (gap N/2, with n^{-1} folded
         // in, ntt.cpp:393-402) needs both halves and is applied by ntt_inv_top_kernel, a pure streaming
         // pass (or, inside the pipelines, by the consumer kernel).
-        template <int T, int R, int W, bool UNIFORM>
-        __device__ __forceinline__ void h_layer_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 neg_p,
-                                                    u64 two_p)
+        // ---- inverse rounds as stage pipelines (mirror of RoundStage / RoundPipe; layers ascend W = 1, 2, 3, 4)
+        template <int T, int R, bool UNIFORM, int K>
+        struct RoundStageInv
         {
-            constexpr int gb = Arr<T, R>::slot_bit(W);
-            const int tb = (N + jb) >> (gb + 1);
-            constexpr int bit = 1 << W;
-#pragma unroll
-            for (int s = 0; s < 32; s++)
+            static constexpr int PER = 16 / kIL;
+            static constexpr int W = 1 + K / PER;
+            static constexpr int C = (K % PER) * kIL;
+            static constexpr int bit = 1 << W;
+            static constexpr int slot(int j)
             {
-                if (s & bit)
-                    continue;
-                u64x2 Wv;
-                if (UNIFORM)
-                    Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
-                else
-                    Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
-                const u64 u = x[s], v = x[s | bit];
-                u64 tt = u + v;
-                tt = tt >= two_p ? tt - two_p : tt; // BackwardLazy, ntt.cpp:265-272
-                x[s] = tt;
-                x[s | bit] = mulmod_lazy_hs<UNIFORM>(u - v + two_p, Wv.x, Wv.y, neg_p);
+                return (((C + j) >> W) << (W + 1)) | ((C + j) & (bit - 1));
             }
-        }
-
-        template <int T, int R, bool UNIFORM>
-        __device__ __forceinline__ void h_round_inv(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 neg_p,
-                                                    u64 two_p)
+            __device__ static __forceinline__ void load(u64 (&w)[kIL], u64 (&ws)[kIL], const u64 *__restrict__ tw, int jb,
+                                                        int N)
+            {
+                const int tb = (N + jb) >> (Arr<T, R>::slot_bit(W) + 1);
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    u64x2 Wv;
+                    if (UNIFORM)
+                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
+                    else
+                        Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                    w[j] = Wv.x;
+                    ws[j] = Wv.y;
+                }
+            }
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
+                                                       u64 neg_p)
+            {
+                u64 u[kIL], y[kIL];
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    u[j] = x[slot(j)];
+                    y[j] = x[slot(j) | bit];
+                }
+                butterflies_inv_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // BackwardLazy, ntt.cpp:265-272
+#pragma unroll
+                for (int j = 0; j < kIL; j++)
+                {
+                    x[slot(j)] = u[j];
+                    x[slot(j) | bit] = y[j];
+                }
+            }
+        };
+        template <int T, int R, bool UNIFORM, int K = 0>
+        struct RoundPipeInv
         {
-            h_layer_inv<T, R, 1, UNIFORM>(x, tw, jb, N, neg_p, two_p);
-            h_layer_inv<T, R, 2, UNIFORM>(x, tw, jb, N, neg_p, two_p);
-            h_layer_inv<T, R, 3, UNIFORM>(x, tw, jb, N, neg_p, two_p);
-            h_layer_inv<T, R, 4, UNIFORM>(x, tw, jb, N, neg_p, two_p);
-        }
+            static constexpr int NST = 4 * (16 / kIL);
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
+                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p)
+            {
+                u64 wn[kIL], wsn[kIL];
+                if constexpr (K + 1 < NST)
+                    RoundStageInv<T, R, UNIFORM, K + 1>::load(wn, wsn, tw, jb, N);
+                __builtin_amdgcn_sched_barrier(0);
+                RoundStageInv<T, R, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
+                if constexpr (K + 1 < NST)
+                    RoundPipeInv<T, R, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
+            }
+        };
 
-        // first phase of the inverse, one group at a time: load the 2^f consecutive coefficients that share the
-        // filler slot bits G and run their low layers (index bits 0 .. f-1, ascending)
+        // first phase of the inverse: the 2^f consecutive coefficients that share the filler slot bits G run their low
+        // layers (index bits 0 .. f-1, ascending); group twiddles in the order used: layer W = 0 (2^(f-1) entries),
+        // W = 1, ..., W = f-1 (1 entry). All coefficients are loaded before (one exposed latency), twiddles are
+        // requested one stage (FinalStage<T>::SG groups) ahead.
         template <int T, int G>
-        __device__ __forceinline__ void h_first_group_inv(u64 (&x)[32], const u64 *__restrict__ tw,
-                                                          const u64 *__restrict__ halfp, int jloc, int jb, int N,
-                                                          u64 neg_p, u64 two_p)
+        __device__ __forceinline__ void h_first_tw(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
         {
             constexpr int f = T - 12;
-#pragma unroll
-            for (int e = 0; e < (1 << f); e += 2)
-            {
-                const int s = (G << f) | e;
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jloc + Arr<T, 4>::slot_index(s));
-                x[s] = v.x;
-                x[s + 1] = v.y;
-            }
+            int base = 0;
 #pragma unroll
             for (int W = 0; W < f; W++)
             {
-                const int gb = Arr<T, 4>::slot_bit(W);
-                const int tb = (N + jb) >> (gb + 1);
+                const int tb = (N + jb) >> (Arr<T, 4>::slot_bit(W) + 1);
+#pragma unroll
+                for (int o = 0; o < (1 << (f - 1 - W)); o++)
+                {
+                    const int s = (G << f) | (o << (W + 1));
+                    tg[base + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                }
+                base += 1 << (f - 1 - W);
+            }
+        }
+        template <int T, int G>
+        __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
+        {
+            constexpr int f = T - 12;
+            int base = 0;
+#pragma unroll
+            for (int W = 0; W < f; W++)
+            {
                 const int bit = 1 << W;
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
@@ -947,34 +985,49 @@ namespace sealhip
                     if (e & bit)
                         continue;
                     const int s = (G << f) | e;
-                    const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    const u64x2 Wv = tg[base + (e >> (W + 1))];
                     const u64 u = x[s], v = x[s | bit];
                     u64 tt = u + v;
                     tt = tt >= two_p ? tt - two_p : tt;
                     x[s] = tt;
                     x[s | bit] = mulmod_lazy_hs<false>(u - v + two_p, Wv.x, Wv.y, neg_p);
                 }
+                base += 1 << (f - 1 - W);
             }
         }
-
-        template <int T, int G, int NG>
-        struct FirstGroupsInv
+        template <int T, int ST, int I = 0>
+        struct FirstStage
         {
-            __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw,
-                                                       const u64 *__restrict__ halfp, int jloc, int jb, int N, u64 neg_p,
-                                                       u64 two_p)
+            __device__ static __forceinline__ void load(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
             {
-                h_first_group_inv<T, G>(x, tw, halfp, jloc, jb, N, neg_p, two_p);
-                if ((G & 1) == 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                FirstGroupsInv<T, G + 1, NG>::run(x, tw, halfp, jloc, jb, N, neg_p, two_p);
+                h_first_tw<T, ST * FinalStage<T>::SG + I>(tg + I * FinalStage<T>::NTW, tw, jb, N);
+                if constexpr (I + 1 < FinalStage<T>::SG)
+                    FirstStage<T, ST, I + 1>::load(tg, tw, jb, N);
+            }
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
+            {
+                h_first_group_regs<T, ST * FinalStage<T>::SG + I>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p);
+                if constexpr (I + 1 < FinalStage<T>::SG)
+                    FirstStage<T, ST, I + 1>::run(x, tg, neg_p, two_p);
             }
         };
-        template <int T, int NG>
-        struct FirstGroupsInv<T, NG, NG>
+        template <int T, int ST>
+        struct FirstPipe
         {
-            __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, const u64 *, int, int, int, u64, u64)
-            {}
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
+                                                       int N, u64 neg_p, u64 two_p)
+            {
+                u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
+                if constexpr (ST + 1 < FinalStage<T>::NS && FinalStage<T>::PIPE)
+                    FirstStage<T, ST + 1>::load(next, tw, jb, N);
+                __builtin_amdgcn_sched_barrier(0);
+                FirstStage<T, ST>::run(x, cur, neg_p, two_p);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST + 1 < FinalStage<T>::NS && !FinalStage<T>::PIPE) // f = 3: two stages do not fit
+                    FirstStage<T, ST + 1>::load(next, tw, jb, N);
+                if constexpr (ST + 1 < FinalStage<T>::NS)
+                    FirstPipe<T, ST + 1>::run(x, next, tw, jb, N, neg_p, two_p);
+            }
         };
 
         template <int LOGN>
@@ -1002,15 +1055,34 @@ namespace sealhip
             u64 x[32];
             const u64 neg_p = 0 - p;
             {
+                // every coefficient of the half row first (16 x 16 bytes per lane in flight at once), the twiddles of
+                // the first stage with them
                 const int jloc = Arr<T, 4>::tid_index(tid);
-                FirstGroupsInv<T, 0, 1 << (5 - (T - 12))>::run(x, tw, halfp, jloc, gbase + jloc, N, neg_p, two_p);
+                u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
+                FirstStage<T, 0>::load(tg0, tw, gbase + jloc, N);
+#pragma unroll
+                for (int s = 0; s < 32; s += 2)
+                {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jloc + Arr<T, 4>::slot_index(s));
+                    x[s] = v.x;
+                    x[s + 1] = v.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FirstPipe<T, 0>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
             }
+            const int jb3 = gbase + Arr<T, 3>::tid_index(tid), jb2 = gbase + Arr<T, 2>::tid_index(tid);
+            u64 w0[kIL], ws0[kIL];
+            RoundStageInv<T, 3, false, 0>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
+            __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 4, 3>(x, lds, tid);
-            h_round_inv<T, 3, false>(x, tw, gbase + Arr<T, 3>::tid_index(tid), N, neg_p, two_p);
+            RoundPipeInv<T, 3, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
+            RoundStageInv<T, 2, false, 0>::load(w0, ws0, tw, jb2, N);
+            __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 3, 2>(x, lds, tid);
-            h_round_inv<T, 2, false>(x, tw, gbase + Arr<T, 2>::tid_index(tid), N, neg_p, two_p);
+            RoundPipeInv<T, 2, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
+            RoundStageInv<T, 1, true, 0>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, tid);
-            h_round_inv<T, 1, true>(x, tw, gbase, N, neg_p, two_p); // block-uniform twiddles -> scalar loads
+            RoundPipeInv<T, 1, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
             {
                 const int jb = Arr<T, 1>::tid_index(tid);
 #pragma unroll
