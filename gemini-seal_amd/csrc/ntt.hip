@@ -658,6 +658,10 @@ namespace sealhip
         }
 
         // load both halves of the row and apply the top layer (gap N/2, twiddle entry 1) on the fly
+#ifndef SEALHIP_NTT_LOAD_BATCH
+#define SEALHIP_NTT_LOAD_BATCH 4
+#endif
+        constexpr int kLoadBatch = SEALHIP_NTT_LOAD_BATCH; // (lo, hi) 16-byte pairs per lane in flight during the load phase
         template <int T, bool STRICT, int HALF>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
                                                    const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p,
@@ -666,13 +670,13 @@ namespace sealhip
             const int jb = Arr<T, 1>::tid_index(tid);
             const u64x2 W1 = ((tw_const_t)tw)[1];
 #pragma unroll
-            for (int batch = 0; batch < 4; batch++)
+            for (int batch = 0; batch < 16 / kLoadBatch; batch++)
             {
-                ulonglong2 lo[4], hi[4];
+                ulonglong2 lo[kLoadBatch], hi[kLoadBatch];
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < kLoadBatch; i++)
                 {
-                    const int s = (batch * 4 + i) * 2;
+                    const int s = (batch * kLoadBatch + i) * 2;
                     const int idx = jb + Arr<T, 1>::slot_index(s);
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
@@ -681,7 +685,7 @@ namespace sealhip
                 {
                     const u64 p = 0 - neg_p;
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int i = 0; i < kLoadBatch; i++)
                     {
                         lo[i].x = barrett_reduce_63(lo[i].x, p, cr1);
                         lo[i].y = barrett_reduce_63(lo[i].y, p, cr1);
@@ -690,20 +694,29 @@ namespace sealhip
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < kLoadBatch; i += 2)
                 {
-                    const int s = (batch * 4 + i) * 2;
-                    u64 u0 = lo[i].x, u1 = lo[i].y;
+                    // four butterflies in lock step (program-ordered asm: the products stay inside their batch instead
+                    // of being sunk below the loads of the later batches, which used to spill loaded values)
+                    const int s = (batch * kLoadBatch + i) * 2;
+                    u64 u[4] = {lo[i].x, lo[i].y, lo[i + 1].x, lo[i + 1].y};
+                    u64 y[4] = {hi[i].x, hi[i].y, hi[i + 1].x, hi[i + 1].y};
+                    const u64 w[4] = {W1.x, W1.x, W1.x, W1.x}, ws[4] = {W1.y, W1.y, W1.y, W1.y};
                     if (STRICT)
                     {
-                        u0 = u0 >= two_p ? u0 - two_p : u0;
-                        u1 = u1 >= two_p ? u1 - two_p : u1;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
                     }
-                    const u64 v0 = mulmod_lazy(hi[i].x, W1.x, W1.y, 0 - neg_p);
-                    const u64 v1 = mulmod_lazy(hi[i].y, W1.x, W1.y, 0 - neg_p);
-                    x[s] = HALF ? u0 - v0 + two_p : u0 + v0;
-                    x[s + 1] = HALF ? u1 - v1 + two_p : u1 + v1;
+                    butterflies_fwd_hs<true, 4>(u, y, w, ws, neg_p, two_p);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        x[s + j] = HALF ? y[j] : u[j];
                 }
+                // keep the next batch's loads from being hoisted over this batch's products: that costs registers
+                // (spilled loaded values came back as HBM write traffic) and buys nothing (the load phase is bound by
+                // the CU's load path, not by latency: tools/ntt_phases.sh)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -741,6 +754,15 @@ namespace sealhip
     {                \
     } while (0)
 #endif
+
+        // An opaque copy of the thread index. Everything a phase derives from it (coefficient indices, LDS addresses,
+        // twiddle indices) is then computed where the phase starts instead of at the top of the kernel, where it
+        // would sit in registers -- or in scratch, whose write-back showed up as +28 % HBM write traffic -- until used.
+        __device__ __forceinline__ int fresh(int v)
+        {
+            asm volatile("" : "+v"(v));
+            return v;
+        }
 
         template <int LOGN, bool STRICT>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
@@ -796,9 +818,9 @@ namespace sealhip
                     x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
             }
             else if (half)
-                h_load_top<T, STRICT, 1>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
+                h_load_top<T, STRICT, 1>(x, srcp, tw, fresh(tid), two_p, neg_p, reduce, P.cr1);
             else
-                h_load_top<T, STRICT, 0>(x, srcp, tw, tid, two_p, neg_p, reduce, P.cr1);
+                h_load_top<T, STRICT, 0>(x, srcp, tw, fresh(tid), two_p, neg_p, reduce, P.cr1);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -813,22 +835,23 @@ namespace sealhip
             RoundStage<T, 1, STRICT, true, 0>::load(w0, ws0, tw, gbase, N);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
-            const int jb2 = gbase + Arr<T, 2>::tid_index(tid), jb3 = gbase + Arr<T, 3>::tid_index(tid);
+            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
             RoundStage<T, 2, STRICT, false, 0>::load(w0, ws0, tw, jb2, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 1, 2>(x, lds, tid);
+                h_exchange<T, 1, 2>(x, lds, fresh(tid));
             if (tid == 0 && tickets)
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
+            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
             RoundStage<T, 3, STRICT, false, 0>::load(w0, ws0, tw, jb3, N);
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 2, 3>(x, lds, tid);
+                h_exchange<T, 2, 3>(x, lds, fresh(tid));
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
-            const int jb4 = gbase + Arr<T, 4>::tid_index(tid);
+            const int jb4 = gbase + Arr<T, 4>::tid_index(fresh(tid));
             u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
             if constexpr (FinalStage<T>::PIPE)
             {
@@ -836,7 +859,7 @@ namespace sealhip
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 3, 4>(x, lds, tid);
+                h_exchange<T, 3, 4>(x, lds, fresh(tid));
             NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
