@@ -300,21 +300,26 @@ namespace sealhip
         // layer of every row read here is applied on load (kNttDeferTop: no ntt_inv_top pass over the 2*(k+nsp) rows).
         // Every value that leaves this kernel is a canonical residue of an exact modular expression, so the
         // representatives chosen for the intermediates do not matter.
+        // both coefficients c and c + N/2 of one row: with DEFER the top inverse-NTT layer (BackwardLazyLast,
+        // ntt.cpp:274-281) is applied to the pair, else the two words are used as they are
         template <bool DEFER>
-        __device__ __forceinline__ u64 row_value(const u64 *__restrict__ row, std::size_t c, std::size_t half,
-                                                 const PrimeDev &P)
+        __device__ __forceinline__ void row_pair(const u64 *__restrict__ row, std::size_t c_lo, std::size_t half,
+                                                 const PrimeDev &P, u64 &x_lo, u64 &x_hi)
         {
-            if (!DEFER)
-                return row[c];
-            const std::size_t c_lo = c & (half - 1);
             const u64 u = row[c_lo], v = row[c_lo + half];
-            if (c >= half)
-                return mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p); // BackwardLazyLast, ntt.cpp:274-281
+            if (!DEFER)
+            {
+                x_lo = u;
+                x_hi = v;
+                return;
+            }
             u64 tt = u + v;
             tt = tt >= P.two_p ? tt - P.two_p : tt;
-            return mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, P.p);
+            x_lo = mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, P.p);
+            x_hi = mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p);
         }
 
+        // One lane per (polynomial, prime q, coefficient pair c / c + N/2): every input word is read exactly once.
         template <bool DEFER>
         __global__ __launch_bounds__(kThreads) void ks_moddown_bfv_kernel(const KsDev *__restrict__ d,
                                                                           const PrimeDev *__restrict__ primes,
@@ -326,8 +331,8 @@ namespace sealhip
             const std::size_t N = static_cast<std::size_t>(1) << logn, half = N >> 1;
             const int k = d->k, nsp = d->nsp;
             const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
-            const std::size_t c = i & (N - 1);
-            const std::size_t rr = i >> logn;
+            const std::size_t c = i & (half - 1);
+            const std::size_t rr = i >> (logn - 1);
             const int q = static_cast<int>(rr % k);
             const std::size_t poly = rr / k;
             if (poly >= npolys)
@@ -335,33 +340,47 @@ namespace sealhip
             const PrimeDev &Q = primes[d->row_prime[q]];
             const u64 *pp = prod + poly * prod_stride;
             // steps 1-2 for this lane's prime (multi_special_primes.cpp:253-282)
-            u64 temp;
+            u64 temp[2];
             if (nsp == 1)
             {
                 const PrimeDev &S = primes[d->row_prime[k]];
-                const u64 sv = row_value<DEFER>(pp + static_cast<std::size_t>(k) * N, c, half, S);
-                const u64 v = neg_mod(barrett_reduce_63(sv, S.p, S.cr1), S.p); // :270-273
-                temp = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
+                u64 sv[2];
+                row_pair<DEFER>(pp + static_cast<std::size_t>(k) * N, c, half, S, sv[0], sv[1]);
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    const u64 v = neg_mod(barrett_reduce_63(sv[h], S.p, S.cr1), S.p); // :270-273
+                    temp[h] = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
+                }
             }
             else
             {
-                u64 lo = 0, hi = 0;
+                u64 lo[2] = {0, 0}, hi[2] = {0, 0};
                 for (int j = 0; j < nsp; j++)
                 {
                     const PrimeDev &S = primes[d->row_prime[k + j]];
-                    u64 sv = row_value<DEFER>(pp + static_cast<std::size_t>(k + j) * N, c, half, S);
-                    if (DEFER)
-                        sv = sv >= S.p ? sv - S.p : sv; // the step-by-step path feeds the lazy value; same residue
-                    const u64 y = mulmod_shoup(sv, d->inv_hat[j], d->inv_hat_shoup[j], S.p); // :262-267
-                    mac128(lo, hi, y, d->neg_hat[q * nsp + j]);
+                    u64 sv[2];
+                    row_pair<DEFER>(pp + static_cast<std::size_t>(k + j) * N, c, half, S, sv[0], sv[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                    {
+                        const u64 y = mulmod_shoup(sv[h], d->inv_hat[j], d->inv_hat_shoup[j], S.p); // :262-267
+                        mac128(lo[h], hi[h], y, d->neg_hat[q * nsp + j]);
+                    }
                 }
-                temp = barrett_reduce_128(lo, hi, Q.p, Q.cr0, Q.cr1);
+                temp[0] = barrett_reduce_128(lo[0], hi[0], Q.p, Q.cr0, Q.cr1);
+                temp[1] = barrett_reduce_128(lo[1], hi[1], Q.p, Q.cr0, Q.cr1);
             }
             // step 4 (:291-302) and the add into the ciphertext
-            const u64 pv = row_value<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q);
-            const u64 v = mulmod_shoup(pv + temp, d->invP[q], d->invP_shoup[q], Q.p);
+            u64 pv[2];
+            row_pair<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q, pv[0], pv[1]);
             u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
-            *pc = add_mod(v, *pc, Q.p);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                const u64 v = mulmod_shoup(pv[h] + temp[h], d->invP[q], d->invP_shoup[q], Q.p);
+                pc[h * half] = add_mod(v, pc[h * half], Q.p);
+            }
         }
 
         inline unsigned blocks_for(std::size_t lanes)
@@ -444,7 +463,7 @@ namespace sealhip
     {
         if (!npolys)
             return hipSuccess;
-        const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
+        const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << (e.logn - 1); // one lane per coefficient pair
         ProfScope prof(e, "ks_moddown_bfv", 0);
         if (top_deferred)
             ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, prod, prod_stride, ct,
