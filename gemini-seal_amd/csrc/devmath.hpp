@@ -40,14 +40,6 @@ namespace sealhip
         return x * y - q * p;
     }
 
-    // The same value computed as lo64(x*y + q*(2^64 - p)): the 64-bit subtract (v_sub_co / s_nop / v_subb on
-    // gfx950) becomes one v_lshl_add_u64. Identical bits: all arithmetic is mod 2^64. neg_p = 2^64 - p.
-    __device__ __forceinline__ u64 mulmod_lazy_np(u64 x, u64 y, u64 yshoup, u64 neg_p)
-    {
-        const u64 q = mulhi(x, yshoup);
-        return x * y + q * neg_p;
-    }
-
     // canonical Shoup product (multi_special_primes.cpp:13-19)
     __device__ __forceinline__ u64 mulmod_shoup(u64 x, u64 y, u64 yshoup, u64 p)
     {

@@ -345,47 +345,6 @@ namespace sealhip
 #endif
         constexpr int kIL = SEALHIP_NTT_IL; // butterflies advanced in lock step (devmath.hpp: butterflies_fwd_hs)
 
-        template <int T, int R, int W, bool STRICT, bool UNIFORM>
-        __device__ __forceinline__ void h_layer(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
-                                                u64 two_p, u64 neg_p, u64 rdp)
-        {
-            constexpr int gb = Arr<T, R>::slot_bit(W);
-            const int tb = (N + jb) >> (gb + 1);
-            constexpr int bit = 1 << W;
-#pragma unroll
-            for (int c = 0; c < 16; c += kIL)
-            {
-                u64 u[kIL], y[kIL], w[kIL], ws[kIL];
-#pragma unroll
-                for (int j = 0; j < kIL; j++)
-                {
-                    // the (c+j)-th slot with bit W clear
-                    const int s = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
-                    u64x2 Wv;
-                    if (UNIFORM)
-                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(s, W)];
-                    else
-                        Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(s, W)];
-                    w[j] = Wv.x;
-                    ws[j] = Wv.y;
-                    u[j] = x[s];
-                    y[j] = x[s | bit];
-                    if (STRICT)
-                        u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
-                    else if (gb == 0)
-                        u[j] = barrett_lazy_hs(u[j], rdp, neg_p); // ForwardLazyLast, ntt.cpp:254-261
-                }
-                butterflies_fwd_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
-#pragma unroll
-                for (int j = 0; j < kIL; j++)
-                {
-                    const int s = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
-                    x[s] = u[j];
-                    x[s | bit] = y[j];
-                }
-            }
-        }
-
         // final round, one group at a time: the low f index bits of the 2^f registers that share the filler
         // slot bits G are finished (layers f-1 .. 0) and stored right away, which bounds the live twiddles
         // Measurement-only hooks (compiled with -DSEALHIP_NTT_EXPERIMENT, driven by SEALHIP_NTT_SKIP): drop the
@@ -647,17 +606,6 @@ namespace sealhip
             }
         };
 
-        template <int T, int R, bool STRICT, bool UNIFORM>
-        __device__ __forceinline__ void h_round(u64 (&x)[32], const u64 *__restrict__ tw, int jb, int N, u64 p,
-                                                u64 two_p, u64 neg_p, u64 rdp)
-        {
-            h_layer<T, R, 4, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
-            h_layer<T, R, 3, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
-            h_layer<T, R, 2, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
-            h_layer<T, R, 1, STRICT, UNIFORM>(x, tw, jb, N, p, two_p, neg_p, rdp);
-        }
-
-        // load both halves of the row and apply the top layer (gap N/2, twiddle entry 1) on the fly
 #ifndef SEALHIP_NTT_LOAD_BATCH
 #define SEALHIP_NTT_LOAD_BATCH 4
 #endif
