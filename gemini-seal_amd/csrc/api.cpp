@@ -1031,4 +1031,38 @@ long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t 
     });
 }
 
+/* ------------------------------------------------------------------ decrypt-side arithmetic */
+
+long sealhip_decryptor_dot_product_ct_sk(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                                         const uint64_t *sk_powers_ntt, int32_t is_ntt_form, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    if (size > 1)
+        REQUIRE_PTR(sk_powers_ntt);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        op_dot_product_ct_sk(e, static_cast<int>(k), reinterpret_cast<const u64 *>(ct), static_cast<int>(size), count,
+                             reinterpret_cast<const u64 *>(sk_powers_ntt), is_ntt_form != 0, reinterpret_cast<u64 *>(out));
+    });
+}
+
+long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(in);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        LevelTools &lt = bfv_level(e, k);
+        check_launch(launch_decrypt_scale_and_round(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in),
+                                                    reinterpret_cast<u64 *>(out), count),
+                     "decrypt_scale_and_round");
+    });
+}
+
 } // extern "C"

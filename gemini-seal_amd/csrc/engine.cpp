@@ -336,6 +336,33 @@ namespace sealhip
             rd.lift_L1m = upload<u64>(*this, lt.owned, L1m.data(), L1m.size());
             rd.floor_G2m = upload<u64>(*this, lt.owned, G2m.data(), G2m.size());
             rd.B_to_qm = upload<u64>(*this, lt.owned, BQm.data(), BQm.size());
+            // decrypt_scale_and_round constants (rns.cpp:690-716): base q -> {t, gamma}
+            {
+                HostBaseConv tg;
+                tg.build(hr.q, std::vector<u64>{ t, hr.gamma });
+                for (int i = 0; i < k; i++)
+                {
+                    const u64 qi = hr.q[i];
+                    rd.dsr_scale[i] = mulmod(mulmod(t % qi, hr.gamma % qi, qi), tg.inv_punct[i], qi);
+                    rd.dsr_scale_s[i] = shoup(rd.dsr_scale[i], qi);
+                    rd.dsr_to_t[i] = tg.matrix[i];
+                    rd.dsr_to_g[i] = tg.matrix[static_cast<std::size_t>(k) + i];
+                }
+                u64 pq_t = 1 % t, pq_g = 1;
+                for (int i = 0; i < k; i++)
+                {
+                    pq_t = mulmod(pq_t, hr.q[i] % t, t);
+                    pq_g = mulmod(pq_g, hr.q[i] % hr.gamma, hr.gamma);
+                }
+                u64 it = 0, ig = 0, igt = 0;
+                if (!invmod(pq_t, t, it) || !invmod(pq_g, hr.gamma, ig) || !invmod(hr.gamma % t, t, igt))
+                    throw std::logic_error("invalid rns bases"); // rns.cpp:693-713
+                rd.dsr_neg_inv_q_t = it ? t - it : 0;
+                rd.dsr_neg_inv_q_g = ig ? hr.gamma - ig : 0;
+                rd.dsr_inv_gamma_t = igt;
+                rd.dsr_gamma = hr.gamma;
+                rd.gamma_prime = static_cast<unsigned short>(n_key + 1); // aux primes: m_sk, gamma, B...
+            }
             // REDC lands below 2p iff (sum of the bounds of the variable factors) <= 2^64:
             //   lift rows:   k terms t_i < q_i plus temp < b_j;  floor Bsk rows: in < b_j plus k terms < q_i;
             //   conv_sk: B terms < b;  out rows: B terms tb_j < b_j plus alpha-term < m_sk

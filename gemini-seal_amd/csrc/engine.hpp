@@ -96,6 +96,11 @@ namespace sealhip
         u64 B_to_mskm[kMaxModuli + 1];
         u64 inv_prod_B_mod_msk_s;
         u64 pBm[kMaxModuli], nBm[kMaxModuli]; // prod_B_mod_q * 2^64, (q - prod_B_mod_q) * 2^64  (mod q_i)
+        // decrypt_scale_and_round (rns.cpp:1070-1126), constants folded where the results are canonical anyway:
+        //   y_i = in_i * dsr_scale[i] mod q_i  (|gamma t|_qi times (q^_i)^{-1});  {t, gamma} part = sum_i y_i * dsr_to_t/g[i]
+        u64 dsr_scale[kMaxModuli], dsr_scale_s[kMaxModuli], dsr_to_t[kMaxModuli], dsr_to_g[kMaxModuli];
+        u64 dsr_neg_inv_q_t, dsr_neg_inv_q_g, dsr_inv_gamma_t, dsr_gamma;
+        unsigned short gamma_prime; // PrimeDev id of gamma
         int redc_small;                        // every REDC of the fused kernels provably lands below 2p
         unsigned short q_prime[kMaxModuli];       // prime ids of q rows
         unsigned short bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
@@ -329,6 +334,13 @@ namespace sealhip
     void op_apply_galois(Engine &e, int k, u64 *ct, std::size_t count, std::uint32_t elt, const KSwitchKey &key);
     void op_multiply_plain(Engine &e, int k, u64 *ct, int size, std::size_t count, const u64 *plain,
                            std::size_t plain_stride);
+    // Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265) and RNSTool::decrypt_scale_and_round
+    void op_dot_product_ct_sk(Engine &e, int k, const u64 *ct, int size, std::size_t count, const u64 *sk_powers,
+                              bool is_ntt_form, u64 *out);
+    hipError_t launch_dot_sk(const Engine &e, const u64 *ct, int size, std::size_t ct_item_stride, const u64 *sk_powers,
+                             std::size_t sk_power_stride, u64 *out, std::size_t count, const RowMap &map, int add_c0);
+    hipError_t launch_decrypt_scale_and_round(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, u64 *out,
+                                              std::size_t count);
 
     std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
                                         bool strict, int device);

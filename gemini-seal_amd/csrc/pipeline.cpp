@@ -450,4 +450,35 @@ namespace sealhip
               "dyadic(plain)");
         check(launch_ntt(e, ct, count * size * k, map_q, true, kNttCanonical), "intt(ct)");
     }
+    // Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265): out[count][k][N] = c_0 + sum_{i>=1} c_i * s^i in the
+    // form of the ciphertext. sk_powers = (size-1) polynomials s, s^2, ... in NTT form with key-level row stride.
+    void op_dot_product_ct_sk(Engine &e, int k, const u64 *ct, int size, std::size_t count, const u64 *sk_powers,
+                              bool is_ntt_form, u64 *out)
+    {
+        const RowMap map_q = e.level_host(k).map_q;
+        const std::size_t N = e.n, poly = static_cast<std::size_t>(k) * N;
+        const std::size_t sk_stride = static_cast<std::size_t>(e.n_key) * N;
+        const std::size_t item = static_cast<std::size_t>(size) * poly;
+        if (is_ntt_form || size == 1)
+        {
+            check(launch_dot_sk(e, ct, size, item, sk_powers, sk_stride, out, count, map_q, 1), "dot_sk");
+            return;
+        }
+        // coefficient form: copies of c_1.. go to (lazy) NTT form (:241-244), the sum comes back canonical (:258-262),
+        // then + c_0 (:265)
+        const std::size_t tail = static_cast<std::size_t>(size - 1) * poly;
+        const std::size_t chunk = plan_chunk(e, count, tail * sizeof(u64), 1);
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *copy = e.ws_alloc(tail * m);
+            check(launch_copy_rows(e, ct + off * item + poly, item, copy, tail, m, (size - 1) * k), "copy(c1..)");
+            check(launch_ntt(e, copy, m * (size - 1) * k, map_q, false, 0), "ntt(c1..)");
+            // the kernel indexes polynomials 1.. of an item: hand it a base one polynomial before the copies
+            check(launch_dot_sk(e, copy - poly, size, tail, sk_powers, sk_stride, out + off * poly, m, map_q, 0), "dot_sk");
+            check(launch_ntt(e, out + off * poly, m * k, map_q, true, kNttCanonical), "intt(dot)");
+            check(launch_dot_sk(e, ct + off * item, 1, item, sk_powers, sk_stride, out + off * poly, m, map_q, 2), "add c0");
+        }
+    }
 } // namespace sealhip

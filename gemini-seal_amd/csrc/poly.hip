@@ -270,6 +270,45 @@ namespace sealhip
                 out[i] = v + (v >= threshold ? p - t : 0);
             }
         }
+
+        // Decryptor::dot_product_ct_sk_array (decryptor.cpp:246-256, :265): out = sum_{i>=1} ct_i (.) s^i, each term
+        // reduced (dyadic_product_coeffmod) and accumulated with add_poly_coeffmod; with add_c0 also + ct_0 (NTT-form
+        // ciphertexts; coefficient-form ones add c_0 after the inverse NTT). ct polys 1.. may hold lazy NTT values.
+        __global__ __launch_bounds__(kThreads) void dot_sk_kernel(const u64 *__restrict__ ct, int size,
+                                                                  std::size_t ct_item_stride,
+                                                                  const u64 *__restrict__ sk, std::size_t sk_power_stride,
+                                                                  u64 *out,
+                                                                  const PrimeDev *__restrict__ primes, RowMap map, int logn,
+                                                                  std::size_t pairs_per_poly, std::size_t count, int add_c0)
+        {
+            const std::size_t total = pairs_per_poly * count;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t poly_words = pairs_per_poly * 2;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total; i += stride)
+            {
+                const std::size_t item = i / pairs_per_poly;
+                const std::size_t off = 2 * (i - item * pairs_per_poly);
+                const PrimeDev &P = primes[map.prime[off >> logn]];
+                ulonglong2 acc;
+                acc.x = acc.y = 0;
+                if (add_c0 == 2)
+                    acc = *reinterpret_cast<const ulonglong2 *>(out + item * poly_words + off);
+                for (int j = 1; j < size; j++)
+                {
+                    const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(ct + item * ct_item_stride + j * poly_words + off);
+                    const ulonglong2 s = *reinterpret_cast<const ulonglong2 *>(sk + (j - 1) * sk_power_stride + off);
+                    acc.x = add_mod(acc.x, mul_mod(c.x, s.x, P.p, P.cr0, P.cr1), P.p);
+                    acc.y = add_mod(acc.y, mul_mod(c.y, s.y, P.p, P.cr0, P.cr1), P.p);
+                }
+                if (add_c0)
+                {
+                    const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(ct + item * ct_item_stride + off);
+                    acc.x = add_mod(acc.x, c0.x, P.p);
+                    acc.y = add_mod(acc.y, c0.y, P.p);
+                }
+                *reinterpret_cast<ulonglong2 *>(out + item * poly_words + off) = acc;
+            }
+        }
     } // namespace
 
     hipError_t launch_poly_op(const Engine &e, PolyOp op, const u64 *a, const u64 *b, u64 scalar, u64 *r,
@@ -390,6 +429,18 @@ namespace sealhip
         ProfScope prof(e, "plain_lift", 0);
         plain_lift_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(plain, plain_stride, out, e.d_primes, map, e.logn, t,
                                                                     (t + 1) >> 1, nplains);
+        return hipGetLastError();
+    }
+    hipError_t launch_dot_sk(const Engine &e, const u64 *ct, int size, std::size_t ct_item_stride, const u64 *sk_powers,
+                             std::size_t sk_power_stride, u64 *out, std::size_t count, const RowMap &map, int add_c0)
+    {
+        const std::size_t pairs = (static_cast<std::size_t>(map.rows) << e.logn) / 2;
+        if (pairs * count == 0)
+            return hipSuccess;
+        ProfScope prof(e, "dot_sk", 0);
+        dot_sk_kernel<<<grid_for(pairs * count), kThreads, 0, e.stream>>>(ct, size, ct_item_stride, sk_powers, sk_power_stride,
+                                                                         out, e.d_primes, map, e.logn, pairs, count,
+                                                                         add_c0);
         return hipGetLastError();
     }
 } // namespace sealhip

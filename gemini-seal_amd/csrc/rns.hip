@@ -628,6 +628,52 @@ namespace sealhip
         {
             return static_cast<unsigned>(((count << logn) + kThreads - 1) / kThreads);
         }
+
+        // RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126): k rows -> one row of coefficients mod t. The two scalar
+        // multiplications before the base conversion are folded into one constant; everything else as written there.
+        __global__ __launch_bounds__(kThreads) void decrypt_scale_and_round_kernel(const RnsDev *__restrict__ d,
+                                                                                   const PrimeDev *__restrict__ primes,
+                                                                                   const u64 *__restrict__ in,
+                                                                                   u64 *__restrict__ out,
+                                                                                   std::size_t count, int logn)
+        {
+            Cols cc;
+            if (!column(count, logn, cc))
+                return;
+            const int k = d->k;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const u64 *pin = in + cc.item * (static_cast<std::size_t>(k) * N) + cc.c;
+            const u64 t = d->t, gamma = d->dsr_gamma;
+            const PrimeDev &G = primes[d->gamma_prime];
+            u64 lt = 0, ht = 0, lg = 0, hg = 0;
+            for (int i = 0; i < k; i++)
+            {
+                const u64 qi = primes[d->q_prime[i]].p;
+                const u64 y = mulmod_shoup(pin[i * N], d->dsr_scale[i], d->dsr_scale_s[i], qi); // :1076-1082 + :476-485
+                mac128(lt, ht, y, d->dsr_to_t[i]);                                             // :487-495
+                mac128(lg, hg, y, d->dsr_to_g[i]);
+            }
+            // reductions mod t (any modulus below 2^61: plain 128-bit remainder) and mod gamma (Barrett)
+            const unsigned __int128 st = (static_cast<unsigned __int128>(ht) << 64) | lt;
+            u64 vt = static_cast<u64>(st % t);
+            u64 vg = barrett_reduce_128(lg, hg, G.p, G.cr0, G.cr1);
+            vt = static_cast<u64>((static_cast<unsigned __int128>(vt) * d->dsr_neg_inv_q_t) % t); // :1091-1096
+            vg = mul_mod(vg, d->dsr_neg_inv_q_g, G.p, G.cr0, G.cr1);
+            u64 r;
+            if (vg > (gamma >> 1)) // :1107-1117
+            {
+                const u64 a = vt + (gamma - vg) % t;
+                r = a >= t ? a - t : a;
+            }
+            else
+            {
+                const u64 b = vg % t;
+                r = vt >= b ? vt - b : vt + t - b;
+            }
+            if (r) // :1120-1124
+                r = static_cast<u64>((static_cast<unsigned __int128>(r) * d->dsr_inv_gamma_t) % t);
+            out[cc.item * N + cc.c] = r;
+        }
     } // namespace
 
 #define SEALHIP_DISPATCH_K(kval, KERNEL, ...)                                             \
@@ -808,6 +854,17 @@ namespace sealhip
         ProfScope prof(e, "rescale_post", 0);
         rescale_post_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(
             d, e.d_primes, in, in_stride, temp, temp_stride, out, out_stride, count, e.logn);
+        return hipGetLastError();
+    }
+    hipError_t launch_decrypt_scale_and_round(const Engine &e, const RnsDev *d, const RnsDev &, const u64 *in, u64 *out,
+                                              std::size_t count)
+    {
+        if (!count)
+            return hipSuccess;
+        ProfScope prof(e, "decrypt_scale_and_round", 0);
+        const std::size_t lanes = count << e.logn;
+        decrypt_scale_and_round_kernel<<<static_cast<unsigned>((lanes + kThreads - 1) / kThreads), kThreads, 0, e.stream>>>(
+            d, e.d_primes, in, out, count, e.logn);
         return hipGetLastError();
     }
 } // namespace sealhip

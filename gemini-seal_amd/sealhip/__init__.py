@@ -108,6 +108,8 @@ SYMBOLS = {
     "sealhip_is_transparent": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_modulo_poly_coeffs_63": [_vp, _vp, _sz, _u32, _u32, _vp],
     "sealhip_evaluator_rotate_vector": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
+    "sealhip_decryptor_dot_product_ct_sk": [_vp, _u32, _vp, _u32, _sz, _vp, _i32, _vp],
+    "sealhip_decrypt_scale_and_round": [_vp, _u32, _vp, _sz, _vp],
 }
 
 
@@ -322,6 +324,15 @@ class Context:
         flags = np.zeros(count, dtype=np.uint8)
         _check(lib().sealhip_is_transparent(self.handle, k, _ptr(ct), size, count, flags.ctypes.data))
         return flags.astype(bool)
+
+    def dot_product_ct_sk(self, ct, size, k, count, sk_powers_ntt, is_ntt_form, out):
+        """Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265)"""
+        _check(lib().sealhip_decryptor_dot_product_ct_sk(self.handle, k, _ptr(ct), size, count, _ptr(sk_powers_ntt),
+                                                         1 if is_ntt_form else 0, _ptr(out)))
+
+    def decrypt_scale_and_round(self, k, poly, count, out):
+        """RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126)"""
+        _check(lib().sealhip_decrypt_scale_and_round(self.handle, k, _ptr(poly), count, _ptr(out)))
 
     def negate_poly_coeffmod(self, a, count, k, result, base=BASE_Q):
         _check(lib().sealhip_negate_poly_coeffmod(self.handle, _ptr(a), count, k, base, _ptr(result)))

@@ -229,6 +229,15 @@ long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t 
                                      const uint32_t *galois_elts, const sealhip_kswitch_key *const *galois_keys,
                                      uint32_t n_keys);
 
+/* ---------------------------------------------------------------- decrypt-side arithmetic */
+/* Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265): out[count][k][N] = c_0 + sum_{i>=1} c_i * s^i, in the form
+   of the ciphertext (is_ntt_form). sk_powers_ntt = the Decryptor's secret_key_array_: (size-1) polynomials s, s^2, ...
+   in NTT form, each with the key level's row stride (n_key_moduli x N); device memory. */
+long sealhip_decryptor_dot_product_ct_sk(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                                         const uint64_t *sk_powers_ntt, int32_t is_ntt_form, uint64_t *out);
+/* RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126), BFV: in[count][k][N] -> out[count][N] coefficients mod t */
+long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

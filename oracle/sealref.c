@@ -1557,6 +1557,238 @@ int ref_is_transparent(const ref_context *c, size_t k, const uint64_t *ct, size_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * encrypt / key generation / decrypt restated for the semantic end-to-end check
+ * ---------------------------------------------------------------------------------------- */
+void ref_sample_ternary(int8_t *s, size_t n, uint64_t *state)
+{
+    for (size_t i = 0; i < n; i++)
+        s[i] = (int8_t)(ref_splitmix64(state) % 3) - 1;
+}
+
+void ref_sample_noise(int8_t *e, size_t n, uint64_t *state)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        const uint64_t r = ref_splitmix64(state);
+        e[i] = (int8_t)(__builtin_popcountll(r & 0x1FFFFFull) - __builtin_popcountll((r >> 21) & 0x1FFFFFull)); /* var 10.5 */
+    }
+}
+
+void ref_small_poly_to_rns(const ref_context *c, const int8_t *s, size_t rows, int to_ntt, uint64_t *out)
+{
+    const size_t n = c->n;
+    for (size_t r = 0; r < rows; r++)
+    {
+        const uint64_t p = c->key_mod[r].value;
+        for (size_t i = 0; i < n; i++)
+            out[r * n + i] = s[i] >= 0 ? (uint64_t)s[i] : p - (uint64_t)(-s[i]);
+        if (to_ntt)
+            ref_ntt_forward(out + r * n, &c->key_tables[r], 0);
+    }
+}
+
+void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
+                                uint64_t *state, uint64_t *ct)
+{
+    const size_t n = c->n;
+    uint64_t *c0 = ct, *c1 = ct + rows * n;
+    int8_t *e = (int8_t *)malloc(n);
+    uint64_t *noise = (uint64_t *)malloc(sizeof(uint64_t) * rows * n);
+    for (size_t r = 0; r < rows; r++) /* rlwe.cpp:245-249: a sampled directly in NTT form */
+        for (size_t i = 0; i < n; i++)
+            c1[r * n + i] = ref_splitmix64(state) % c->key_mod[r].value;
+    ref_sample_noise(e, n, state);
+    ref_small_poly_to_rns(c, e, rows, 0, noise);
+    for (size_t r = 0; r < rows; r++) /* rlwe.cpp:266-284 */
+    {
+        const ref_modulus *m = &c->key_mod[r];
+        ref_dyadic_product_coeffmod(sk_ntt + r * n, c1 + r * n, n, m, c0 + r * n);
+        if (is_ntt_form)
+            ref_ntt_forward(noise + r * n, &c->key_tables[r], 0);
+        else
+            ref_ntt_inverse(c0 + r * n, &c->key_tables[r]);
+        ref_add_poly_coeffmod(noise + r * n, c0 + r * n, n, m, c0 + r * n);
+        ref_negate_poly_coeffmod(c0 + r * n, n, m, c0 + r * n);
+        if (!is_ntt_form) /* :286-293 */
+            ref_ntt_inverse(c1 + r * n, &c->key_tables[r]);
+    }
+    free(e);
+    free(noise);
+}
+
+/* q = prod of the first k key primes as little-endian 64-bit limbs */
+static void big_product(const ref_context *c, size_t k, uint64_t *limbs /* [k] */)
+{
+    memset(limbs, 0, sizeof(uint64_t) * k);
+    limbs[0] = 1;
+    for (size_t i = 0; i < k; i++)
+    {
+        unsigned __int128 carry = 0;
+        for (size_t l = 0; l < k; l++)
+        {
+            const unsigned __int128 v = (unsigned __int128)limbs[l] * c->key_mod[i].value + carry;
+            limbs[l] = (uint64_t)v;
+            carry = v >> 64;
+        }
+    }
+}
+/* quotient (k limbs) and remainder of a k-limb number by a word */
+static uint64_t big_divide_word(const uint64_t *num, size_t k, uint64_t d, uint64_t *quot)
+{
+    unsigned __int128 rem = 0;
+    for (size_t l = k; l-- > 0;)
+    {
+        const unsigned __int128 cur = (rem << 64) | num[l];
+        quot[l] = (uint64_t)(cur / d);
+        rem = cur % d;
+    }
+    return (uint64_t)rem;
+}
+static uint64_t big_mod_word(const uint64_t *num, size_t k, uint64_t d)
+{
+    unsigned __int128 rem = 0;
+    for (size_t l = k; l-- > 0;)
+        rem = ((rem << 64) | num[l]) % d;
+    return (uint64_t)rem;
+}
+
+void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
+                               uint64_t *state, uint64_t *ct)
+{
+    const size_t n = c->n;
+    const uint64_t t = c->t;
+    ref_encrypt_zero_symmetric(c, k, sk_ntt, 0, state, ct);
+    /* context.cpp:303-321: coeff_div_plain_modulus = floor(q / t) in RNS form, q mod t, (t + 1) / 2 */
+    uint64_t q[64], quot[64];
+    big_product(c, k, q);
+    const uint64_t q_mod_t = big_divide_word(q, k, t, quot);
+    const uint64_t threshold = (t + 1) >> 1;
+    for (size_t i = 0; i < n; i++) /* scalingvariant.cpp:31-51 */
+    {
+        const unsigned __int128 numerator = (unsigned __int128)plain[i] * q_mod_t + threshold;
+        const uint64_t fix = (uint64_t)(numerator / t);
+        for (size_t j = 0; j < k; j++)
+        {
+            const ref_modulus *m = &c->key_mod[j];
+            const uint64_t div_j = big_mod_word(quot, k, m->value);
+            const unsigned __int128 z = (unsigned __int128)div_j * plain[i] + fix; /* multiply_add_uint_mod */
+            const uint64_t scaled = ref_barrett_reduce_128((uint64_t)z, (uint64_t)(z >> 64), m);
+            const uint64_t sum = scaled + ct[j * n + i];
+            ct[j * n + i] = sum >= m->value ? sum - m->value : sum;
+        }
+    }
+}
+
+void ref_generate_kswitch_key(const ref_context *c, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
+                              uint64_t *state, uint64_t *key)
+{
+    const size_t n = c->n, n_key = c->n_key, n_ct = c->k_first, nsp = c->nsp;
+    const size_t digits = (n_ct + nsp - 1) / nsp;
+    uint64_t *temp = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (size_t j = 0; j < digits; j++)
+    {
+        uint64_t *dst = key + j * 2 * n_key * n;
+        ref_encrypt_zero_symmetric(c, n_key, sk_ntt, 1, state, dst); /* keygenerator.cpp:347 */
+        const size_t r0 = j * nsp, r1 = r0 + nsp < n_ct ? r0 + nsp : n_ct;
+        for (size_t r = r0; r < r1; r++) /* :351-362 */
+        {
+            const ref_modulus *m = &c->key_mod[r];
+            uint64_t factor = 1;
+            for (size_t s = 0; s < nsp; s++)
+                factor = ref_multiply_uint_mod(factor, c->key_mod[n_ct + s].value % m->value, m);
+            ref_multiply_poly_scalar_coeffmod(new_key_ntt + r * n, n, factor, m, temp);
+            ref_add_poly_coeffmod(dst + r * n, temp, n, m, dst + r * n);
+        }
+    }
+    free(temp);
+}
+
+void ref_dot_product_ct_sk(const ref_context *c, size_t k, const uint64_t *ct, size_t size, int is_ntt_form,
+                           const uint64_t *sk_powers, uint64_t *out)
+{
+    const size_t n = c->n, n_key = c->n_key;
+    uint64_t *copy = (uint64_t *)malloc(sizeof(uint64_t) * (size - 1) * k * n);
+    memcpy(copy, ct + k * n, sizeof(uint64_t) * (size - 1) * k * n); /* decryptor.cpp:237-238 */
+    memset(out, 0, sizeof(uint64_t) * k * n);
+    for (size_t i = 0; i + 1 < size; i++)
+        for (size_t r = 0; r < k; r++)
+        {
+            uint64_t *row = copy + (i * k + r) * n;
+            const ref_modulus *m = &c->key_mod[r];
+            if (!is_ntt_form) /* :241-244 */
+                ref_ntt_forward_lazy(row, &c->key_tables[r], c->mode == REF_MODE_STRICT);
+            ref_dyadic_product_coeffmod(row, sk_powers + (i * n_key + r) * n, n, m, row); /* :247-250 */
+            ref_add_poly_coeffmod(out + r * n, row, n, m, out + r * n);                    /* :253-256 */
+        }
+    for (size_t r = 0; r < k; r++)
+    {
+        if (!is_ntt_form) /* :258-262 */
+            ref_ntt_inverse(out + r * n, &c->key_tables[r]);
+        ref_add_poly_coeffmod(out + r * n, ct + r * n, n, &c->key_mod[r], out + r * n); /* :265 */
+    }
+    free(copy);
+}
+
+int ref_decrypt_scale_and_round(ref_context *c, size_t k, const uint64_t *in, uint64_t *out)
+{
+    const ref_rns_tool *rt = ref_context_rns_tool(c, k);
+    if (!rt)
+        return -1;
+    const size_t n = c->n;
+    const uint64_t t = rt->t.value, gamma = rt->gamma.value;
+    uint64_t qv[64], tg[2] = { t, gamma };
+    for (size_t i = 0; i < k; i++)
+        qv[i] = rt->q[i].value;
+    ref_base_converter conv; /* base_q_to_t_gamma_conv_, rns.cpp:634-638 */
+    if (ref_base_converter_init(&conv, qv, k, tg, 2))
+        return -1;
+    uint64_t neg_inv_q[2], inv_gamma_mod_t;
+    for (int i = 0; i < 2; i++) /* rns.cpp:707-716 */
+    {
+        uint64_t pq = 1 % tg[i];
+        for (size_t j = 0; j < k; j++)
+            pq = ref_multiply_uint_mod(pq, qv[j] % tg[i], &conv.obase[i]);
+        if (!ref_try_invert_uint_mod(pq, tg[i], &neg_inv_q[i]))
+            return -1;
+        neg_inv_q[i] = neg_inv_q[i] ? tg[i] - neg_inv_q[i] : 0;
+    }
+    if (!ref_try_invert_uint_mod(gamma % t, t, &inv_gamma_mod_t)) /* :693 */
+        return -1;
+    uint64_t *temp = (uint64_t *)malloc(sizeof(uint64_t) * k * n);
+    uint64_t *ttg = (uint64_t *)malloc(sizeof(uint64_t) * 2 * n);
+    for (size_t i = 0; i < k; i++) /* :1076-1082, prod_t_gamma_mod_q_ (:699-704) */
+    {
+        const uint64_t ptg = ref_multiply_uint_mod(t % qv[i], gamma % qv[i], &rt->q[i]);
+        ref_multiply_poly_scalar_coeffmod(in + i * n, n, ptg, &rt->q[i], temp + i * n);
+    }
+    ref_fast_convert_array(&conv, temp, n, ttg); /* :1088 */
+    for (int i = 0; i < 2; i++)                  /* :1091-1096 */
+        ref_multiply_poly_scalar_coeffmod(ttg + i * n, n, neg_inv_q[i], &conv.obase[i], ttg + i * n);
+    const uint64_t gamma_div_2 = gamma >> 1;
+    for (size_t i = 0; i < n; i++) /* :1104-1125 */
+    {
+        uint64_t d;
+        if (ttg[n + i] > gamma_div_2)
+        {
+            const uint64_t a = ttg[i] + (gamma - ttg[n + i]) % t;
+            d = a >= t ? a - t : a;
+        }
+        else
+        {
+            const uint64_t b = ttg[n + i] % t;
+            d = ttg[i] >= b ? ttg[i] - b : ttg[i] + t - b;
+        }
+        if (d)
+            d = ref_multiply_uint_mod(d, inv_gamma_mod_t, &conv.obase[0]);
+        out[i] = d;
+    }
+    free(temp);
+    free(ttg);
+    ref_base_converter_free(&conv);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic data helpers
  * ---------------------------------------------------------------------------------------- */
 uint64_t ref_splitmix64(uint64_t *state)

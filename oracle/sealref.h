@@ -199,6 +199,33 @@ int ref_multiply_plain(const ref_context *c, size_t k, uint64_t *ct, size_t size
 /* ciphertext.h:471-476 */
 int ref_is_transparent(const ref_context *c, size_t k, const uint64_t *ct, size_t size);
 
+/* ---- the steps either side of the path, restated for an end-to-end SEMANTIC check (encrypt ->
+   evaluate -> decrypt == plaintext arithmetic). Sampling uses splitmix64 (the reference's Blake2/SHAKE PRNG is a
+   client-side detail; no bit parity with its random streams is claimed or needed). ---- */
+/* uniform ternary secret {-1,0,1}^n and a centred-binomial error (sigma ~ 3.2, util/rlwe.cpp:25-95 samples a
+   clipped normal of the same width) */
+void ref_sample_ternary(int8_t *s, size_t n, uint64_t *state);
+void ref_sample_noise(int8_t *e, size_t n, uint64_t *state);
+/* small signed polynomial -> RNS rows (key primes 0..rows-1), optionally NTT form */
+void ref_small_poly_to_rns(const ref_context *c, const int8_t *s, size_t rows, int to_ntt, uint64_t *out);
+/* util/rlwe.cpp:204-300 without seed saving: ct = ([-(a*s + e)]_q, a) over key primes 0..rows-1;
+   sk_ntt = secret key in NTT form (row stride n) */
+void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
+                                uint64_t *state, uint64_t *ct);
+/* Encryptor::encrypt (BFV, symmetric): encrypt_zero + multiply_add_plain_with_scaling_variant (util/scalingvariant.cpp:15-52) */
+void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
+                               uint64_t *state, uint64_t *ct);
+/* KeyGenerator::generate_one_kswitch_key (keygenerator.cpp:325-369): key = digits x 2 x n_key x N; new_key_ntt has
+   k_first rows (NTT form) */
+void ref_generate_kswitch_key(const ref_context *c, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,
+                              uint64_t *state, uint64_t *key);
+/* Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265): sk_powers = (size-1) polys (s, s^2, ...) in NTT form,
+   each with key-level row stride (n_key rows); out = k rows, same form as the ciphertext */
+void ref_dot_product_ct_sk(const ref_context *c, size_t k, const uint64_t *ct, size_t size, int is_ntt_form,
+                           const uint64_t *sk_powers, uint64_t *out);
+/* RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126): k rows -> N coefficients mod t */
+int ref_decrypt_scale_and_round(ref_context *c, size_t k, const uint64_t *in, uint64_t *out);
+
 /* ---- synthetic data helpers shared by tests ---- */
 uint64_t ref_splitmix64(uint64_t *state);
 uint64_t ref_fnv1a64(const uint64_t *words, size_t count);

@@ -180,6 +180,20 @@ def lib():
     L.ref_multiply_plain_ntt.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_multiply_plain.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_is_transparent.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt]
+    i8p = C.c_void_p
+    L.ref_sample_ternary.restype = None
+    L.ref_sample_ternary.argtypes = [i8p, szt, u64p]
+    L.ref_small_poly_to_rns.restype = None
+    L.ref_small_poly_to_rns.argtypes = [C.POINTER(Context), i8p, szt, C.c_int, C.c_void_p]
+    L.ref_encrypt_zero_symmetric.restype = None
+    L.ref_encrypt_zero_symmetric.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_int, u64p, C.c_void_p]
+    L.ref_bfv_encrypt_symmetric.restype = None
+    L.ref_bfv_encrypt_symmetric.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p, u64p, C.c_void_p]
+    L.ref_generate_kswitch_key.restype = None
+    L.ref_generate_kswitch_key.argtypes = [C.POINTER(Context), C.c_void_p, C.c_void_p, u64p, C.c_void_p]
+    L.ref_dot_product_ct_sk.restype = None
+    L.ref_dot_product_ct_sk.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_int, C.c_void_p, C.c_void_p]
+    L.ref_decrypt_scale_and_round.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]
@@ -271,3 +285,76 @@ class RefContext:
             lib().ref_context_free(C.byref(self.c))
         except Exception:
             pass
+
+
+class Client:
+    """Secret-key side of a BFV/CKKS session built from the oracle's restatements: key generation,
+    symmetric encryption, key-switch keys, decryption. Test infrastructure for the semantic end-to-end checks."""
+
+    def __init__(self, ref, seed=1):
+        self.ref = ref
+        c = ref.c
+        self.n, self.n_key, self.k = int(c.n), int(c.n_key), int(c.k_first)
+        self.state = C.c_uint64(seed)
+        s = np.zeros(self.n, dtype=np.int8)
+        lib().ref_sample_ternary(s.ctypes.data, self.n, C.byref(self.state))
+        self.s = s
+        self.sk = np.zeros((self.n_key, self.n), dtype=np.uint64)  # NTT form, every key prime
+        lib().ref_small_poly_to_rns(C.byref(c), s.ctypes.data, self.n_key, 1, ptr(self.sk))
+        self.mods = [int(c.key_mod[i].value) for i in range(self.n_key)]
+
+    def sk_powers(self, count):
+        """s, s^2, ... in NTT form with key-level row stride (Decryptor::compute_secret_key_array)"""
+        out = np.zeros((count, self.n_key, self.n), dtype=np.uint64)
+        cur = self.sk.copy()
+        for i in range(count):
+            out[i] = cur
+            nxt = np.zeros_like(cur)
+            for r in range(self.n_key):
+                lib().ref_dyadic_product_coeffmod(ptr(cur[r]), ptr(self.sk[r]), self.n, C.byref(self.ref.c.key_mod[r]), ptr(nxt[r]))
+            cur = nxt
+        return out
+
+    def encrypt_bfv(self, plain):
+        ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        lib().ref_bfv_encrypt_symmetric(C.byref(self.ref.c), self.k, ptr(self.sk), ptr(plain), C.byref(self.state), ptr(ct))
+        return ct
+
+    def kswitch_key(self, new_key_ntt):
+        d = (self.k + int(self.ref.c.nsp) - 1) // int(self.ref.c.nsp)
+        key = np.zeros((d, 2, self.n_key, self.n), dtype=np.uint64)
+        new_key_ntt = np.ascontiguousarray(new_key_ntt[: self.k], dtype=np.uint64)
+        lib().ref_generate_kswitch_key(C.byref(self.ref.c), ptr(self.sk), ptr(new_key_ntt), C.byref(self.state), ptr(key))
+        return key
+
+    def relin_key(self):
+        return self.kswitch_key(self.sk_powers(2)[1])
+
+    def galois_key(self, elt):
+        """key for s(x^elt) (KeyGenerator::galois_keys: apply_galois_ntt on the secret key)"""
+        rot = np.zeros((self.k, self.n), dtype=np.uint64)
+        for r in range(self.k):
+            lib().ref_apply_galois_ntt(ptr(self.sk[r]), int(self.ref.c.logn), elt, ptr(rot[r]))
+        return self.kswitch_key(rot)
+
+    def decrypt_bfv(self, ct, k=None):
+        k = k or ct.shape[1]
+        size = ct.shape[0]
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        dot = np.zeros((k, self.n), dtype=np.uint64)
+        pw = self.sk_powers(size - 1)
+        lib().ref_dot_product_ct_sk(C.byref(self.ref.c), k, ptr(ct), size, 0, ptr(pw), ptr(dot))
+        out = np.zeros(self.n, dtype=np.uint64)
+        assert lib().ref_decrypt_scale_and_round(C.byref(self.ref.c), k, ptr(dot), ptr(out)) == 0
+        return out
+
+
+def negacyclic_mod_t(a, b, t):
+    """a*b in Z_t[x]/(x^N+1) with exact integer convolution"""
+    n = len(a)
+    full = np.convolve(np.asarray(a, dtype=object), np.asarray(b, dtype=object))
+    res = [int(v) for v in full[:n]]
+    for i in range(n, 2 * n - 1):
+        res[i - n] -= int(full[i])
+    return np.array([v % t for v in res], dtype=np.uint64)

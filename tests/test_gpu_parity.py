@@ -823,3 +823,62 @@ def test_key_switch_large_batch_key_reuse(sealhip, scheme, nsp, count):
         exp = ct2[i].copy()
         assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(exp), elt, O.ptr(key)) == 0
         assert np.array_equal(got[i], exp), i
+
+
+# ---------------------------------------------------------------- decrypt-side arithmetic, semantic end-to-end
+@pytest.mark.parametrize("logn,nsp", [(8, 1), (12, 2), (14, 1)])
+def test_f2_encrypt_evaluate_on_gpu_decrypt(sealhip, logn, nsp):
+    """Client side from the oracle (keys, symmetric encryption), evaluation on the GPU in STRICT mode (the fork's BFV
+    relinearize is not semantically valid, F3), decryption on the GPU: plaintexts multiply as polynomials mod
+    (x^N + 1, t); and every GPU decrypt equals the oracle's decrypt of the same ciphertext."""
+    n, t = 1 << logn, 65537
+    kmods = O.coeff_modulus_create(n, [45] * (3 + nsp))
+    ref = O.RefContext(1, logn, kmods, nsp=nsp, t=t, mode=1)
+    cl = O.Client(ref, seed=logn)
+    k, count = cl.k, 3
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, nsp, t, mode=sealhip.MODE_STRICT)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(logn)
+    m1 = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    m2 = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    a = np.stack([cl.encrypt_bfv(m) for m in m1])
+    b = np.stack([cl.encrypt_bfv(m) for m in m2])
+    pw = ctx.upload(cl.sk_powers(2))
+
+    def gpu_decrypt(dct, size, kk):
+        dot = ctx.alloc(count * kk * n)
+        ctx.dot_product_ct_sk(dct, size, kk, count, pw, False, dot)
+        out = ctx.alloc(count * n)
+        ctx.decrypt_scale_and_round(kk, dot, count, out)
+        return out.download((count, n))
+
+    da = ctx.upload(a)
+    assert np.array_equal(gpu_decrypt(da, 2, k), m1)  # fresh ciphertexts
+    prod = ctx.alloc(count * 3 * k * n)
+    ev.multiply(da, 2, ctx.upload(b), 2, k, count, prod)
+    want = np.stack([O.negacyclic_mod_t(x, y, t) for x, y in zip(m1, m2)]) if logn <= 12 else None
+    got3 = gpu_decrypt(prod, 3, k)
+    host3 = prod.download((count, 3, k, n))
+    for i in range(count):  # bit-exact against the oracle's decrypt of the GPU ciphertext
+        assert np.array_equal(got3[i], cl.decrypt_bfv(host3[i])), i
+    if want is not None:
+        assert np.array_equal(got3, want)
+    rk = sealhip.KSwitchKeys(ctx, cl.relin_key())
+    ev.relinearize_inplace(prod, 3, k, count, [rk])
+    c2 = ctx.upload(prod.download((count, 3, k, n))[:, :2].copy())
+    got2 = gpu_decrypt(c2, 2, k)
+    assert np.array_equal(got2, got3)  # relinearization does not change the plaintext
+    low = ctx.alloc(count * 2 * (k - 1) * n)
+    ev.mod_switch_to_next(c2, 2, k, count, low)
+    assert np.array_equal(gpu_decrypt(low, 2, k - 1), got3)
+    # rotate by one step and compare with the permuted plaintext
+    elt = ctx.galois_elt_from_step(1)
+    gk = sealhip.KSwitchKeys(ctx, cl.galois_key(elt))
+    g = ctx.upload(a)
+    ev.apply_galois_inplace(g, k, count, elt, gk)
+    rot = gpu_decrypt(g, 2, k)
+    idx = (np.arange(n, dtype=np.int64) * elt) % (2 * n)
+    for i in range(count):
+        perm = np.zeros(n, dtype=np.uint64)
+        perm[idx % n] = np.where(idx < n, m1[i], (t - m1[i]) % t)
+        assert np.array_equal(rot[i], perm), i

@@ -407,3 +407,48 @@ def test_f1_add_sub_negate_sizes_and_transparent():
     z[1:] = 0
     assert L.ref_is_transparent(C.byref(ctx.c), k, O.ptr(z), 3) == 1
     assert L.ref_is_transparent(C.byref(ctx.c), k, O.ptr(z), 1) == 1
+
+
+# ---------------------------------------------------------------- semantic end-to-end (encrypt -> evaluate -> decrypt)
+@pytest.mark.parametrize("nsp", [1, 2])
+def test_f2_bfv_semantics_strict_and_the_forks_relinearize(nsp):
+    """Encrypt two plaintexts, multiply, relinearize, mod-switch, decrypt: in STRICT mode the result is the negacyclic
+    product mod t. In PARITY mode (the fork as built) multiply and mod-switch are also right -- a size-3 ciphertext
+    decrypts correctly -- but BFV relinearize is not (finding F3: the in-bundle rows meet the NTT-form key in
+    coefficient form), which is exactly what the parity target reproduces."""
+    logn, n, t = 8, 256, 65537
+    kmods = O.coeff_modulus_create(n, [40] * (3 + nsp))
+    rng = np.random.default_rng(9)
+    m1, m2 = rng.integers(0, t, size=n, dtype=np.uint64), rng.integers(0, t, size=n, dtype=np.uint64)
+    want = O.negacyclic_mod_t(m1, m2, t)
+    for mode, relin_ok in ((1, True), (0, False)):
+        ref = O.RefContext(1, logn, kmods, nsp=nsp, t=t, mode=mode)
+        cl = O.Client(ref, seed=77)
+        k = cl.k
+        a, b = cl.encrypt_bfv(m1), cl.encrypt_bfv(m2)
+        assert np.array_equal(cl.decrypt_bfv(a), m1) and np.array_equal(cl.decrypt_bfv(b), m2)
+        prod = np.zeros((3, k, n), dtype=np.uint64)
+        assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a), 2, O.ptr(b), 2, O.ptr(prod)) == 0
+        assert np.array_equal(cl.decrypt_bfv(prod), want), mode  # size 3, with s^2
+        rk = cl.relin_key()
+        keys = (C.c_void_p * 1)(rk.ctypes.data)
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(prod), 3, keys) == 0
+        c2 = prod[:2].copy()
+        assert np.array_equal(cl.decrypt_bfv(c2), want) == relin_ok, (mode, nsp)
+        if relin_ok:
+            low = np.zeros((2, k - 1, n), dtype=np.uint64)
+            assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(c2), 2, O.ptr(low)) == 0
+            assert np.array_equal(cl.decrypt_bfv(low, k - 1), want)
+            # rotate_rows by one step: decrypt(apply_galois(ct)) == plaintext with x -> x^elt
+            elt = int(L.ref_galois_elt_from_step(n, 1, None))
+            g = a.copy()
+            gk = cl.galois_key(elt)
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(g), elt, O.ptr(gk)) == 0
+            perm = np.zeros(n, dtype=np.uint64)
+            for i in range(n):
+                j = (i * elt) % (2 * n)
+                if j < n:
+                    perm[j] = m1[i]
+                else:
+                    perm[j - n] = (t - int(m1[i])) % t
+            assert np.array_equal(cl.decrypt_bfv(g), perm)
