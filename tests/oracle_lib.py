@@ -321,6 +321,36 @@ class Client:
         lib().ref_bfv_encrypt_symmetric(C.byref(self.ref.c), self.k, ptr(self.sk), ptr(plain), C.byref(self.state), ptr(ct))
         return ct
 
+    def encrypt_poly_ntt(self, coeffs):
+        """CKKS-style: encrypt an integer polynomial (already scaled), NTT form, at the first ciphertext level"""
+        ct = np.zeros((2, self.k, self.n), dtype=np.uint64)
+        lib().ref_encrypt_zero_symmetric(C.byref(self.ref.c), self.k, ptr(self.sk), 1, C.byref(self.state), ptr(ct))
+        for r in range(self.k):
+            p = self.mods[r]
+            row = np.array([int(v) % p for v in coeffs], dtype=np.uint64)
+            lib().ref_ntt_forward(ptr(row), C.byref(self.ref.c.key_tables[r]), 0)
+            lib().ref_add_poly_coeffmod(ptr(ct[0, r]), ptr(row), self.n, C.byref(self.ref.c.key_mod[r]), ptr(ct[0, r]))
+        return ct
+
+    def centered_from_ntt_rows(self, rows):
+        """k NTT-form rows -> centred integer coefficients (CRT over the first k key primes)"""
+        k = rows.shape[0]
+        res = []
+        for r in range(k):
+            row = np.ascontiguousarray(rows[r]).copy()
+            lib().ref_ntt_inverse(ptr(row), C.byref(self.ref.c.key_tables[r]))
+            res.append([int(v) for v in row])
+        q = 1
+        for r in range(k):
+            q *= self.mods[r]
+        out = [0] * self.n
+        for r in range(k):
+            qr = q // self.mods[r]
+            inv = pow(qr % self.mods[r], -1, self.mods[r])
+            for i in range(self.n):
+                out[i] = (out[i] + res[r][i] * inv % self.mods[r] * qr) % q
+        return [v - q if v > q // 2 else v for v in out], q
+
     def kswitch_key(self, new_key_ntt):
         d = (self.k + int(self.ref.c.nsp) - 1) // int(self.ref.c.nsp)
         key = np.zeros((d, 2, self.n_key, self.n), dtype=np.uint64)

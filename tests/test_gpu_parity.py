@@ -882,3 +882,53 @@ def test_f2_encrypt_evaluate_on_gpu_decrypt(sealhip, logn, nsp):
         perm = np.zeros(n, dtype=np.uint64)
         perm[idx % n] = np.where(idx < n, m1[i], (t - m1[i]) % t)
         assert np.array_equal(rot[i], perm), i
+
+
+def test_f2_ckks_semantics_parity_mode(sealhip):
+    """CKKS in PARITY mode (the fork as built) is semantically sound: encrypt two scaled integer polynomials, multiply,
+    relinearize, rescale and rotate on the GPU, decrypt (dot product with the secret key on the GPU, CRT on the host):
+    the results are the polynomial product / its rescaled value / the permuted input up to the scheme's noise."""
+    logn, n = 10, 1024
+    kmods = O.coeff_modulus_create(n, [40, 40, 40, 45])
+    ref = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    cl = O.Client(ref, seed=5)
+    k = cl.k
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(5)
+    p1 = rng.integers(-(1 << 20), 1 << 20, size=n).astype(object)
+    p2 = rng.integers(-(1 << 20), 1 << 20, size=n).astype(object)
+    full = np.convolve(p1, p2)
+    want = [int(full[i]) - (int(full[i + n]) if i + n < len(full) else 0) for i in range(n)]
+    a, b = ctx.upload(cl.encrypt_poly_ntt(p1)), ctx.upload(cl.encrypt_poly_ntt(p2))
+    pw = ctx.upload(cl.sk_powers(2))
+
+    def decrypt(dct, size, kk):
+        dot = ctx.alloc(kk * n)
+        ctx.dot_product_ct_sk(dct, size, kk, 1, pw, True, dot)
+        return cl.centered_from_ntt_rows(dot.download((kk, n)))
+
+    got, _ = decrypt(a, 2, k)
+    assert max(abs(g - int(w)) for g, w in zip(got, p1)) < 64  # fresh noise
+    prod = ctx.alloc(3 * k * n)
+    ev.multiply(a, 2, b, 2, k, 1, prod)
+    got, _ = decrypt(prod, 3, k)
+    assert max(abs(g - w) for g, w in zip(got, want)) < 1 << 40  # ~ N * |p| * |e|
+    ev.relinearize_inplace(prod, 3, k, 1, [sealhip.KSwitchKeys(ctx, cl.relin_key())])
+    c2 = ctx.upload(prod.download((3, k, n))[:2].copy())
+    got, _ = decrypt(c2, 2, k)
+    assert max(abs(g - w) for g, w in zip(got, want)) < 1 << 41
+    low = ctx.alloc(2 * (k - 1) * n)
+    ev.rescale_to_next(c2, 2, k, 1, low)
+    got, _ = decrypt(low, 2, k - 1)
+    qlast = kmods[k - 1]
+    assert max(abs(g - w / qlast) for g, w in zip(got, want)) < 1 << 12
+    elt = ctx.galois_elt_from_step(3)
+    g = ctx.upload(a.download((2, k, n)))
+    ev.apply_galois_inplace(g, k, 1, elt, sealhip.KSwitchKeys(ctx, cl.galois_key(elt)))
+    got, _ = decrypt(g, 2, k)
+    perm = [0] * n
+    for i in range(n):
+        j = (i * elt) % (2 * n)
+        perm[j % n] = int(p1[i]) if j < n else -int(p1[i])
+    assert max(abs(x - y) for x, y in zip(got, perm)) < 1 << 30  # key-switch noise ~ N * q_i * |e| / P
