@@ -37,8 +37,13 @@ namespace sealhip
         const u64 *base[2];
         std::size_t poly_stride[2];
         unsigned short code[kMaxRows];
+        // launch-wide treatment of the loaded words (single-prime mod-up, multi_special_primes.cpp:99-108): 0 none,
+        // 1 barrett_reduce_63 w.r.t. the row's prime, 2 one conditional subtraction (every source prime is below twice
+        // every destination prime, so the canonical residue is x or x - p). Both are no-ops on rows whose source prime
+        // does not exceed their own.
+        int reduce_mode;
     };
-    constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000;
+    constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
 
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies

@@ -610,10 +610,9 @@ namespace sealhip
 #define SEALHIP_NTT_LOAD_BATCH 4
 #endif
         constexpr int kLoadBatch = SEALHIP_NTT_LOAD_BATCH; // (lo, hi) 16-byte pairs per lane in flight during the load phase
-        template <int T, bool STRICT, int HALF>
+        template <int T, bool STRICT, int HALF, int REDUCE>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
-                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p,
-                                                   bool reduce, u64 cr1)
+                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
             const u64x2 W1 = ((tw_const_t)tw)[1];
@@ -629,16 +628,22 @@ namespace sealhip
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
                 }
-                if (reduce) // block-uniform: gathered single-prime mod-up (multi_special_primes.cpp:103-107)
+                if constexpr (REDUCE != 0) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
                 {
                     const u64 p = 0 - neg_p;
+                    const auto red = [&](u64 v) {
+                        if constexpr (REDUCE == 2)
+                            return v >= p ? v - p : v; // source prime < 2p: the canonical residue is v or v - p
+                        else
+                            return barrett_reduce_63(v, p, cr1);
+                    };
 #pragma unroll
                     for (int i = 0; i < kLoadBatch; i++)
                     {
-                        lo[i].x = barrett_reduce_63(lo[i].x, p, cr1);
-                        lo[i].y = barrett_reduce_63(lo[i].y, p, cr1);
-                        hi[i].x = barrett_reduce_63(hi[i].x, p, cr1);
-                        hi[i].y = barrett_reduce_63(hi[i].y, p, cr1);
+                        lo[i].x = red(lo[i].x);
+                        lo[i].y = red(lo[i].y);
+                        hi[i].x = red(hi[i].x);
+                        hi[i].y = red(hi[i].y);
                     }
                 }
 #pragma unroll
@@ -712,7 +717,7 @@ namespace sealhip
             return v;
         }
 
-        template <int LOGN, bool STRICT>
+        template <int LOGN, bool STRICT, int REDUCE>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
             unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src, std::size_t chunk)
@@ -737,7 +742,6 @@ namespace sealhip
             // ---- load both halves, top layer on the fly, arrangement 1 (block-uniform branch on the half)
             const u64 neg_p = 0 - p;
             const u64 *srcp = rowp;
-            bool reduce = false;
             if (src.base[0])
             {
                 const unsigned short code = src.code[row % map.rows];
@@ -746,7 +750,6 @@ namespace sealhip
                     const int b = code >> 15;
                     srcp = src.base[b] + (row / map.rows) * src.poly_stride[b] +
                            (static_cast<std::size_t>(code & 0x3FFF) << LOGN);
-                    reduce = (code & kSrcReduce) != 0;
                 }
             }
             NTT_STAMP(0);
@@ -766,9 +769,9 @@ namespace sealhip
                     x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
             }
             else if (half)
-                h_load_top<T, STRICT, 1>(x, srcp, tw, fresh(tid), two_p, neg_p, reduce, P.cr1);
+                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1);
             else
-                h_load_top<T, STRICT, 0>(x, srcp, tw, fresh(tid), two_p, neg_p, reduce, P.cr1);
+                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -1149,7 +1152,7 @@ namespace sealhip
             if (const char *ex = std::getenv("SEALHIP_NTT_LDS_EXTRA")) // lower the occupancy on purpose
             {
                 lds_bytes += std::strtoul(ex, nullptr, 0);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
             }
 #endif
@@ -1199,12 +1202,29 @@ namespace sealhip
             } trace_dump{trace, trace_path, blocks, e.stream};
 #endif
             ProfScope prof(e, "ntt_fwd_half", static_cast<double>(nrows));
+#define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
+    ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>( \
+        data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk)
+            const int red = src.base[0] ? src.reduce_mode : 0;
             if (flags & kNttStrict)
-                ntt_fwd_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk);
+            {
+                if (red == 2)
+                    SEALHIP_FWD_HALF(true, 2);
+                else if (red == 1)
+                    SEALHIP_FWD_HALF(true, 1);
+                else
+                    SEALHIP_FWD_HALF(true, 0);
+            }
             else
-                ntt_fwd_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk);
+            {
+                if (red == 2)
+                    SEALHIP_FWD_HALF(false, 2);
+                else if (red == 1)
+                    SEALHIP_FWD_HALF(false, 1);
+                else
+                    SEALHIP_FWD_HALF(false, 0);
+            }
+#undef SEALHIP_FWD_HALF
             return hipGetLastError();
         }
 
@@ -1212,14 +1232,19 @@ namespace sealhip
         hipError_t init_half()
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (err != hipSuccess)
-                return err;
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (err != hipSuccess)
-                return err;
+            hipError_t err = hipSuccess;
+            const void *fwd[6] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 1>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 2>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 0>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 1>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 2>) };
+            for (const void *f : fwd)
+            {
+                err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (err != hipSuccess)
+                    return err;
+            }
             return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         }

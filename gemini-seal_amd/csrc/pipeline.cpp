@@ -123,6 +123,17 @@ namespace sealhip
             // bundle's single row (multi_special_primes.cpp:99-108): the NTT kernel gathers and reduces it on load,
             // so the extended polynomial is never written in coefficient form.
             const bool gather = e.nsp == 1 && ntt_can_gather(e);
+            // launch-wide reduction of the gathered words: none when no source prime exceeds a destination prime, one
+            // conditional subtraction when every source prime is below twice every destination prime, else Barrett-63
+            bool need_any = false, need_barrett = false;
+            for (int a = 0; a < k; a++)
+                for (int b = 0; b < rows; b++)
+                {
+                    const u64 ps = e.key_moduli[h.row_prime[a]], pd = e.key_moduli[h.row_prime[b]];
+                    need_any = need_any || (a != b && ps > pd);
+                    need_barrett = need_barrett || (a != b && ps >= 2 * pd);
+                }
+            const int modup_mode = need_barrett ? 1 : (need_any ? 2 : 0);
             if (!gather)
                 check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
             for (int j = 0; j < nd; j++)
@@ -136,6 +147,7 @@ namespace sealhip
                     NttSource ns{};
                     ns.base[0] = src;
                     ns.poly_stride[0] = src_stride;
+                    ns.reduce_mode = modup_mode;
                     const u64 p_src = e.key_moduli[h.row_prime[j]];
                     for (int r = 0; r < rows; r++)
                     {
