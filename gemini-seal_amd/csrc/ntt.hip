@@ -1031,7 +1031,7 @@ namespace sealhip
             {
                 // every coefficient of the half row first (16 x 16 bytes per lane in flight at once), the twiddles of
                 // the first stage with them
-                const int jloc = Arr<T, 4>::tid_index(tid);
+                const int jloc = Arr<T, 4>::tid_index(fresh(tid));
                 u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
                 FirstStage<T, 0>::load(tg0, tw, gbase + jloc, N);
 #pragma unroll
@@ -1044,21 +1044,22 @@ namespace sealhip
                 __builtin_amdgcn_sched_barrier(0);
                 FirstPipe<T, 0>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
             }
-            const int jb3 = gbase + Arr<T, 3>::tid_index(tid), jb2 = gbase + Arr<T, 2>::tid_index(tid);
+            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
             u64 w0[kIL], ws0[kIL];
             RoundStageInv<T, 3, false, 0>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
-            h_exchange<T, 4, 3>(x, lds, tid);
+            h_exchange<T, 4, 3>(x, lds, fresh(tid));
             RoundPipeInv<T, 3, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
+            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
             RoundStageInv<T, 2, false, 0>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
-            h_exchange<T, 3, 2>(x, lds, tid);
+            h_exchange<T, 3, 2>(x, lds, fresh(tid));
             RoundPipeInv<T, 2, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
             RoundStageInv<T, 1, true, 0>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
-            h_exchange<T, 2, 1>(x, lds, tid);
+            h_exchange<T, 2, 1>(x, lds, fresh(tid));
             RoundPipeInv<T, 1, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
             {
-                const int jb = Arr<T, 1>::tid_index(tid);
+                const int jb = Arr<T, 1>::tid_index(fresh(tid));
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
