@@ -1112,6 +1112,15 @@ namespace sealhip
             }
         }
 
+        // rows a launch really transforms (rows mapped to kSkipRow are left alone): the unit count of the profiler
+        inline double transformed_rows(std::size_t nrows, const RowMap &map)
+        {
+            int live = 0;
+            for (int r = 0; r < map.rows; r++)
+                live += map.prime[r] != kSkipRow;
+            return static_cast<double>(nrows / map.rows) * live;
+        }
+
         template <int LOGN>
         hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags)
         {
@@ -1124,7 +1133,7 @@ namespace sealhip
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
             {
-                ProfScope prof(e, "ntt_inv_half", static_cast<double>(nrows));
+                ProfScope prof(e, "ntt_inv_half", transformed_rows(nrows, map));
                 ntt_inv_half_kernel<LOGN><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
                     data, e.d_primes, map, nrows, chunk);
                 hipError_t err = hipGetLastError();
@@ -1137,7 +1146,7 @@ namespace sealhip
             std::size_t grid = (npairs + 255) / 256;
             if (grid > 256u * 32u)
                 grid = 256u * 32u;
-            ProfScope prof(e, "ntt_inv_top", static_cast<double>(nrows));
+            ProfScope prof(e, "ntt_inv_top", transformed_rows(nrows, map));
             ntt_inv_top_kernel<<<static_cast<unsigned>(grid), 256, 0, e.stream>>>(data, e.d_primes, map, LOGN, npairs,
                                                                                flags);
             return hipGetLastError();
@@ -1202,7 +1211,7 @@ namespace sealhip
                 }
             } trace_dump{trace, trace_path, blocks, e.stream};
 #endif
-            ProfScope prof(e, "ntt_fwd_half", static_cast<double>(nrows));
+            ProfScope prof(e, "ntt_fwd_half", transformed_rows(nrows, map));
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
     ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>( \
         data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk)
@@ -1341,7 +1350,7 @@ namespace sealhip
                 return hipErrorInvalidValue;
             hipError_t err;
             {
-                ProfScope prof(e, DIR == 0 ? "ntt_fwd_pass" : "ntt_inv_pass", static_cast<double>(nrows));
+                ProfScope prof(e, DIR == 0 ? "ntt_fwd_pass" : "ntt_inv_pass", transformed_rows(nrows, map));
                 ntt_pass_kernel<DIR><<<static_cast<unsigned>(blocks), threads, lds_bytes, e.stream>>>(data, e.d_primes,
                                                                                                       map, ps);
                 err = hipGetLastError();
