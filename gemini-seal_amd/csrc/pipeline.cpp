@@ -15,11 +15,19 @@ namespace sealhip
         std::size_t workspace_budget_bytes()
         {
             static const std::size_t budget = [] {
-                const char *env = std::getenv("SEALHIP_WORKSPACE_MB");
-                std::size_t mb = env ? static_cast<std::size_t>(std::strtoull(env, nullptr, 10)) : 8192;
-                if (mb < 64)
-                    mb = 64;
-                return mb << 20;
+                // cap of the temporaries arena (it grows on demand up to this): SEALHIP_WORKSPACE_MB, else a sixth of
+                // the memory free on the device at first use, between 2 and 48 GiB -- sized for 288 GB of HBM, where
+                // larger chunks mean larger launches (bench: +3 % from 8 to 48 GiB)
+                if (const char *env = std::getenv("SEALHIP_WORKSPACE_MB"))
+                {
+                    std::size_t mb = static_cast<std::size_t>(std::strtoull(env, nullptr, 10));
+                    return (mb < 64 ? std::size_t(64) : mb) << 20;
+                }
+                std::size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+                    return std::size_t(8192) << 20;
+                const std::size_t lo = std::size_t(2) << 30, hi = std::size_t(48) << 30;
+                return std::min(hi, std::max(lo, free_b / 6));
             }();
             return budget;
         }
