@@ -222,6 +222,12 @@ namespace sealhip
     {
         return mullo2_acc<WU>(0, x, y, mulhi_c<WU>(x, yshoup), neg_p);
     }
+    // canonical Shoup product (MulModShoup, multi_special_primes.cpp:13-19) with a wave-uniform constant
+    __device__ __forceinline__ u64 mulmod_shoup_hs(u64 x, u64 y, u64 yshoup, u64 p)
+    {
+        const u64 t = mulmod_lazy_hs<true>(x, y, yshoup, 0 - p);
+        return t >= p ? t - p : t;
+    }
     // barrett_lazy with the sequences above: x + q*(2^64-p); rdp is wave-uniform
     __device__ __forceinline__ u64 barrett_lazy_hs(u64 x, u64 rdp, u64 neg_p)
     {

@@ -189,7 +189,7 @@ namespace sealhip
                 if (KMAX < 0 || i < k)
                 {
                     const u64 qp = primes[d->q_prime[i]].p;
-                    t[i] = mulmod_shoup(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
+                    t[i] = mulmod_shoup_hs(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
                     acc += t[i] * d->q_to_mt[i];
                 }
             const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
@@ -237,19 +237,18 @@ namespace sealhip
         template <class PP>
         __device__ __forceinline__ u64 after_top(u64 u, u64 v, bool is_hi, PP P)
         {
-            const u64 p = P->p, two_p = P->two_p;
+            const u64 p = P->p, two_p = P->two_p, neg_p = 0 - p;
             u64 r;
             if (is_hi)
-                r = mulmod_lazy(u - v + two_p, P->inv_n_w, P->inv_n_w_shoup, p);
+                r = mulmod_lazy_hs<true>(u - v + two_p, P->inv_n_w, P->inv_n_w_shoup, neg_p);
             else
             {
                 u64 tt = u + v;
                 tt = tt >= two_p ? tt - two_p : tt;
-                r = mulmod_lazy(tt, P->inv_n, P->inv_n_shoup, p);
+                r = mulmod_lazy_hs<true>(tt, P->inv_n, P->inv_n_shoup, neg_p);
             }
             return r >= p ? r - p : r;
         }
-
         template <int KMAX, bool DEFER>
         __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d_,
                                                                          const PrimeDev *__restrict__ primes_,
@@ -296,7 +295,7 @@ namespace sealhip
                 {
                     const auto *Q = primes + d->q_prime[i];
                     const u64 xin = DEFER ? after_top(ru[i], rv[i], is_hi, Q) : ru[i];
-                    t[i] = mulmod_shoup(xin, kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
+                    t[i] = mulmod_shoup_hs(xin, kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
                 }
             u64 tb[KA + 1];
             u64 fl_sk = 0;
