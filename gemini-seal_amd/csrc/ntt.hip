@@ -298,9 +298,12 @@ namespace sealhip
             }
         };
 
+        // LDS image of the exchange buffer: two pad words per 32 and one more for the odd 16-word blocks. With
+        // 2 * (e >> 5) alone the final arrangement (lanes two words apart) had two-way bank conflicts
+        // (SQ_LDS_BANK_CONFLICT 2048 per row at N = 2^15); this form measures zero (tools/hpad_sweep.sh).
         __host__ __device__ constexpr int hpad(int e)
         {
-            return e + 2 * (e >> 5);
+            return e + 2 * (e >> 5) + ((e >> 4) & 1);
         }
 
         template <int T, int RA, int RB>
