@@ -279,6 +279,9 @@ namespace sealhip
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int deferred_top = 0);
     bool ntt_can_defer_top(const Engine &e, int k);
+    // inverse NTT whose input rows come from another buffer (single-pass kernels only: ntt_can_gather(e))
+    hipError_t launch_intt_from(const Engine &e, u64 *data, const u64 *src, std::size_t src_poly_stride, std::size_t nrows,
+                                const RowMap &map, int flags);
     hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int out_rows);

@@ -1011,7 +1011,9 @@ namespace sealhip
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
-                                                                                  std::size_t chunk)
+                                                                                  std::size_t chunk,
+                                                                                  const u64 *__restrict__ src,
+                                                                                  std::size_t src_poly_stride)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
@@ -1029,6 +1031,8 @@ namespace sealhip
             const u64 *tw = P.inv;
             const int gbase = half << T;
             u64 *halfp = data + (row << LOGN) + gbase;
+            // optional out-of-place input (polynomial-strided rows of another buffer): saves a copy kernel
+            const u64 *inp = src ? src + (row / map.rows) * src_poly_stride + ((row % map.rows) << LOGN) + gbase : halfp;
             u64 x[32];
             const u64 neg_p = 0 - p;
             {
@@ -1040,7 +1044,7 @@ namespace sealhip
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(halfp + jloc + Arr<T, 4>::slot_index(s));
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(inp + jloc + Arr<T, 4>::slot_index(s));
                     x[s] = v.x;
                     x[s + 1] = v.y;
                 }
@@ -1125,7 +1129,8 @@ namespace sealhip
         }
 
         template <int LOGN>
-        hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags)
+        hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags,
+                                   const u64 *src = nullptr, std::size_t src_poly_stride = 0)
         {
             constexpr int T = LOGN - 1;
             const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
@@ -1138,7 +1143,7 @@ namespace sealhip
             {
                 ProfScope prof(e, "ntt_inv_half", transformed_rows(nrows, map));
                 ntt_inv_half_kernel<LOGN><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, chunk);
+                    data, e.d_primes, map, nrows, chunk, src, src_poly_stride);
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -1406,6 +1411,21 @@ namespace sealhip
         if (e.logn == 15)
             return launch_half<15>(e, data, nrows, map, flags, src);
         return launch_half<16>(e, data, nrows, map, flags, src);
+    }
+
+    // inverse NTT of rows read from another buffer (polynomial stride src_poly_stride words), written to data
+    hipError_t launch_intt_from(const Engine &e, u64 *data, const u64 *src, std::size_t src_poly_stride, size_t nrows,
+                                const RowMap &map, int flags)
+    {
+        if (!(e.use_half_kernel && e.logn >= 14 && e.logn <= 16))
+            return hipErrorInvalidValue;
+        if (nrows == 0)
+            return hipSuccess;
+        if (e.logn == 14)
+            return launch_half_inv<14>(e, data, nrows, map, flags, src, src_poly_stride);
+        if (e.logn == 15)
+            return launch_half_inv<15>(e, data, nrows, map, flags, src, src_poly_stride);
+        return launch_half_inv<16>(e, data, nrows, map, flags, src, src_poly_stride);
     }
 
     hipError_t launch_ntt(const Engine &e, u64 *data, size_t nrows, const RowMap &map, bool inverse, int flags)

@@ -121,8 +121,13 @@ namespace sealhip
             std::size_t src_stride = target_stride;
             if (ckks)
             {
-                check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
-                check(launch_ntt(e, coeff, m * k, map_q, true, kNttCanonical), "intt(target)");
+                if (ntt_can_gather(e)) // the inverse kernel reads the target rows where they are
+                    check(launch_intt_from(e, coeff, tg, target_stride, m * k, map_q, kNttCanonical), "intt(target)");
+                else
+                {
+                    check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
+                    check(launch_ntt(e, coeff, m * k, map_q, true, kNttCanonical), "intt(target)");
+                }
                 src = coeff;
                 src_stride = static_cast<std::size_t>(k) * N;
             }
