@@ -128,6 +128,10 @@ def cpu_baseline(threads, per_thread):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(run, work))
     dt = time.perf_counter() - t0
+    # the same on one thread (SURVEY 8d asks for both)
+    t1 = time.perf_counter()
+    run((work[0][0], work[0][1], work[0][2]))
+    one_thread = per_thread / (time.perf_counter() - t1)
     # forward NTT/s on one core, same primes
     x = rows(kmods[:k])
     t1 = time.perf_counter()
@@ -144,6 +148,7 @@ def cpu_baseline(threads, per_thread):
         "sample": "%d threads x %d BFV multiply+relinearize at N=2^15, 8 primes (same workload, %d ciphertexts)"
                   % (threads, per_thread, threads * per_thread),
         "seconds": dt,
+        "value_1thread": one_thread,
         "forward_ntt_per_s_1core": ntt_s,
     }
 
