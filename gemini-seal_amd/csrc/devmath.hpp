@@ -28,6 +28,21 @@ namespace sealhip
         const u64 *inv;  // N {w, w'} pairs for psi^{-1}
     };
 
+    // streaming stores (nontemporal hint): outputs that the producing kernel does not read again should not push the
+    // constant tables (twiddles, key slices) out of L2
+    __device__ __forceinline__ void store_stream(u64 *p, u64 v)
+    {
+        __builtin_nontemporal_store(v, p);
+    }
+    __device__ __forceinline__ void store_stream2(u64 *p, u64 a, u64 b)
+    {
+        typedef u64 u64x2_s __attribute__((ext_vector_type(2)));
+        u64x2_s v;
+        v.x = a;
+        v.y = b;
+        __builtin_nontemporal_store(v, reinterpret_cast<u64x2_s *>(p));
+    }
+
     __device__ __forceinline__ u64 mulhi(u64 a, u64 b)
     {
         return __umul64hi(a, b);

@@ -206,8 +206,8 @@ namespace sealhip
                     mac128(lo1, hi1, x[j], k1[j]);
                 }
                 u64 *pp = prod + item * prod_stride + row_off;
-                pp[0] = barrett_reduce_128(lo0, hi0, p, cr0, cr1);
-                pp[static_cast<std::size_t>(rows) * N] = barrett_reduce_128(lo1, hi1, p, cr0, cr1);
+                store_stream(pp, barrett_reduce_128(lo0, hi0, p, cr0, cr1));
+                store_stream(pp + static_cast<std::size_t>(rows) * N, barrett_reduce_128(lo1, hi1, p, cr0, cr1));
 #pragma unroll
                 for (int j = 0; j < ND; j++)
                     x[j] = xn[j];
