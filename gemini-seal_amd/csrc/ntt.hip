@@ -412,7 +412,9 @@ namespace sealhip
                 }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
-                store_nt(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s), v.x, v.y);
+                // (plain store: this path serves f = 3, where a lane's 64-byte run is written by four instructions and
+                //  the L2 has to merge them; streaming stores cost 12 % there)
+                *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
             }
         }
 
