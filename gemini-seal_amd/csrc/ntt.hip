@@ -345,15 +345,6 @@ namespace sealhip
         typedef const __attribute__((address_space(1))) u64x2 *tw_global_t;
         typedef const __attribute__((address_space(4))) u64x2 *tw_const_t;
 
-        // sched_barrier mask: only VMEM reads and SALU may move across (twiddle loads keep hoisting, the
-        // multiply chains of different butterfly groups do not interleave -> bounded register pressure)
-        constexpr int kSchedLoadsOnly = 0x0020 | 0x0004;
-#ifndef SEALHIP_FWD_GROUP_MASK
-#define SEALHIP_FWD_GROUP_MASK 3
-#endif
-        constexpr int kFwdGroupMask = SEALHIP_FWD_GROUP_MASK;
-        // all butterflies of one layer (slot bit W) on the 32 registers; PARITY/STRICT as in ntt_pass_kernel.
-        // UNIFORM: the twiddle index does not depend on the lane (round 1) -> scalar loads.
 #ifndef SEALHIP_NTT_IL
 #define SEALHIP_NTT_IL 4
 #endif
