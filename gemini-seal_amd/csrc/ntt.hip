@@ -98,45 +98,71 @@ namespace sealhip
                     if (DIR == 0)
                     {
                         const bool last = (gb == 0) && !strict;
+                        // eight butterflies per layer, four at a time in lock step (devmath.hpp: butterflies_fwd_hs)
 #pragma unroll
-                        for (int s = 0; s < 16; s++)
+                        for (int c4 = 0; c4 < 8; c4 += 4)
                         {
-                            if (s & bit)
-                                continue;
-                            const ulonglong2 W = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (tb + (s >> (w + 1))));
-                            u64 u = x[s];
-                            if (strict)
-                                u = u >= two_p ? u - two_p : u;
-                            else if (last)
-                                u = barrett_lazy(u, P.rdp, p); // ForwardLazyLast, ntt.cpp:254-261
-                            const u64 v = mulmod_lazy(x[s | bit], W.x, W.y, p);
-                            x[s] = u + v;               // ForwardLazy, ntt.cpp:245-252
-                            x[s | bit] = u - v + two_p;
+                            u64 uu[4], yy[4], ww[4], ws[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                            {
+                                const int s = (((c4 + j) >> w) << (w + 1)) | ((c4 + j) & (bit - 1)); // (c4+j)-th slot with bit w clear
+                                const ulonglong2 W = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (tb + (s >> (w + 1))));
+                                ww[j] = W.x;
+                                ws[j] = W.y;
+                                u64 u = x[s];
+                                if (strict)
+                                    u = u >= two_p ? u - two_p : u;
+                                else if (last)
+                                    u = barrett_lazy(u, P.rdp, p); // ForwardLazyLast, ntt.cpp:254-261
+                                uu[j] = u;
+                                yy[j] = x[s | bit];
+                            }
+                            butterflies_fwd_hs<false, 4>(uu, yy, ww, ws, 0 - p, two_p); // ForwardLazy, ntt.cpp:245-252
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                            {
+                                const int s = (((c4 + j) >> w) << (w + 1)) | ((c4 + j) & (bit - 1));
+                                x[s] = uu[j];
+                                x[s | bit] = yy[j];
+                            }
                         }
                     }
                     else
                     {
+                        // Gentleman-Sande layer, four butterflies in lock step; the top layer (gap N/2) uses the merged
+                        // twiddle psi^-1... * n^-1 on the difference side and multiplies the sum side by n^-1 afterwards
+                        // (BackwardLazyLast, ntt.cpp:274-281)
                         const bool top = gb == logn - 1;
 #pragma unroll
-                        for (int s = 0; s < 16; s++)
+                        for (int c4 = 0; c4 < 8; c4 += 4)
                         {
-                            if (s & bit)
-                                continue;
-                            ulonglong2 W;
-                            if (top)
+                            u64 uu[4], yy[4], ww[4], ws[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
                             {
-                                W.x = P.inv_n_w;
-                                W.y = P.inv_n_w_shoup;
+                                const int s = (((c4 + j) >> w) << (w + 1)) | ((c4 + j) & (bit - 1));
+                                ulonglong2 W;
+                                if (top)
+                                {
+                                    W.x = P.inv_n_w;
+                                    W.y = P.inv_n_w_shoup;
+                                }
+                                else
+                                    W = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (tb + (s >> (w + 1))));
+                                ww[j] = W.x;
+                                ws[j] = W.y;
+                                uu[j] = x[s];
+                                yy[j] = x[s | bit];
                             }
-                            else
-                                W = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (tb + (s >> (w + 1))));
-                            const u64 u = x[s], v = x[s | bit];
-                            u64 tt = u + v;
-                            tt = tt >= two_p ? tt - two_p : tt; // BackwardLazy, ntt.cpp:265-272
-                            if (top)
-                                tt = mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, p); // BackwardLazyLast, :274-281
-                            x[s] = tt;
-                            x[s | bit] = mulmod_lazy(u - v + two_p, W.x, W.y, p);
+                            butterflies_inv_hs<false, 4>(uu, yy, ww, ws, 0 - p, two_p); // BackwardLazy, ntt.cpp:265-272
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                            {
+                                const int s = (((c4 + j) >> w) << (w + 1)) | ((c4 + j) & (bit - 1));
+                                x[s] = top ? mulmod_lazy(uu[j], P.inv_n, P.inv_n_shoup, p) : uu[j];
+                                x[s | bit] = yy[j];
+                            }
                         }
                     }
                 }
