@@ -1065,4 +1065,118 @@ long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uin
     });
 }
 
+/* ------------------------------------------------------------------ encrypt-side arithmetic */
+
+long sealhip_encrypt_zero_symmetric(sealhip_context *ctx, uint32_t rows, int32_t is_ntt_form, const uint64_t *a_ntt,
+                                    const int32_t *noise, const uint64_t *sk_ntt, size_t count, uint64_t *ct)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(a_ntt);
+    REQUIRE_PTR(noise);
+    REQUIRE_PTR(sk_ntt);
+    REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, rows);
+        op_encrypt_zero_symmetric(e, static_cast<int>(rows), is_ntt_form != 0, reinterpret_cast<const u64 *>(a_ntt), noise,
+                                  reinterpret_cast<const u64 *>(sk_ntt), count, reinterpret_cast<u64 *>(ct));
+    });
+}
+
+long sealhip_encrypt_zero_asymmetric(sealhip_context *ctx, uint32_t rows, int32_t is_ntt_form, const uint64_t *pk_ntt,
+                                     const int32_t *u, const int32_t *noise, size_t count, uint64_t *ct)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(pk_ntt);
+    REQUIRE_PTR(u);
+    REQUIRE_PTR(noise);
+    REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, rows);
+        op_encrypt_zero_asymmetric(e, static_cast<int>(rows), is_ntt_form != 0, reinterpret_cast<const u64 *>(pk_ntt), u,
+                                   noise, count, reinterpret_cast<u64 *>(ct));
+    });
+}
+
+long sealhip_multiply_add_plain_with_scaling_variant(sealhip_context *ctx, uint32_t k, const uint64_t *plain,
+                                                     size_t plain_item_stride, uint64_t *ct, uint32_t size, size_t count,
+                                                     int32_t subtract)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (e.scheme != 1)
+            throw std::logic_error("unsupported operation for scheme type");
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        op_scaling_variant(e, static_cast<int>(k), reinterpret_cast<const u64 *>(plain), plain_item_stride,
+                           reinterpret_cast<u64 *>(ct), static_cast<std::size_t>(size) * k * e.n, count, subtract != 0);
+    });
+}
+
+long sealhip_evaluator_add_plain(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                 const uint64_t *plain, size_t plain_item_stride, int32_t subtract)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const std::size_t item = static_cast<std::size_t>(size) * k * e.n;
+        if (e.scheme == 1) // evaluator.cpp:1338-1342 / :1412-1416
+        {
+            op_scaling_variant(e, static_cast<int>(k), reinterpret_cast<const u64 *>(plain), plain_item_stride,
+                               reinterpret_cast<u64 *>(ct), item, count, subtract != 0);
+            return;
+        }
+        // CKKS: c_0 +-= plain, both in NTT form (evaluator.cpp:1344-1350 / :1418-1424)
+        const RowMap map = e.map_for(static_cast<int>(k), SEALHIP_BASE_Q);
+        u64 *c = reinterpret_cast<u64 *>(ct);
+        const u64 *p = reinterpret_cast<const u64 *>(plain);
+        for (std::size_t i = 0; i < count; i++)
+            check_launch(launch_poly_op(e, subtract ? PolyOp::Sub : PolyOp::Add, c + i * item, p + i * plain_item_stride, 0,
+                                        c + i * item, k, map),
+                         "add_plain");
+    });
+}
+
+/* ------------------------------------------------------------------ BatchEncoder */
+
+long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_batching)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(using_batching);
+    *using_batching = ctx->engine->plain_prime >= 0 ? 1 : 0;
+    return SEALHIP_S_OK;
+}
+
+long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(values);
+    REQUIRE_PTR(plain);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        op_batch_encode(e, reinterpret_cast<const u64 *>(values), n_values, count, reinterpret_cast<u64 *>(plain));
+    });
+}
+
+long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    REQUIRE_PTR(values);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        op_batch_decode(e, reinterpret_cast<const u64 *>(plain), count, reinterpret_cast<u64 *>(values));
+    });
+}
+
 } // extern "C"

@@ -72,12 +72,16 @@ namespace sealhip
         // auxiliary 60-bit primes for BEHZ (rns.cpp:587): m_sk, gamma, B_0, B_1, ...
         if (scheme == 1)
             e->aux_primes = get_primes(e->n, 60, static_cast<std::size_t>(n_key) + 3);
-        const int n_primes = n_key + static_cast<int>(e->aux_primes.size());
+        // BFV with a prime plain modulus = 1 (mod 2N): the plain NTT tables BatchEncoder uses (context.cpp:262-275)
+        const bool batching = scheme == 1 && (t - 1) % (2 * static_cast<u64>(e->n)) == 0 && is_prime_u64(t);
+        const int n_primes = n_key + static_cast<int>(e->aux_primes.size()) + (batching ? 1 : 0);
+        if (batching)
+            e->plain_prime = n_primes - 1;
         e->tables.resize(n_primes);
         for (int i = 0; i < n_primes; i++)
         {
-            const u64 p = i < n_key ? e->key_moduli[i] : e->aux_primes[i - n_key];
-            if (i == n_key + 1)
+            const u64 p = i == e->plain_prime ? t : i < n_key ? e->key_moduli[i] : e->aux_primes[i - n_key];
+            if (i == n_key + 1 && i != e->plain_prime)
             {
                 // gamma is never transformed; keep only its modulus
                 e->tables[i].logn = logn;
@@ -177,6 +181,8 @@ namespace sealhip
             (void)hipFree(kv.second);
         for (void *p : owned)
             (void)hipFree(p);
+        if (d_batch_map)
+            (void)hipFree(d_batch_map);
         if (ws)
             (void)hipFree(ws);
         if (d_tickets)
@@ -485,6 +491,27 @@ namespace sealhip
         SEALHIP_CHECK(hipMemcpy(dev, tab.data(), sizeof(std::uint32_t) * n, hipMemcpyHostToDevice));
         galois_tables.emplace(elt, dev);
         return dev;
+    }
+
+    const std::uint32_t *Engine::batch_map()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (d_batch_map)
+            return d_batch_map;
+        // populate_matrix_reps_index_map, batchencoder.cpp:70-94
+        std::vector<std::uint32_t> tab(n);
+        const std::size_t row = n >> 1, m = n << 1;
+        std::uint64_t pos = 1;
+        for (std::size_t i = 0; i < row; i++)
+        {
+            tab[i] = reverse_bits(static_cast<std::uint32_t>((pos - 1) >> 1), logn);
+            tab[row | i] = reverse_bits(static_cast<std::uint32_t>((m - pos - 1) >> 1), logn);
+            pos = (pos * 3) & (m - 1);
+        }
+        SEALHIP_CHECK(hipSetDevice(device));
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_batch_map), sizeof(std::uint32_t) * n));
+        SEALHIP_CHECK(hipMemcpy(d_batch_map, tab.data(), sizeof(std::uint32_t) * n, hipMemcpyHostToDevice));
+        return d_batch_map;
     }
 
     void Engine::ws_reserve(std::size_t bytes)

@@ -170,6 +170,9 @@ namespace sealhip
         std::vector<void *> owned;
         std::map<int, std::unique_ptr<LevelTools>> levels;
         std::map<std::uint32_t, std::uint32_t *> galois_tables; // elt -> device table (galois.cpp:18-47)
+        int plain_prime = -1;                  // prime id of the plain modulus when batching is possible (context.cpp:262-275)
+        std::uint32_t *d_batch_map = nullptr;  // BatchEncoder::matrix_reps_index_map_ (batchencoder.cpp:70-94)
+        const std::uint32_t *batch_map();
         std::mutex mu;
         std::recursive_mutex op_mu; // one operation at a time per context (they share the arena and the stream)
         // profiler
@@ -349,6 +352,48 @@ namespace sealhip
                              std::size_t sk_power_stride, u64 *out, std::size_t count, const RowMap &map, int add_c0);
     hipError_t launch_decrypt_scale_and_round(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, u64 *out,
                                               std::size_t count);
+
+    // ---- encrypt-side arithmetic, scaling variant, BatchEncoder (rlwe.hip) ----
+    struct RlweArgs
+    {
+        u64 *ct;
+        std::size_t ct_item_stride, ct_poly_stride; // words
+        int polys, rows;                            // polynomials written per item; rows (prime ids 0..rows-1)
+        const u64 *x;                               // per-item multiplicand
+        std::size_t x_item_stride, x_poly_stride;
+        const u64 *y; // multiplicand shared by all items (secret key / public key, NTT form)
+        std::size_t y_poly_stride;
+        const std::int32_t *e; // small signed samples, N per polynomial
+        std::size_t e_item_stride, e_poly_stride;
+        int negate;
+    };
+    struct ScalingArgs
+    {
+        const u64 *plain;
+        std::size_t plain_item_stride;
+        u64 *c0;
+        std::size_t c0_item_stride;
+        int k, sub;
+        u64 t, t_cr0, t_cr1, q_mod_t, threshold;
+        u64 div[kMaxModuli]; // floor(q / t) mod q_j  (context.cpp:303-321)
+    };
+    hipError_t launch_rlwe_stage(const Engine &e, int stage, const RlweArgs &a, std::size_t count);
+    hipError_t launch_scaling_variant(const Engine &e, const ScalingArgs &a, std::size_t count);
+    hipError_t launch_batch_permute(const Engine &e, bool encode, const u64 *in, std::size_t in_item_stride,
+                                    std::size_t nvalues, u64 *out, const std::uint32_t *map, std::size_t count);
+    // util/rlwe.cpp:204-300: ct[item] = ([-(a*s + e)]_q, a) over key primes 0..rows-1; a_ntt = count x rows x N
+    // uniform words in NTT form, e = count x N, sk_ntt = rows x N (row stride N)
+    void op_encrypt_zero_symmetric(Engine &e, int rows, bool is_ntt_form, const u64 *a_ntt, const std::int32_t *noise,
+                                   const u64 *sk_ntt, std::size_t count, u64 *ct);
+    // util/rlwe.cpp:140-202: ct[item][j] = pk[j]*u + e[j]; pk = 2 x rows x N (NTT form), u = count x N, e = count x 2 x N
+    void op_encrypt_zero_asymmetric(Engine &e, int rows, bool is_ntt_form, const u64 *pk, const std::int32_t *u,
+                                    const std::int32_t *noise, std::size_t count, u64 *ct);
+    // util/scalingvariant.cpp:15-92 on the c0 of every item (ct_item_stride words apart)
+    void op_scaling_variant(Engine &e, int k, const u64 *plain, std::size_t plain_item_stride, u64 *ct,
+                            std::size_t ct_item_stride, std::size_t count, bool sub);
+    // batchencoder.cpp:113-154 / :339-376 (needs a prime plain modulus = 1 mod 2N: Engine::plain_prime >= 0)
+    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain);
+    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values);
 
     std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
                                         bool strict, int device);

@@ -506,4 +506,192 @@ namespace sealhip
             check(launch_dot_sk(e, ct + off * item, 1, item, sk_powers, sk_stride, out + off * poly, m, map_q, 2), "add c0");
         }
     }
+    // ---------------------------------------------------------------- encrypt-side arithmetic
+    namespace
+    {
+        // rows 0..rows-1 of the key primes for each of `polys` polynomials of an item; `only` >= 0 keeps that polynomial
+        RowMap ct_row_map(int rows, int polys, int only)
+        {
+            if (rows * polys > kMaxRows)
+                throw std::invalid_argument("too many rows");
+            RowMap m{};
+            m.rows = rows * polys;
+            for (int j = 0; j < polys; j++)
+                for (int r = 0; r < rows; r++)
+                    m.prime[j * rows + r] = (only < 0 || only == j) ? static_cast<unsigned short>(r) : kSkipRow;
+            return m;
+        }
+    } // namespace
+
+    void op_encrypt_zero_symmetric(Engine &e, int rows, bool is_ntt_form, const u64 *a_ntt, const std::int32_t *noise,
+                                   const u64 *sk_ntt, std::size_t count, u64 *ct)
+    {
+        const std::size_t N = e.n, poly = static_cast<std::size_t>(rows) * N;
+        u64 *c1 = ct + poly;
+        if (c1 != a_ntt) // c_1 = a, sampled directly in NTT form (rlwe.cpp:245-249)
+            check(launch_copy_rows(e, a_ntt, poly, c1, 2 * poly, count, rows), "copy(a)");
+        RlweArgs a{};
+        a.ct = ct;
+        a.ct_item_stride = 2 * poly;
+        a.ct_poly_stride = poly;
+        a.polys = 1;
+        a.rows = rows;
+        a.x = c1;
+        a.x_item_stride = 2 * poly;
+        a.y = sk_ntt;
+        a.e = noise;
+        a.e_item_stride = N;
+        a.negate = 1;
+        if (is_ntt_form)
+        {
+            // noise to NTT form in the c_0 slot, then c_0 = -(noise + a*s)  (rlwe.cpp:266-284)
+            check(launch_rlwe_stage(e, 0, a, count), "lift(e)");
+            check(launch_ntt(e, ct, count * 2 * rows, ct_row_map(rows, 2, 0), false, kNttCanonical), "ntt(e)");
+            check(launch_rlwe_stage(e, 2, a, count), "c0");
+        }
+        else
+        {
+            // c_0 = a*s back to coefficient form, c_0 = -(noise + c_0), and c_1 to coefficient form (:286-293)
+            check(launch_rlwe_stage(e, 1, a, count), "a*s");
+            check(launch_ntt(e, ct, count * 2 * rows, ct_row_map(rows, 2, -1), true, kNttCanonical), "intt(c0, c1)");
+            check(launch_rlwe_stage(e, 3, a, count), "c0");
+        }
+    }
+
+    void op_encrypt_zero_asymmetric(Engine &e, int rows, bool is_ntt_form, const u64 *pk, const std::int32_t *u,
+                                    const std::int32_t *noise, std::size_t count, u64 *ct)
+    {
+        const std::size_t N = e.n, poly = static_cast<std::size_t>(rows) * N;
+        const std::size_t chunk = plan_chunk(e, count, poly * sizeof(u64), 1);
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *u_ntt = e.ws_alloc(poly * m);
+            RlweArgs a{};
+            // u to RNS + NTT form (rlwe.cpp:161-170)
+            a.ct = u_ntt;
+            a.ct_item_stride = poly;
+            a.polys = 1;
+            a.rows = rows;
+            a.e = u + off * N;
+            a.e_item_stride = N;
+            check(launch_rlwe_stage(e, 0, a, m), "lift(u)");
+            check(launch_ntt(e, u_ntt, m * rows, ct_row_map(rows, 1, -1), false, kNttCanonical), "ntt(u)");
+            // c_j = u * pk_j + e_j  (:171-201)
+            a = RlweArgs{};
+            a.ct = ct + off * 2 * poly;
+            a.ct_item_stride = 2 * poly;
+            a.ct_poly_stride = poly;
+            a.polys = 2;
+            a.rows = rows;
+            a.x = u_ntt;
+            a.x_item_stride = poly;
+            a.x_poly_stride = 0;
+            a.y = pk;
+            a.y_poly_stride = poly;
+            a.e = noise + off * 2 * N;
+            a.e_item_stride = 2 * N;
+            a.e_poly_stride = N;
+            if (is_ntt_form)
+            {
+                check(launch_rlwe_stage(e, 0, a, m), "lift(e)");
+                check(launch_ntt(e, a.ct, m * 2 * rows, ct_row_map(rows, 2, -1), false, kNttCanonical), "ntt(e)");
+                check(launch_rlwe_stage(e, 2, a, m), "c = e + u*pk");
+            }
+            else
+            {
+                check(launch_rlwe_stage(e, 1, a, m), "u*pk");
+                check(launch_ntt(e, a.ct, m * 2 * rows, ct_row_map(rows, 2, -1), true, kNttCanonical), "intt(c)");
+                check(launch_rlwe_stage(e, 3, a, m), "c += e");
+            }
+        }
+    }
+
+    void op_scaling_variant(Engine &e, int k, const u64 *plain, std::size_t plain_item_stride, u64 *ct,
+                            std::size_t ct_item_stride, std::size_t count, bool sub)
+    {
+        if (e.scheme != 1)
+            throw std::invalid_argument("unsupported scheme");
+        ScalingArgs a{};
+        a.plain = plain;
+        a.plain_item_stride = plain_item_stride;
+        a.c0 = ct;
+        a.c0_item_stride = ct_item_stride;
+        a.k = k;
+        a.sub = sub ? 1 : 0;
+        a.t = e.t;
+        HostModulus tm(e.t);
+        a.t_cr0 = tm.cr0;
+        a.t_cr1 = tm.cr1;
+        a.threshold = (e.t + 1) >> 1; // plain_upper_half_threshold, context.cpp:317
+        // coeff_div_plain_modulus = floor(q / t) in RNS form and q mod t (context.cpp:303-321)
+        std::vector<u64> q(static_cast<std::size_t>(k), 0), quot(static_cast<std::size_t>(k), 0);
+        q[0] = 1;
+        for (int i = 0; i < k; i++)
+        {
+            u128 carry = 0;
+            for (int l = 0; l < k; l++)
+            {
+                const u128 v = static_cast<u128>(q[l]) * e.key_moduli[i] + carry;
+                q[l] = static_cast<u64>(v);
+                carry = v >> 64;
+            }
+        }
+        u128 rem = 0;
+        for (int l = k; l-- > 0;)
+        {
+            const u128 cur = (rem << 64) | q[l];
+            quot[l] = static_cast<u64>(cur / e.t);
+            rem = cur % e.t;
+        }
+        a.q_mod_t = static_cast<u64>(rem);
+        for (int j = 0; j < k; j++)
+        {
+            u128 r = 0;
+            for (int l = k; l-- > 0;)
+                r = ((r << 64) | quot[l]) % e.key_moduli[j];
+            a.div[j] = static_cast<u64>(r);
+        }
+        check(launch_scaling_variant(e, a, count), "scaling_variant");
+    }
+
+    // ---------------------------------------------------------------- BatchEncoder
+    namespace
+    {
+        RowMap plain_row_map(const Engine &e)
+        {
+            if (e.plain_prime < 0)
+                throw std::invalid_argument("encryption parameters are not valid for batching"); // batchencoder.cpp:35-38
+            RowMap m{};
+            m.rows = 1;
+            m.prime[0] = static_cast<unsigned short>(e.plain_prime);
+            return m;
+        }
+    } // namespace
+
+    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain)
+    {
+        const RowMap map = plain_row_map(e);
+        if (nvalues > e.n)
+            throw std::logic_error("values_matrix size is too large"); // batchencoder.cpp:119-122
+        check(launch_batch_permute(e, true, values, nvalues, nvalues, plain, e.batch_map(), count), "batch scatter");
+        check(launch_ntt(e, plain, count, map, true, kNttCanonical), "intt(plain)");
+    }
+
+    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values)
+    {
+        const RowMap map = plain_row_map(e);
+        const std::size_t N = e.n;
+        const std::size_t chunk = plan_chunk(e, count, N * sizeof(u64), 1);
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *tmp = e.ws_alloc(N * m);
+            check(launch_copy_rows(e, plain + off * N, N, tmp, N, m, 1), "copy(plain)");
+            check(launch_ntt(e, tmp, m, map, false, kNttCanonical), "ntt(plain)");
+            check(launch_batch_permute(e, false, tmp, N, N, values + off * N, e.batch_map(), m), "batch gather");
+        }
+    }
 } // namespace sealhip

@@ -110,6 +110,13 @@ SYMBOLS = {
     "sealhip_evaluator_rotate_vector": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
     "sealhip_decryptor_dot_product_ct_sk": [_vp, _u32, _vp, _u32, _sz, _vp, _i32, _vp],
     "sealhip_decrypt_scale_and_round": [_vp, _u32, _vp, _sz, _vp],
+    "sealhip_encrypt_zero_symmetric": [_vp, _u32, _i32, _vp, _vp, _vp, _sz, _vp],
+    "sealhip_encrypt_zero_asymmetric": [_vp, _u32, _i32, _vp, _vp, _vp, _sz, _vp],
+    "sealhip_multiply_add_plain_with_scaling_variant": [_vp, _u32, _vp, _sz, _vp, _u32, _sz, _i32],
+    "sealhip_evaluator_add_plain": [_vp, _u32, _vp, _u32, _sz, _vp, _sz, _i32],
+    "sealhip_context_using_batching": [_vp, C.POINTER(_i32)],
+    "sealhip_batch_encode": [_vp, _vp, _sz, _sz, _vp],
+    "sealhip_batch_decode": [_vp, _vp, _sz, _vp],
 }
 
 
@@ -245,6 +252,12 @@ class Context:
         host = np.ascontiguousarray(host, dtype=np.uint64)
         return DeviceBuffer(self, host.size).upload(host)
 
+    def upload_i32(self, host):
+        """small signed samples (int32) -> device; returns a DeviceBuffer holding the raw words"""
+        host = np.ascontiguousarray(host, dtype=np.int32)
+        assert host.size % 2 == 0
+        return DeviceBuffer(self, host.size // 2).upload(host.view(np.uint64))
+
     def synchronize(self):
         _check(lib().sealhip_synchronize(self.handle))
 
@@ -333,6 +346,38 @@ class Context:
     def decrypt_scale_and_round(self, k, poly, count, out):
         """RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126)"""
         _check(lib().sealhip_decrypt_scale_and_round(self.handle, k, _ptr(poly), count, _ptr(out)))
+
+    # ---- SURVEY 8(f2): encrypt-side arithmetic (the random samples come from the caller)
+    def encrypt_zero_symmetric(self, rows, is_ntt_form, a_ntt, noise, sk_ntt, count, ct):
+        """util::encrypt_zero_symmetric (util/rlwe.cpp:204-300); noise = int32 device words (count x N)"""
+        _check(lib().sealhip_encrypt_zero_symmetric(self.handle, rows, 1 if is_ntt_form else 0, _ptr(a_ntt), _ptr(noise),
+                                                    _ptr(sk_ntt), count, _ptr(ct)))
+
+    def encrypt_zero_asymmetric(self, rows, is_ntt_form, pk_ntt, u, noise, count, ct):
+        """util::encrypt_zero_asymmetric (util/rlwe.cpp:140-202); u = count x N, noise = count x 2 x N int32"""
+        _check(lib().sealhip_encrypt_zero_asymmetric(self.handle, rows, 1 if is_ntt_form else 0, _ptr(pk_ntt), _ptr(u),
+                                                     _ptr(noise), count, _ptr(ct)))
+
+    def multiply_add_plain_with_scaling_variant(self, k, plain, ct, size, count, plain_stride=None, subtract=False):
+        """util/scalingvariant.cpp:15-92 on c_0 of every ciphertext"""
+        stride = self.n if plain_stride is None else plain_stride
+        _check(lib().sealhip_multiply_add_plain_with_scaling_variant(self.handle, k, _ptr(plain), stride, _ptr(ct), size,
+                                                                     count, 1 if subtract else 0))
+
+    # ---- SURVEY 8(f4): BatchEncoder
+    @property
+    def using_batching(self):
+        flag = _i32(0)
+        _check(lib().sealhip_context_using_batching(self.handle, C.byref(flag)))
+        return bool(flag.value)
+
+    def batch_encode(self, values, n_values, count, plain):
+        """BatchEncoder::encode (batchencoder.cpp:113-154)"""
+        _check(lib().sealhip_batch_encode(self.handle, _ptr(values), n_values, count, _ptr(plain)))
+
+    def batch_decode(self, plain, count, values):
+        """BatchEncoder::decode (batchencoder.cpp:339-376)"""
+        _check(lib().sealhip_batch_decode(self.handle, _ptr(plain), count, _ptr(values)))
 
     def negate_poly_coeffmod(self, a, count, k, result, base=BASE_Q):
         _check(lib().sealhip_negate_poly_coeffmod(self.handle, _ptr(a), count, k, base, _ptr(result)))
@@ -454,6 +499,17 @@ class Evaluator:
             ntt_form = self.ctx.scheme == SCHEME_CKKS
         fn = lib().sealhip_evaluator_multiply_plain_ntt if ntt_form else lib().sealhip_evaluator_multiply_plain
         _check(fn(self.ctx.handle, k, _ptr(ct), size, count, _ptr(plain), plain_stride))
+
+    def add_plain_inplace(self, ct, size, k, count, plain, plain_stride=None, subtract=False):
+        """Evaluator::add_plain_inplace / sub_plain_inplace (evaluator.cpp:1290-1435): BFV plain = N coefficients < t,
+        CKKS plain = k x N in NTT form"""
+        if plain_stride is None:
+            plain_stride = self.ctx.n if self.ctx.scheme == SCHEME_BFV else k * self.ctx.n
+        _check(lib().sealhip_evaluator_add_plain(self.ctx.handle, k, _ptr(ct), size, count, _ptr(plain), plain_stride,
+                                                 1 if subtract else 0))
+
+    def sub_plain_inplace(self, ct, size, k, count, plain, plain_stride=None):
+        self.add_plain_inplace(ct, size, k, count, plain, plain_stride, subtract=True)
 
     def check_not_transparent(self, ct, size, k, count):
         """evaluator.cpp:265-271 (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT)"""

@@ -238,6 +238,41 @@ long sealhip_decryptor_dot_product_ct_sk(sealhip_context *ctx, uint32_t k, const
 /* RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126), BFV: in[count][k][N] -> out[count][N] coefficients mod t */
 long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
 
+/* ---------------------------------------------------------------- encrypt-side arithmetic */
+/* util::encrypt_zero_symmetric (util/rlwe.cpp:204-300) with the random samples handed in (sampling and the CSPRNG
+   stay on the host): ct[count][2][rows][N] = ([-(a*s + e)]_q, a) over key primes 0..rows-1 (rows = n_key_moduli for
+   key generation, keygenerator.cpp:347; rows = the level's k for Encryptor::encrypt_zero_internal, encryptor.cpp:183).
+   a_ntt[count][rows][N]: uniform residues, taken to be in NTT form as the reference samples them (:245-249);
+   noise[count][N]: small signed error coefficients (sample_poly_normal, :61-95); sk_ntt: rows x N, NTT form.
+   is_ntt_form != 0 leaves the ciphertext in NTT form (CKKS, keys), 0 in coefficient form (BFV). Device memory. */
+long sealhip_encrypt_zero_symmetric(sealhip_context *ctx, uint32_t rows, int32_t is_ntt_form, const uint64_t *a_ntt,
+                                    const int32_t *noise, const uint64_t *sk_ntt, size_t count, uint64_t *ct);
+/* util::encrypt_zero_asymmetric (util/rlwe.cpp:140-202): ct[count][2][rows][N], ct_j = pk_j * u + e_j.
+   pk_ntt[2][rows][N] (NTT form); u[count][N] ternary (sample_poly_ternary, :25-59); noise[count][2][N]. */
+long sealhip_encrypt_zero_asymmetric(sealhip_context *ctx, uint32_t rows, int32_t is_ntt_form, const uint64_t *pk_ntt,
+                                     const int32_t *u, const int32_t *noise, size_t count, uint64_t *ct);
+/* util::multiply_add_plain_with_scaling_variant / multiply_sub_plain_with_scaling_variant
+   (util/scalingvariant.cpp:15-52 / :54-92) on c_0 of every ciphertext: the last step of Encryptor::encrypt for BFV
+   (encryptor.cpp:221-225) and Evaluator::add_plain_inplace / sub_plain_inplace for BFV (evaluator.cpp:1338-1342).
+   plain[count][N] coefficients < t (plain_item_stride words apart; 0 = one plaintext for all);
+   ct[count][size][k][N] in place. */
+long sealhip_multiply_add_plain_with_scaling_variant(sealhip_context *ctx, uint32_t k, const uint64_t *plain,
+                                                     size_t plain_item_stride, uint64_t *ct, uint32_t size, size_t count,
+                                                     int32_t subtract);
+/* Evaluator::add_plain_inplace / sub_plain_inplace (evaluator.cpp:1290-1435): BFV = the scaling variant above;
+   CKKS = add/sub_poly_coeffmod of the NTT-form plaintext plain[count][k][N] on c_0. */
+long sealhip_evaluator_add_plain(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count,
+                                 const uint64_t *plain, size_t plain_item_stride, int32_t subtract);
+
+/* ---------------------------------------------------------------- BatchEncoder */
+/* 1 when the context can batch: BFV with a prime plain modulus = 1 (mod 2N) (context.cpp:262-275, qualifiers().using_batching) */
+long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_batching);
+/* BatchEncoder::encode (batchencoder.cpp:113-154): values[count][n_values] (n_values <= N, each < t; missing slots are
+   zero) -> plain[count][N] coefficients; BatchEncoder::decode (:339-376): plain[count][N] -> values[count][N].
+   E_INVALIDARG when the parameters do not support batching. Device memory. */
+long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain);
+long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1587,18 +1587,26 @@ void ref_small_poly_to_rns(const ref_context *c, const int8_t *s, size_t rows, i
     }
 }
 
-void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
-                                uint64_t *state, uint64_t *ct)
+static void small32_to_rns(const ref_context *c, const int32_t *s, size_t rows, uint64_t *out)
+{
+    const size_t n = c->n;
+    for (size_t r = 0; r < rows; r++) /* the representation sample_poly_ternary/normal write, util/rlwe.cpp:25-95 */
+    {
+        const uint64_t p = c->key_mod[r].value;
+        for (size_t i = 0; i < n; i++)
+            out[r * n + i] = s[i] >= 0 ? (uint64_t)s[i] : p - (uint64_t)(-(int64_t)s[i]);
+    }
+}
+
+void ref_encrypt_zero_symmetric_given(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
+                                      const uint64_t *a_ntt, const int32_t *e, uint64_t *ct)
 {
     const size_t n = c->n;
     uint64_t *c0 = ct, *c1 = ct + rows * n;
-    int8_t *e = (int8_t *)malloc(n);
     uint64_t *noise = (uint64_t *)malloc(sizeof(uint64_t) * rows * n);
-    for (size_t r = 0; r < rows; r++) /* rlwe.cpp:245-249: a sampled directly in NTT form */
-        for (size_t i = 0; i < n; i++)
-            c1[r * n + i] = ref_splitmix64(state) % c->key_mod[r].value;
-    ref_sample_noise(e, n, state);
-    ref_small_poly_to_rns(c, e, rows, 0, noise);
+    if (c1 != a_ntt)
+        memcpy(c1, a_ntt, sizeof(uint64_t) * rows * n); /* rlwe.cpp:245-249: a sampled directly in NTT form */
+    small32_to_rns(c, e, rows, noise);
     for (size_t r = 0; r < rows; r++) /* rlwe.cpp:266-284 */
     {
         const ref_modulus *m = &c->key_mod[r];
@@ -1612,8 +1620,59 @@ void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_
         if (!is_ntt_form) /* :286-293 */
             ref_ntt_inverse(c1 + r * n, &c->key_tables[r]);
     }
-    free(e);
     free(noise);
+}
+
+void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
+                                uint64_t *state, uint64_t *ct)
+{
+    const size_t n = c->n;
+    uint64_t *c1 = ct + rows * n;
+    int8_t *e = (int8_t *)malloc(n);
+    int32_t *e32 = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (size_t r = 0; r < rows; r++)
+        for (size_t i = 0; i < n; i++)
+            c1[r * n + i] = ref_splitmix64(state) % c->key_mod[r].value;
+    ref_sample_noise(e, n, state);
+    for (size_t i = 0; i < n; i++)
+        e32[i] = e[i];
+    ref_encrypt_zero_symmetric_given(c, rows, sk_ntt, is_ntt_form, c1, e32, ct);
+    free(e);
+    free(e32);
+}
+
+/* util/rlwe.cpp:140-202 with the samples handed in: u ternary, e = two noise polynomials (size-2 public key);
+ * pk = 2 x rows x N in NTT form; ct[j] = pk[j] * u + e[j] */
+void ref_encrypt_zero_asymmetric_given(const ref_context *c, size_t rows, const uint64_t *pk, int is_ntt_form,
+                                       const int32_t *u, const int32_t *e, uint64_t *ct)
+{
+    const size_t n = c->n;
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * rows * n);
+    small32_to_rns(c, u, rows, tmp);
+    for (size_t r = 0; r < rows; r++) /* :168-185 */
+    {
+        const ref_modulus *m = &c->key_mod[r];
+        ref_ntt_forward(tmp + r * n, &c->key_tables[r], 0);
+        for (size_t j = 0; j < 2; j++)
+        {
+            uint64_t *dst = ct + (j * rows + r) * n;
+            ref_dyadic_product_coeffmod(tmp + r * n, pk + (j * rows + r) * n, n, m, dst);
+            if (!is_ntt_form)
+                ref_ntt_inverse(dst, &c->key_tables[r]);
+        }
+    }
+    for (size_t j = 0; j < 2; j++) /* :187-201 */
+    {
+        small32_to_rns(c, e + j * n, rows, tmp);
+        for (size_t r = 0; r < rows; r++)
+        {
+            uint64_t *dst = ct + (j * rows + r) * n;
+            if (is_ntt_form)
+                ref_ntt_forward(tmp + r * n, &c->key_tables[r], 0);
+            ref_add_poly_coeffmod(tmp + r * n, dst, n, &c->key_mod[r], dst);
+        }
+    }
+    free(tmp);
 }
 
 /* q = prod of the first k key primes as little-endian 64-bit limbs */
@@ -1652,12 +1711,13 @@ static uint64_t big_mod_word(const uint64_t *num, size_t k, uint64_t d)
     return (uint64_t)rem;
 }
 
-void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
-                               uint64_t *state, uint64_t *ct)
+/* util/scalingvariant.cpp:15-52 (sub = 0) and :54-92 (sub != 0): c0 +-= round(q * plain / t) over the first k primes;
+ * plain = n coefficients < t, c0 = k x N */
+void ref_multiply_add_plain_with_scaling_variant(const ref_context *c, size_t k, const uint64_t *plain, int sub,
+                                                 uint64_t *c0)
 {
     const size_t n = c->n;
     const uint64_t t = c->t;
-    ref_encrypt_zero_symmetric(c, k, sk_ntt, 0, state, ct);
     /* context.cpp:303-321: coeff_div_plain_modulus = floor(q / t) in RNS form, q mod t, (t + 1) / 2 */
     uint64_t q[64], quot[64];
     big_product(c, k, q);
@@ -1673,10 +1733,76 @@ void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *s
             const uint64_t div_j = big_mod_word(quot, k, m->value);
             const unsigned __int128 z = (unsigned __int128)div_j * plain[i] + fix; /* multiply_add_uint_mod */
             const uint64_t scaled = ref_barrett_reduce_128((uint64_t)z, (uint64_t)(z >> 64), m);
-            const uint64_t sum = scaled + ct[j * n + i];
-            ct[j * n + i] = sum >= m->value ? sum - m->value : sum;
+            if (sub)
+            {
+                const uint64_t x = c0[j * n + i]; /* sub_uint64_mod */
+                c0[j * n + i] = x >= scaled ? x - scaled : x + m->value - scaled;
+            }
+            else
+            {
+                const uint64_t sum = scaled + c0[j * n + i];
+                c0[j * n + i] = sum >= m->value ? sum - m->value : sum;
+            }
         }
     }
+}
+
+void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
+                               uint64_t *state, uint64_t *ct)
+{
+    ref_encrypt_zero_symmetric(c, k, sk_ntt, 0, state, ct);
+    ref_multiply_add_plain_with_scaling_variant(c, k, plain, 0, ct);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BatchEncoder (batchencoder.cpp). plain_tables = NTTTables(logn, t) (context.cpp:262-275).
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t bitrev32(uint32_t x, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++)
+        r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+/* batchencoder.cpp:70-94 */
+void ref_batch_index_map(int logn, uint32_t *map)
+{
+    const size_t n = (size_t)1 << logn, row = n >> 1, m = n << 1;
+    uint64_t pos = 1;
+    for (size_t i = 0; i < row; i++)
+    {
+        map[i] = bitrev32((uint32_t)((pos - 1) >> 1), logn);
+        map[row | i] = bitrev32((uint32_t)((m - pos - 1) >> 1), logn);
+        pos = (pos * 3) & (m - 1);
+    }
+}
+
+/* batchencoder.cpp:113-154: values (count <= n, each < t) -> plaintext coefficients */
+void ref_batch_encode(const ref_ntt_tables *plain_tables, const uint64_t *values, size_t count, uint64_t *plain)
+{
+    const size_t n = plain_tables->n;
+    uint32_t *map = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    ref_batch_index_map(plain_tables->logn, map);
+    for (size_t i = 0; i < n; i++)
+        plain[map[i]] = i < count ? values[i] : 0;
+    ref_ntt_inverse(plain, plain_tables);
+    free(map);
+}
+
+/* batchencoder.cpp:339-376: plaintext coefficients (count <= n) -> n values */
+void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, uint64_t *values)
+{
+    const size_t n = plain_tables->n;
+    uint32_t *map = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint64_t *tmp = (uint64_t *)calloc(n, sizeof(uint64_t));
+    ref_batch_index_map(plain_tables->logn, map);
+    memcpy(tmp, plain, sizeof(uint64_t) * (count < n ? count : n));
+    ref_ntt_forward(tmp, plain_tables, 0);
+    for (size_t i = 0; i < n; i++)
+        values[i] = tmp[map[i]];
+    free(tmp);
+    free(map);
 }
 
 void ref_generate_kswitch_key(const ref_context *c, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,

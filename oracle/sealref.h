@@ -212,6 +212,19 @@ void ref_small_poly_to_rns(const ref_context *c, const int8_t *s, size_t rows, i
    sk_ntt = secret key in NTT form (row stride n) */
 void ref_encrypt_zero_symmetric(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
                                 uint64_t *state, uint64_t *ct);
+/* the same with the samples handed in (a uniform in NTT form, e small signed); a_ntt may alias c1 */
+void ref_encrypt_zero_symmetric_given(const ref_context *c, size_t rows, const uint64_t *sk_ntt, int is_ntt_form,
+                                      const uint64_t *a_ntt, const int32_t *e, uint64_t *ct);
+/* util/rlwe.cpp:140-202 with the samples handed in: pk = 2 x rows x N (NTT form), u ternary, e = 2 x N noise */
+void ref_encrypt_zero_asymmetric_given(const ref_context *c, size_t rows, const uint64_t *pk, int is_ntt_form,
+                                       const int32_t *u, const int32_t *e, uint64_t *ct);
+/* util/scalingvariant.cpp:15-52 / :54-92: c0 (k x N) +-= round(q * plain / t); Evaluator::add_plain / sub_plain for BFV */
+void ref_multiply_add_plain_with_scaling_variant(const ref_context *c, size_t k, const uint64_t *plain, int sub,
+                                                 uint64_t *c0);
+/* ---- BatchEncoder (batchencoder.cpp:70-154, :339-376); plain_tables = NTTTables(logn, t) ---- */
+void ref_batch_index_map(int logn, uint32_t *map);
+void ref_batch_encode(const ref_ntt_tables *plain_tables, const uint64_t *values, size_t count, uint64_t *plain);
+void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, uint64_t *values);
 /* Encryptor::encrypt (BFV, symmetric): encrypt_zero + multiply_add_plain_with_scaling_variant (util/scalingvariant.cpp:15-52) */
 void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
                                uint64_t *state, uint64_t *ct);

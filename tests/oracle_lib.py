@@ -194,6 +194,20 @@ def lib():
     L.ref_dot_product_ct_sk.restype = None
     L.ref_dot_product_ct_sk.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_int, C.c_void_p, C.c_void_p]
     L.ref_decrypt_scale_and_round.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p]
+    L.ref_encrypt_zero_symmetric_given.restype = None
+    L.ref_encrypt_zero_symmetric_given.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
+    L.ref_encrypt_zero_asymmetric_given.restype = None
+    L.ref_encrypt_zero_asymmetric_given.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]
+    L.ref_multiply_add_plain_with_scaling_variant.restype = None
+    L.ref_multiply_add_plain_with_scaling_variant.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_int, C.c_void_p]
+    L.ref_batch_index_map.restype = None
+    L.ref_batch_index_map.argtypes = [C.c_int, C.c_void_p]
+    L.ref_batch_encode.restype = None
+    L.ref_batch_encode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
+    L.ref_batch_decode.restype = None
+    L.ref_batch_decode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]
@@ -202,7 +216,7 @@ def lib():
 
 
 def ptr(a):
-    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype in (np.uint64, np.int32, np.uint32) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 

@@ -946,3 +946,199 @@ def test_randomised_differential_against_oracle(sealhip):
     rng = np.random.default_rng(2024)
     done = sum(fz.one(rng, it) != "skip" for it in range(16))
     assert done >= 8
+
+
+# ---------------------------------------------------------------- encrypt-side arithmetic on the device
+@pytest.mark.parametrize("scheme,logn,bits,nsp,t", [(1, 5, [30, 30, 31], 1, 257), (1, 11, [45] * 4, 2, 65537),
+                                                     (2, 13, [50] * 3, 1, 0), (1, 14, [55] * 3, 1, 786433)])
+def test_f2_encrypt_zero_parity(sealhip, scheme, logn, bits, nsp, t):
+    """encrypt_zero_symmetric / encrypt_zero_asymmetric (util/rlwe.cpp:140-300) with the same samples on both sides:
+    bit-exact against the oracle in both output forms, at key level and at the first ciphertext level."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t)
+    ctx = sealhip.Context(scheme, logn, kmods, nsp, t)
+    rng = np.random.default_rng(logn)
+    count = 3
+    sk = rand_rows(rng, kmods, n)
+    dsk = ctx.upload(sk)
+    for rows in (len(kmods), len(kmods) - nsp):
+        a = np.stack([rand_rows(rng, kmods[:rows], n) for _ in range(count)])
+        e = rng.integers(-19, 20, size=(count, n)).astype(np.int32)
+        e[0, :4] = [-19, 19, 0, -1]
+        pk = np.stack([rand_rows(rng, kmods[:rows], n) for _ in range(2)])
+        u = rng.integers(-1, 2, size=(count, n)).astype(np.int32)
+        e2 = rng.integers(-19, 20, size=(count, 2, n)).astype(np.int32)
+        for ntt_form in (True, False):
+            out = ctx.alloc(count * 2 * rows * n)
+            # the secret key keeps its key-level row stride N: rows 0..rows-1 are its first rows
+            ctx.encrypt_zero_symmetric(rows, ntt_form, ctx.upload(a), ctx.upload_i32(e), dsk, count, out)
+            got = out.download((count, 2, rows, n))
+            for i in range(count):
+                exp = np.zeros((2, rows, n), dtype=np.uint64)
+                L.ref_encrypt_zero_symmetric_given(C.byref(ref.c), rows, O.ptr(sk), 1 if ntt_form else 0,
+                                                   O.ptr(a[i]), O.ptr(e[i]), O.ptr(exp))
+                assert np.array_equal(got[i], exp), (rows, ntt_form, i)
+            # in place: a already sits in the c_1 slot
+            buf = np.zeros((count, 2, rows, n), dtype=np.uint64)
+            buf[:, 1] = a
+            dbuf = ctx.upload(buf)
+            ctx.encrypt_zero_symmetric(rows, ntt_form, dbuf.ptr + rows * n * 8, ctx.upload_i32(e), dsk, count, dbuf)
+            assert np.array_equal(dbuf.download(got.shape), got)
+            ctx.encrypt_zero_asymmetric(rows, ntt_form, ctx.upload(pk), ctx.upload_i32(u), ctx.upload_i32(e2), count, out)
+            got = out.download((count, 2, rows, n))
+            for i in range(count):
+                exp = np.zeros((2, rows, n), dtype=np.uint64)
+                L.ref_encrypt_zero_asymmetric_given(C.byref(ref.c), rows, O.ptr(pk), 1 if ntt_form else 0,
+                                                    O.ptr(u[i]), O.ptr(e2[i]), O.ptr(exp))
+                assert np.array_equal(got[i], exp), (rows, ntt_form, i)
+
+
+@pytest.mark.parametrize("logn,bits,t", [(4, [30, 31], 2), (10, [40] * 3, 65537), (12, [60, 60, 60], (1 << 60) - 93),
+                                         (13, [50] * 4, 1 << 20)])
+def test_f2_scaling_variant_add_sub_plain(sealhip, logn, bits, t):
+    """multiply_add/sub_plain_with_scaling_variant (util/scalingvariant.cpp:15-92) = BFV add_plain / sub_plain:
+    bit-exact for small, large (60-bit), prime and power-of-two plain moduli; sub undoes add."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits + [bits[-1]])
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(logn)
+    count, size = 3, 2
+    for k in (len(bits), 1):
+        ct = np.stack([_rand_ct(rng, kmods[:k], size, n, 1)[0] for _ in range(count)])
+        plain = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+        plain[0, :3] = [0, t - 1, t // 2]
+        d = ctx.upload(ct)
+        ev.add_plain_inplace(d, size, k, count, ctx.upload(plain))
+        got = d.download(ct.shape)
+        exp = ct.copy()
+        for i in range(count):
+            L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(plain[i]), 0, O.ptr(exp[i, 0]))
+        assert np.array_equal(got, exp), k
+        ev.sub_plain_inplace(d, size, k, count, ctx.upload(plain))
+        assert np.array_equal(d.download(ct.shape), ct)
+        ev.sub_plain_inplace(d, size, k, count, ctx.upload(plain[0]), plain_stride=0)  # one plaintext for all
+        exp = ct.copy()
+        for i in range(count):
+            L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(plain[0]), 1, O.ptr(exp[i, 0]))
+        assert np.array_equal(d.download(ct.shape), exp)
+
+
+def test_f2_ckks_add_plain(sealhip):
+    logn, n = 10, 1024
+    kmods = O.coeff_modulus_create(n, [40] * 4)
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(3)
+    k, count = 3, 2
+    ct = np.stack([_rand_ct(rng, kmods[:k], 2, n, 1)[0] for _ in range(count)])
+    plain = np.stack([rand_rows(rng, kmods[:k], n) for _ in range(count)])
+    d = ctx.upload(ct)
+    ev.add_plain_inplace(d, 2, k, count, ctx.upload(plain))
+    got = d.download(ct.shape)
+    mods = np.array(kmods[:k], dtype=np.uint64)[:, None]
+    assert np.array_equal(got[:, 0], (ct[:, 0] + plain) % mods) and np.array_equal(got[:, 1], ct[:, 1])
+    ev.sub_plain_inplace(d, 2, k, count, ctx.upload(plain))
+    assert np.array_equal(d.download(ct.shape), ct)
+
+
+def test_f2_public_key_encrypt_on_gpu_decrypt_on_gpu(sealhip):
+    """Encryptor::encrypt with a public key, every arithmetic step on the device (encrypt_zero_asymmetric at key level,
+    divide_and_round_q_last to the first level, + round(q m / t)), then multiply in STRICT mode and decrypt on the device."""
+    logn, n, t, nsp = 12, 4096, 65537, 1
+    kmods = O.coeff_modulus_create(n, [45] * 4)
+    ref = O.RefContext(1, logn, kmods, nsp=nsp, t=t, mode=1)
+    cl = O.Client(ref, seed=4)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, nsp, t, mode=sealhip.MODE_STRICT)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(8)
+    n_key, k, count = cl.n_key, cl.k, 2
+    dsk = ctx.upload(cl.sk)
+    a = rand_rows(rng, kmods, n)[None]
+    pk = ctx.alloc(2 * n_key * n)
+    ctx.encrypt_zero_symmetric(n_key, True, ctx.upload(a), ctx.upload_i32(rng.integers(-6, 7, size=(1, n))), dsk, 1, pk)
+
+    def encrypt(m):
+        u = rng.integers(-1, 2, size=(count, n)).astype(np.int32)
+        e = rng.integers(-6, 7, size=(count, 2, n)).astype(np.int32)
+        big = ctx.alloc(count * 2 * n_key * n)
+        ctx.encrypt_zero_asymmetric(n_key, False, pk, ctx.upload_i32(u), ctx.upload_i32(e), count, big)
+        ctx.divide_and_round_q_last_inplace(n_key, big, count * 2)
+        ct = ctx.upload(big.download((count, 2, n_key, n))[:, :, :k].copy())
+        ev.add_plain_inplace(ct, 2, k, count, ctx.upload(m))
+        return ct
+
+    m1 = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    m2 = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    c1, c2 = encrypt(m1), encrypt(m2)
+    pw = ctx.upload(cl.sk_powers(2))
+
+    def decrypt(dct, size):
+        dot = ctx.alloc(count * k * n)
+        ctx.dot_product_ct_sk(dct, size, k, count, pw, False, dot)
+        out = ctx.alloc(count * n)
+        ctx.decrypt_scale_and_round(k, dot, count, out)
+        return out.download((count, n))
+
+    assert np.array_equal(decrypt(c1, 2), m1)
+    prod = ctx.alloc(count * 3 * k * n)
+    ev.multiply(c1, 2, c2, 2, k, count, prod)
+    want = np.stack([O.negacyclic_mod_t(x, y, t) for x, y in zip(m1, m2)])
+    assert np.array_equal(decrypt(prod, 3), want)
+
+
+# ---------------------------------------------------------------- SURVEY 8(f4): BatchEncoder on the device
+@pytest.mark.parametrize("logn,t", [(6, 257), (12, 65537), (13, 786433), (15, 786433), (16, 786433)])
+def test_f4_batch_encoder_parity(sealhip, logn, t):
+    """BatchEncoder::encode / decode (batchencoder.cpp:113-154, :339-376): bit-exact against the oracle, the
+    reference's own known answers (all-5 -> the constant 5; zero padding), round trip and slot-wise products."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, [50, 50])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    assert ctx.using_batching
+    tb = O.Tables(logn, t)
+    rng = np.random.default_rng(logn)
+    count = 4
+    vals = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    vals[0] = 5
+    vals[1] = np.arange(n) % t
+    plain = ctx.alloc(count * n)
+    ctx.batch_encode(ctx.upload(vals), n, count, plain)
+    got = plain.download((count, n))
+    for i in range(count):
+        exp = np.zeros(n, dtype=np.uint64)
+        L.ref_batch_encode(C.byref(tb.t), O.ptr(vals[i]), n, O.ptr(exp))
+        assert np.array_equal(got[i], exp), i
+    assert got[0, 0] == 5 and not got[0, 1:].any()
+    back = ctx.alloc(count * n)
+    ctx.batch_decode(plain, count, back)
+    assert np.array_equal(back.download((count, n)), vals)
+    # short input: the remaining slots are zero
+    nv = 20
+    ctx.batch_encode(ctx.upload(vals[:, :nv].copy()), nv, count, plain)
+    ctx.batch_decode(plain, count, back)
+    res = back.download((count, n))
+    assert np.array_equal(res[:, :nv], vals[:, :nv]) and not res[:, nv:].any()
+    # decode of arbitrary plaintexts against the oracle
+    pl = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    ctx.batch_decode(ctx.upload(pl), count, back)
+    res = back.download((count, n))
+    for i in range(count):
+        exp = np.zeros(n, dtype=np.uint64)
+        L.ref_batch_decode(C.byref(tb.t), O.ptr(pl[i]), n, O.ptr(exp))
+        assert np.array_equal(res[i], exp), i
+
+
+def test_f4_batching_unavailable_is_reported(sealhip):
+    n = 1024
+    kmods = O.coeff_modulus_create(n, [40, 40])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, 10, kmods, 1, 1 << 16)  # not prime
+    assert not ctx.using_batching
+    buf = ctx.alloc(n)
+    with pytest.raises(ValueError):
+        ctx.batch_encode(buf, n, 1, buf)
+    ctx2 = sealhip.Context(sealhip.SCHEME_BFV, 10, kmods, 1, 65537)
+    with pytest.raises(sealhip.LogicError):  # batchencoder.cpp:119-122
+        ctx2.batch_encode(ctx2.alloc(n + 1), n + 1, 1, ctx2.alloc(n))

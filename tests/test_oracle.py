@@ -452,3 +452,105 @@ def test_f2_bfv_semantics_strict_and_the_forks_relinearize(nsp):
                 else:
                     perm[j - n] = (t - int(m1[i])) % t
             assert np.array_equal(cl.decrypt_bfv(g), perm)
+
+
+# ---------------------------------------------------------------- public-key encryption, add_plain / sub_plain
+def _keypair(ref, cl, rng):
+    """KeyGenerator::generate_pk (keygenerator.cpp:114-130): pk = encrypt_zero_symmetric at key level, NTT form"""
+    n, n_key = cl.n, cl.n_key
+    a = np.stack([rng.integers(0, p, size=n, dtype=np.uint64) for p in cl.mods])
+    e = rng.integers(-6, 7, size=n).astype(np.int32)
+    pk = np.zeros((2, n_key, n), dtype=np.uint64)
+    L.ref_encrypt_zero_symmetric_given(C.byref(ref.c), n_key, O.ptr(cl.sk), 1, O.ptr(a), O.ptr(e), O.ptr(pk))
+    return pk
+
+
+def test_f2_asymmetric_encrypt_add_plain_semantics():
+    """Encryptor::encrypt with a public key (encryptor.cpp:146-171, 221-225): encrypt_zero_asymmetric at key level,
+    divide_and_round_q_last to the first level, + round(q m / t); it decrypts to m. add_plain / sub_plain shift the
+    plaintext by the added polynomial (evaluator.cpp:1338-1342). Pins the restatements of rlwe.cpp:140-202 and
+    scalingvariant.cpp:15-92 through the scheme's semantics."""
+    logn, n, t = 8, 256, 65537
+    kmods = O.coeff_modulus_create(n, [40, 40, 41])
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t, mode=1)
+    cl = O.Client(ref, seed=11)
+    rng = np.random.default_rng(5)
+    pk = _keypair(ref, cl, rng)
+    n_key, k = cl.n_key, cl.k
+    u = rng.integers(-1, 2, size=n).astype(np.int32)
+    e = rng.integers(-6, 7, size=(2, n)).astype(np.int32)
+    big = np.zeros((2, n_key, n), dtype=np.uint64)
+    L.ref_encrypt_zero_asymmetric_given(C.byref(ref.c), n_key, O.ptr(pk), 0, O.ptr(u), O.ptr(e), O.ptr(big))
+    ct = np.zeros((2, k, n), dtype=np.uint64)
+    for j in range(2):
+        L.ref_divide_and_round_q_last_inplace(ref.rns_tool(n_key), O.ptr(big[j]))
+        ct[j] = big[j, :k]
+    assert np.array_equal(cl.decrypt_bfv(ct), np.zeros(n, dtype=np.uint64))  # an encryption of zero
+    m1 = rng.integers(0, t, size=n, dtype=np.uint64)
+    m2 = rng.integers(0, t, size=n, dtype=np.uint64)
+    L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(m1), 0, O.ptr(ct[0]))
+    assert np.array_equal(cl.decrypt_bfv(ct), m1)
+    keep = ct.copy()
+    L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(m2), 0, O.ptr(ct[0]))
+    assert np.array_equal(cl.decrypt_bfv(ct), (m1 + m2) % t)
+    L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(m2), 1, O.ptr(ct[0]))
+    assert np.array_equal(ct, keep)  # sub undoes add exactly
+    L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(m2), 1, O.ptr(ct[0]))
+    assert np.array_equal(cl.decrypt_bfv(ct), (m1 + t - m2) % t)
+    # NTT-form variant of the asymmetric encryption = the forward transform of the coefficient-form one when noise is zero
+    z = np.zeros((2, n), dtype=np.int32)
+    c_ntt = np.zeros((2, n_key, n), dtype=np.uint64)
+    c_coef = np.zeros((2, n_key, n), dtype=np.uint64)
+    L.ref_encrypt_zero_asymmetric_given(C.byref(ref.c), n_key, O.ptr(pk), 1, O.ptr(u), O.ptr(z), O.ptr(c_ntt))
+    L.ref_encrypt_zero_asymmetric_given(C.byref(ref.c), n_key, O.ptr(pk), 0, O.ptr(u), O.ptr(z), O.ptr(c_coef))
+    for j in range(2):
+        for r in range(n_key):
+            L.ref_ntt_forward(O.ptr(c_coef[j, r]), ref.tables(r), 0)
+    assert np.array_equal(c_ntt, c_coef)
+
+
+# ---------------------------------------------------------------- SURVEY 8(f4): BatchEncoder
+def test_f4_batch_encoder_reference_kats_and_slot_semantics():
+    """The reference's own expectations (native/tests/seal/batchencoder.cpp:18-69, 124-175: N = 64, t = 257; the all-5
+    matrix encodes to the constant polynomial 5; encode/decode round-trips; short inputs are zero-padded), plus the
+    semantics batchencoder.h documents: slot-wise products under polynomial multiplication and a row rotation under
+    the automorphism x -> x^3."""
+    logn, n, t = 6, 64, 257
+    tb = O.Tables(logn, t)
+    vals = np.arange(n, dtype=np.uint64)
+    plain = np.zeros(n, dtype=np.uint64)
+    back = np.zeros(n, dtype=np.uint64)
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(vals), n, O.ptr(plain))
+    L.ref_batch_decode(C.byref(tb.t), O.ptr(plain), n, O.ptr(back))
+    assert np.array_equal(back, vals)
+    five = np.full(n, 5, dtype=np.uint64)
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(five), n, O.ptr(plain))
+    assert plain[0] == 5 and not plain[1:].any()  # plain.to_string() == "5"
+    short = np.arange(20, dtype=np.uint64)
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(short), 20, O.ptr(plain))
+    L.ref_batch_decode(C.byref(tb.t), O.ptr(plain), n, O.ptr(back))
+    assert np.array_equal(back[:20], short) and not back[20:].any()
+    # BatchUnbatchPlaintext (:124-175): encode of the matrix read from a plaintext with coefficients 0..63 round-trips
+    L.ref_batch_decode(C.byref(tb.t), O.ptr(vals), n, O.ptr(back))
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(back), n, O.ptr(plain))
+    assert np.array_equal(plain, vals)
+    # slot-wise product
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, t, size=n, dtype=np.uint64)
+    b = rng.integers(0, t, size=n, dtype=np.uint64)
+    pa, pb = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(a), n, O.ptr(pa))
+    L.ref_batch_encode(C.byref(tb.t), O.ptr(b), n, O.ptr(pb))
+    prod = np.ascontiguousarray(O.negacyclic_mod_t(pa, pb, t), dtype=np.uint64)
+    L.ref_batch_decode(C.byref(tb.t), O.ptr(prod), n, O.ptr(back))
+    assert np.array_equal(back, (a * b) % t)
+    # the index map walks the powers of 3 (batchencoder.cpp:77), so the automorphism x -> x^3 rotates both rows left by
+    # one. (The fork's GaloisTool generator is 5, util/galois.h:169, so its rotate_rows(1) is x -> x^5: kept as built.)
+    ok = C.c_int(0)
+    assert L.ref_galois_elt_from_step(n, 1, C.byref(ok)) == 5 and ok.value
+    rot = np.zeros(n, dtype=np.uint64)
+    L.ref_apply_galois(O.ptr(pa), logn, 3, C.byref(O.modulus(t)), O.ptr(rot))
+    L.ref_batch_decode(C.byref(tb.t), O.ptr(rot), n, O.ptr(back))
+    half = n // 2
+    want = np.concatenate([np.roll(a[:half], -1), np.roll(a[half:], -1)])
+    assert np.array_equal(back, want)
