@@ -16,6 +16,17 @@
 
 using namespace sealhip;
 
+namespace sealhip
+{
+    // wire.cpp
+    void wire_set_parms_id(Engine &e, int k, const std::uint64_t *id);
+    void wire_peek(const void *bytes, std::size_t len, sealhip_ciphertext_info *info);
+    void wire_load(Engine &e, const void *bytes, std::size_t len, sealhip_ciphertext_info *info, u64 *dst,
+                   std::size_t capacity_words);
+    std::size_t wire_save_size(std::uint32_t size, std::uint32_t k, std::size_t n);
+    std::size_t wire_save(Engine &e, const sealhip_ciphertext_info &ci, const u64 *src, void *bytes, std::size_t capacity);
+} // namespace sealhip
+
 struct sealhip_context
 {
     std::unique_ptr<Engine> engine;
@@ -1176,6 +1187,87 @@ long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t co
     return guarded([&] {
         Engine &e = device_engine(ctx);
         op_batch_decode(e, reinterpret_cast<const u64 *>(plain), count, reinterpret_cast<u64 *>(values));
+    });
+}
+
+/* ------------------------------------------------------------------ ciphertext wire format */
+
+long sealhip_context_set_parms_id(sealhip_context *ctx, uint32_t k, const uint64_t parms_id[4])
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(parms_id);
+    return guarded([&] { wire_set_parms_id(*ctx->engine, static_cast<int>(k), parms_id); });
+}
+
+long sealhip_ciphertext_peek(const void *bytes, size_t len, sealhip_ciphertext_info *info)
+{
+    REQUIRE_PTR(bytes);
+    REQUIRE_PTR(info);
+    return guarded([&] { wire_peek(bytes, len, info); });
+}
+
+long sealhip_ciphertext_load(sealhip_context *ctx, const void *bytes, size_t len, sealhip_ciphertext_info *info,
+                             uint64_t *dst_device, size_t capacity_words)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(bytes);
+    REQUIRE_PTR(info);
+    REQUIRE_PTR(dst_device);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        wire_load(e, bytes, len, info, reinterpret_cast<u64 *>(dst_device), capacity_words);
+    });
+}
+
+long sealhip_ciphertext_save_size(const sealhip_context *ctx, uint32_t size, uint32_t k, size_t *bytes)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(bytes);
+    *bytes = wire_save_size(size, k, ctx->engine->n);
+    return SEALHIP_S_OK;
+}
+
+long sealhip_ciphertext_save(sealhip_context *ctx, const sealhip_ciphertext_info *info, const uint64_t *src_device,
+                             void *bytes, size_t capacity, size_t *written)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(info);
+    REQUIRE_PTR(src_device);
+    REQUIRE_PTR(bytes);
+    REQUIRE_PTR(written);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        *written = wire_save(e, *info, reinterpret_cast<const u64 *>(src_device), bytes, capacity);
+    });
+}
+
+long sealhip_is_data_valid_for(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                               uint8_t *valid)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(valid);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (count == 0)
+            return;
+        RowMap map{};
+        map.rows = static_cast<int>(k);
+        for (uint32_t r = 0; r < k; r++)
+            map.prime[r] = static_cast<unsigned short>(r);
+        e.ws_reserve(e.ws_floor + count * sizeof(unsigned) + 512);
+        e.ws_reset();
+        unsigned *flags = reinterpret_cast<unsigned *>(e.ws_alloc((count * sizeof(unsigned) + 7) / 8));
+        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.stream));
+        check_launch(launch_out_of_range(e, reinterpret_cast<const u64 *>(ct), static_cast<std::size_t>(size) * k * e.n, count,
+                                         map, flags),
+                     "is_data_valid_for");
+        std::vector<unsigned> host(count);
+        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        for (size_t i = 0; i < count; i++)
+            valid[i] = host[i] ? 0 : 1;
     });
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <array>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -170,6 +171,9 @@ namespace sealhip
         std::vector<void *> owned;
         std::map<int, std::unique_ptr<LevelTools>> levels;
         std::map<std::uint32_t, std::uint32_t *> galois_tables; // elt -> device table (galois.cpp:18-47)
+        // parms_id of level k (k = n_key: key level), registered by the binding (SEALContext computes them with Blake2,
+        // encryptionparams.cpp:132-166); used by the wire-format loader to find a ciphertext's level
+        std::map<int, std::array<std::uint64_t, 4>> parms_ids;
         int plain_prime = -1;                  // prime id of the plain modulus when batching is possible (context.cpp:262-275)
         std::uint32_t *d_batch_map = nullptr;  // BatchEncoder::matrix_reps_index_map_ (batchencoder.cpp:70-94)
         const std::uint32_t *batch_map();
@@ -308,6 +312,8 @@ namespace sealhip
                                 std::size_t b_item_stride, u64 *out, std::size_t count, const RowMap &map);
     hipError_t launch_nonzero_tail(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t skip_words,
                                    std::size_t count, unsigned *flags);
+    hipError_t launch_out_of_range(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t count,
+                                   const RowMap &map, unsigned *flags);
     hipError_t launch_plain_lift(const Engine &e, const u64 *plain, std::size_t plain_stride, u64 *out, std::size_t nplains,
                                  const RowMap &map, u64 t);
     hipError_t launch_galois(const Engine &e, const u64 *in, u64 *out, std::size_t nrows, const RowMap &map,

@@ -248,6 +248,27 @@ namespace sealhip
             }
         }
 
+        // is_data_valid_for (valcheck.cpp:284-317): flag[item] != 0 iff some coefficient is not below its row's prime
+        __global__ __launch_bounds__(kThreads) void out_of_range_kernel(const u64 *__restrict__ ct, std::size_t item_words,
+                                                                        std::size_t count,
+                                                                        const PrimeDev *__restrict__ primes, RowMap map,
+                                                                        int logn, unsigned *__restrict__ flag)
+        {
+            const std::size_t item_pairs = item_words / 2;
+            const std::size_t total = item_pairs * count;
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total;
+                 i += stride)
+            {
+                const std::size_t item = i / item_pairs;
+                const std::size_t off = 2 * (i - item * item_pairs);
+                const u64 p = primes[map.prime[(off >> logn) % map.rows]].p;
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(ct + item * item_words + off);
+                if ((v.x >= p || v.y >= p) && flag[item] == 0)
+                    flag[item] = 1; // benign race: every writer stores the same value
+            }
+        }
+
         // multiply_plain_normal's lift of a plaintext into the RNS base when every q_i > t (fast plain lift,
         // evaluator.cpp:1583-1592): temp_r[i] = plain[i] + (plain[i] >= threshold ? q_r - t : 0)
         __global__ __launch_bounds__(kThreads) void plain_lift_kernel(const u64 *__restrict__ plain,
@@ -417,6 +438,17 @@ namespace sealhip
         ProfScope prof(e, "nonzero_tail", 0);
         nonzero_tail_kernel<<<grid_for((item_words - skip_words) / 2 * count), kThreads, 0, e.stream>>>(
             ct, item_words, skip_words, count, flags);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_out_of_range(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t count,
+                                   const RowMap &map, unsigned *flags)
+    {
+        if (item_words == 0 || count == 0)
+            return hipSuccess;
+        ProfScope prof(e, "out_of_range", 0);
+        out_of_range_kernel<<<grid_for(item_words / 2 * count), kThreads, 0, e.stream>>>(ct, item_words, count, e.d_primes,
+                                                                                        map, e.logn, flags);
         return hipGetLastError();
     }
 

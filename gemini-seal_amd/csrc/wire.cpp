@@ -1,0 +1,211 @@
+// wire.cpp -- the reference's ciphertext wire format, uncompressed mode:
+//   Serialization::SEALHeader        native/src/seal/serialization.h:69-90   (16 bytes, magic 0xA15E, version 3.5)
+//   Ciphertext::save_members         native/src/seal/ciphertext.cpp:170-226
+//   IntArray<T>::save_members        native/src/seal/intarray.h:592-620      (nested SEALHeader + count + words)
+// Parsing happens on the host; the coefficient words go straight from the caller's buffer to HBM (and back),
+// so the host library never touches coefficient data. The reference build has no zlib, so
+// compr_mode_type::deflate is rejected exactly as Serialization::IsValidHeader does without SEAL_USE_ZLIB.
+#include "../../include/sealhip.h"
+
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr std::uint16_t kMagic = 0xA15E;    // serialization.h:51
+        constexpr std::uint8_t kHeaderSize = 0x10;  // serialization.h:56
+        constexpr std::uint8_t kVersionMajor = 3, kVersionMinor = 5; // CMakeLists.txt:14 (SEAL 3.5.3)
+        constexpr std::size_t kMembersFixed = 32 + 1 + 8 + 8 + 8 + 8; // parms_id, is_ntt_form, size, N, k, scale
+        constexpr std::size_t kSeedBytes = 64;                        // random_seed_type, randomgen.h (8 x uint64)
+        constexpr std::uint64_t kSeedMarker = 0xFFFFFFFFFFFFFFFFULL;  // ciphertext.h:704-707
+
+        struct Header
+        {
+            std::uint16_t magic;
+            std::uint8_t header_size, version_major, version_minor, compr_mode;
+            std::uint16_t reserved;
+            std::uint64_t size;
+        };
+        static_assert(sizeof(Header) == 16, "SEALHeader is 16 bytes (tests/seal/serialization.cpp:50)");
+
+        bool header_valid(const Header &h) // Serialization::IsValidHeader, serialization.h:140-162 (no zlib)
+        {
+            return h.magic == kMagic && h.header_size == kHeaderSize && h.version_major == kVersionMajor &&
+                   h.version_minor == kVersionMinor && h.compr_mode == 0;
+        }
+
+        // Serialization::LoadHeader with try_upgrade_if_invalid (serialization.cpp:137-165): a SEAL 3.4 header
+        // {magic u16, zero u8, compr_mode u8, size u32, reserved u64} is upgraded in place
+        Header read_header(const unsigned char *p, std::size_t len)
+        {
+            if (len < sizeof(Header))
+                throw std::runtime_error("I/O error");
+            Header h;
+            std::memcpy(&h, p, sizeof(h));
+            if (!header_valid(h))
+            {
+                std::uint32_t size32;
+                std::memcpy(&size32, p + 4, 4);
+                Header up{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, p[3], 0, size32 };
+                if (header_valid(up))
+                    h = up;
+            }
+            if (h.version_major != kVersionMajor || h.version_minor != kVersionMinor)
+                throw std::logic_error("incompatible version"); // serialization.cpp:345-348
+            if (!header_valid(h))
+                throw std::logic_error("loaded SEALHeader is invalid"); // :349-352
+            return h;
+        }
+
+        struct Parsed
+        {
+            sealhip_ciphertext_info info;
+            const unsigned char *words; // start of the coefficient words
+        };
+
+        Parsed parse(const void *bytes, std::size_t len)
+        {
+            const unsigned char *p = static_cast<const unsigned char *>(bytes);
+            const Header outer = read_header(p, len);
+            if (outer.size > len || outer.size < sizeof(Header) + kMembersFixed + sizeof(Header) + 8)
+                throw std::runtime_error("I/O error");
+            const unsigned char *end = p + outer.size;
+            p += sizeof(Header);
+            Parsed out{};
+            sealhip_ciphertext_info &ci = out.info;
+            std::memcpy(ci.parms_id, p, 32); // ciphertext.cpp:248-259
+            p += 32;
+            ci.is_ntt_form = *p++ != 0;
+            std::uint64_t size64, n64, k64;
+            std::memcpy(&size64, p, 8);
+            std::memcpy(&n64, p + 8, 8);
+            std::memcpy(&k64, p + 16, 8);
+            std::memcpy(&ci.scale, p + 24, 8);
+            p += 32;
+            if (size64 > 0xFFFFFFFFull || k64 > 0xFFFFFFFFull)
+                throw std::logic_error("ciphertext data is invalid");
+            ci.size = static_cast<std::uint32_t>(size64);
+            ci.coeff_modulus_size = static_cast<std::uint32_t>(k64);
+            ci.poly_modulus_degree = n64;
+            // nested IntArray (intarray.h:622-650) behind its own header
+            const Header inner = read_header(p, static_cast<std::size_t>(end - p));
+            if (inner.size > static_cast<std::size_t>(end - p) || inner.size < sizeof(Header) + 8)
+                throw std::runtime_error("I/O error");
+            p += sizeof(Header);
+            std::uint64_t count;
+            std::memcpy(&count, p, 8);
+            p += 8;
+            if (inner.size != sizeof(Header) + 8 + count * 8 || count > (static_cast<std::uint64_t>(1) << 40))
+                throw std::runtime_error("I/O error");
+            ci.data_words = count;
+            out.words = p;
+            p += count * 8;
+            ci.seeded = static_cast<std::size_t>(end - p) == kSeedBytes ? 1u : 0u; // ciphertext.cpp:296-309
+            if (static_cast<std::size_t>(end - p) != (ci.seeded ? kSeedBytes : 0))
+                throw std::runtime_error("I/O error");
+            ci.total_bytes = outer.size;
+            return out;
+        }
+
+        // is_metadata_valid_for(ciphertext, context, allow_pure_key_levels = true), valcheck.cpp:67-105
+        int level_of(const Engine &e, const sealhip_ciphertext_info &ci)
+        {
+            int k = -1;
+            for (const auto &kv : e.parms_ids)
+                if (std::memcmp(kv.second.data(), ci.parms_id, 32) == 0)
+                    k = kv.first;
+            if (k < 0)
+                throw std::logic_error("ciphertext data is invalid"); // no ContextData for the parms_id (:76-80)
+            if (static_cast<int>(ci.coeff_modulus_size) != k || ci.poly_modulus_degree != e.n)
+                throw std::logic_error("ciphertext data is invalid"); // :90-95
+            if ((ci.size < 2 && ci.size != 0) || ci.size > 16)
+                throw std::logic_error("ciphertext data is invalid"); // :97-102, SEAL_CIPHERTEXT_SIZE_MIN/MAX
+            return k;
+        }
+    } // namespace
+
+    void wire_set_parms_id(Engine &e, int k, const std::uint64_t *id)
+    {
+        if (k < 1 || k > e.n_key)
+            throw std::invalid_argument("level k out of range");
+        std::array<std::uint64_t, 4> a{ id[0], id[1], id[2], id[3] };
+        std::lock_guard<std::mutex> lock(e.mu);
+        e.parms_ids[k] = a;
+    }
+
+    void wire_peek(const void *bytes, std::size_t len, sealhip_ciphertext_info *info)
+    {
+        *info = parse(bytes, len).info;
+    }
+
+    // Ciphertext::load (ciphertext.cpp:228-330) with the words landing in HBM
+    void wire_load(Engine &e, const void *bytes, std::size_t len, sealhip_ciphertext_info *info, u64 *dst,
+                   std::size_t capacity_words)
+    {
+        const Parsed ps = parse(bytes, len);
+        *info = ps.info;
+        const int k = level_of(e, ps.info);
+        const std::uint64_t total = static_cast<std::uint64_t>(ps.info.size) * e.n * k;
+        if (ps.info.data_words > total)
+            throw std::logic_error("unexpected size"); // intarray.h:633-638
+        if (ps.info.seeded)
+            // expand_seed needs the reference's Blake2xb PRNG (ciphertext.cpp:301-309): the host library expands
+            // seeded ciphertexts before handing them over
+            throw std::logic_error("seeded ciphertext: expand the seed on the host before loading");
+        if (ps.info.data_words != total)
+            throw std::logic_error("ciphertext data is invalid"); // is_buffer_valid, valcheck.cpp:228-240
+        if (total > capacity_words)
+            throw std::invalid_argument("destination buffer is too small");
+        if (total)
+            SEALHIP_CHECK(hipMemcpyAsync(dst, ps.words, total * 8, hipMemcpyHostToDevice, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream)); // the caller's buffer may go away after the call
+    }
+
+    std::size_t wire_save_size(std::uint32_t size, std::uint32_t k, std::size_t n)
+    {
+        // Ciphertext::save_size(compr_mode_type::none), ciphertext.cpp:135-168
+        return sizeof(Header) + kMembersFixed + sizeof(Header) + 8 + static_cast<std::size_t>(size) * k * n * 8;
+    }
+
+    // Ciphertext::save (ciphertext.cpp:170-226), unseeded
+    std::size_t wire_save(Engine &e, const sealhip_ciphertext_info &ci, const u64 *src, void *bytes, std::size_t capacity)
+    {
+        const int k = level_of(e, ci);
+        const std::size_t words = static_cast<std::size_t>(ci.size) * k * e.n;
+        const std::size_t total = wire_save_size(ci.size, static_cast<std::uint32_t>(k), e.n);
+        if (capacity < total)
+            throw std::invalid_argument("destination buffer is too small");
+        unsigned char *p = static_cast<unsigned char *>(bytes);
+        const Header outer{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, total };
+        std::memcpy(p, &outer, sizeof(outer));
+        p += sizeof(outer);
+        std::memcpy(p, ci.parms_id, 32);
+        p += 32;
+        *p++ = ci.is_ntt_form ? 1 : 0;
+        const std::uint64_t size64 = ci.size, n64 = e.n, k64 = static_cast<std::uint64_t>(k);
+        std::memcpy(p, &size64, 8);
+        std::memcpy(p + 8, &n64, 8);
+        std::memcpy(p + 16, &k64, 8);
+        std::memcpy(p + 24, &ci.scale, 8);
+        p += 32;
+        const Header inner{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, sizeof(Header) + 8 + words * 8 };
+        std::memcpy(p, &inner, sizeof(inner));
+        p += sizeof(inner);
+        const std::uint64_t count = words;
+        std::memcpy(p, &count, 8);
+        p += 8;
+        if (words)
+            SEALHIP_CHECK(hipMemcpyAsync(p, src, words * 8, hipMemcpyDeviceToHost, e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        if (ci.size == 2 && words && reinterpret_cast<const std::uint64_t *>(p)[static_cast<std::size_t>(k) * e.n] == kSeedMarker)
+        {
+            // a ciphertext whose c_1 starts with the seed marker would be written in the seeded form by the reference
+            // (ciphertext.cpp:189-208); evaluated ciphertexts never carry it
+            throw std::logic_error("ciphertext carries a seed marker: save it on the host");
+        }
+        return total;
+    }
+} // namespace sealhip

@@ -278,6 +278,16 @@ namespace sealhip_host
                 ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, p.ptr(), 0));
             c.down(encrypted.data(), size * k * n);
         }
+        // Evaluator::add_plain_inplace (evaluator.cpp:1290-1362) / sub_plain_inplace (:1364-1435). BFV: plain = N
+        // coefficients below t, ciphertext in coefficient form; CKKS: plain = k*N words in NTT form, same level.
+        void add_plain_inplace(CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form)
+        {
+            plain_linear(encrypted, plain, plain_is_ntt_form, false);
+        }
+        void sub_plain_inplace(CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form)
+        {
+            plain_linear(encrypted, plain, plain_is_ntt_form, true);
+        }
         // Ciphertext::is_transparent (ciphertext.h:471-476) evaluated on the device copy
         bool is_transparent(const CT &encrypted)
         {
@@ -290,6 +300,23 @@ namespace sealhip_host
         }
 
     private:
+        void plain_linear(CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form, bool sub)
+        {
+            if (ctx_.scheme() == SEALHIP_SCHEME_BFV && encrypted.is_ntt_form())
+                throw std::invalid_argument("BFV encrypted cannot be in NTT form"); // :1304-1307
+            if (ctx_.scheme() == SEALHIP_SCHEME_CKKS && !encrypted.is_ntt_form())
+                throw std::invalid_argument("CKKS encrypted must be in NTT form"); // :1308-1311
+            if (encrypted.is_ntt_form() != plain_is_ntt_form)
+                throw std::invalid_argument("NTT form mismatch"); // :1312-1315
+            const std::size_t k = encrypted.coeff_modulus_size(), n = ctx_.n(), size = encrypted.size();
+            const std::size_t pw = plain_is_ntt_form ? k * n : n;
+            Staged c(ctx_, size * k * n), p(ctx_, pw);
+            c.up(encrypted.data(), size * k * n);
+            p.up(plain, pw);
+            throw_on(sealhip_evaluator_add_plain(ctx_.get(), std::uint32_t(k), c.ptr(), std::uint32_t(size), 1, p.ptr(), pw,
+                                                 sub ? 1 : 0));
+            c.down(encrypted.data(), size * k * n);
+        }
         void add_sub(CT &a, const CT &b, bool sub)
         {
             if (a.poly_modulus_degree() != ctx_.n() || b.poly_modulus_degree() != ctx_.n() || a.size() < 1 || b.size() < 1)

@@ -117,7 +117,28 @@ SYMBOLS = {
     "sealhip_context_using_batching": [_vp, C.POINTER(_i32)],
     "sealhip_batch_encode": [_vp, _vp, _sz, _sz, _vp],
     "sealhip_batch_decode": [_vp, _vp, _sz, _vp],
+    "sealhip_context_set_parms_id": [_vp, _u32, _vp],
+    "sealhip_ciphertext_peek": [_vp, _sz, _vp],
+    "sealhip_ciphertext_load": [_vp, _vp, _sz, _vp, _vp, _sz],
+    "sealhip_ciphertext_save_size": [_vp, _u32, _u32, C.POINTER(_sz)],
+    "sealhip_ciphertext_save": [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)],
+    "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
 }
+
+
+class CiphertextInfo(C.Structure):
+    """sealhip_ciphertext_info: what Ciphertext::save_members writes ahead of the words (ciphertext.cpp:170-188)"""
+    _fields_ = [("parms_id", C.c_uint64 * 4), ("is_ntt_form", C.c_uint32), ("size", C.c_uint32),
+                ("coeff_modulus_size", C.c_uint32), ("seeded", C.c_uint32), ("poly_modulus_degree", C.c_uint64),
+                ("scale", C.c_double), ("data_words", C.c_uint64), ("total_bytes", C.c_uint64)]
+
+
+def ciphertext_peek(raw):
+    """Header + metadata of a serialized ciphertext (no context needed)"""
+    info = CiphertextInfo()
+    buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+    _check(lib().sealhip_ciphertext_peek(C.addressof(buf), len(raw), C.addressof(info)))
+    return info
 
 
 def lib():
@@ -363,6 +384,35 @@ class Context:
         stride = self.n if plain_stride is None else plain_stride
         _check(lib().sealhip_multiply_add_plain_with_scaling_variant(self.handle, k, _ptr(plain), stride, _ptr(ct), size,
                                                                      count, 1 if subtract else 0))
+
+    # ---- ciphertext wire format
+    def set_parms_id(self, k, parms_id):
+        arr = (C.c_uint64 * 4)(*[int(x) for x in parms_id])
+        _check(lib().sealhip_context_set_parms_id(self.handle, k, C.addressof(arr)))
+
+    def load_ciphertext(self, raw, dst, capacity_words=None):
+        """Ciphertext::load (ciphertext.cpp:228-330): words go from `raw` (host bytes) straight into dst (device)"""
+        info = CiphertextInfo()
+        buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        cap = dst.words if capacity_words is None else capacity_words
+        _check(lib().sealhip_ciphertext_load(self.handle, C.addressof(buf), len(raw), C.addressof(info), _ptr(dst), cap))
+        return info
+
+    def save_ciphertext(self, info, src):
+        """Ciphertext::save (ciphertext.cpp:170-226), uncompressed -> bytes"""
+        need = _sz(0)
+        _check(lib().sealhip_ciphertext_save_size(self.handle, info.size, info.coeff_modulus_size, C.byref(need)))
+        buf = (C.c_char * need.value)()
+        written = _sz(0)
+        _check(lib().sealhip_ciphertext_save(self.handle, C.addressof(info), _ptr(src), C.addressof(buf), need.value,
+                                             C.byref(written)))
+        return bytes(buf[: written.value])
+
+    def is_data_valid_for(self, ct, size, k, count):
+        """is_data_valid_for (valcheck.cpp:284-317) per ciphertext of the batch -> numpy bool array"""
+        flags = np.zeros(count, dtype=np.uint8)
+        _check(lib().sealhip_is_data_valid_for(self.handle, k, _ptr(ct), size, count, flags.ctypes.data))
+        return flags.astype(bool)
 
     # ---- SURVEY 8(f4): BatchEncoder
     @property

@@ -273,6 +273,43 @@ long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_b
 long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain);
 long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values);
 
+/* ---------------------------------------------------------------- ciphertext wire format */
+/* What Ciphertext::save_members writes ahead of the coefficient words (ciphertext.cpp:170-188). */
+typedef struct sealhip_ciphertext_info
+{
+    uint64_t parms_id[4];         /* parms_id_type (4 x uint64 Blake2 hash, computed by the host library)  */
+    uint32_t is_ntt_form;
+    uint32_t size;                /* polynomials                                                           */
+    uint32_t coeff_modulus_size;  /* k                                                                     */
+    uint32_t seeded;              /* 1: c_1 was replaced by a PRNG seed (ciphertext.cpp:189-208)           */
+    uint64_t poly_modulus_degree; /* N                                                                     */
+    double scale;
+    uint64_t data_words;          /* uint64 words stored in the stream                                     */
+    uint64_t total_bytes;         /* SEALHeader::size of the whole object                                  */
+} sealhip_ciphertext_info;
+/* Registers the parms_id of level k (k = n_key_moduli: the key level). The binding copies them from
+   SEALContext::get_context_data(...)->parms_id() once per context (context.cpp:455-540 builds the chain);
+   the loader uses them the way is_metadata_valid_for does (valcheck.cpp:67-105). */
+long sealhip_context_set_parms_id(sealhip_context *ctx, uint32_t k, const uint64_t parms_id[4]);
+/* Serialization::LoadHeader + the metadata of Ciphertext::load_members, no context needed (serialization.cpp:137-176,
+   ciphertext.cpp:248-267). Errors as the reference: bad magic/size/compression -> COR_E_INVALIDOPERATION
+   ("loaded SEALHeader is invalid" / "incompatible version"), truncated input -> E_UNEXPECTED ("I/O error"). */
+long sealhip_ciphertext_peek(const void *bytes, size_t len, sealhip_ciphertext_info *info);
+/* Ciphertext::load (ciphertext.cpp:228-330, uncompressed stream): validates the metadata against the context and
+   copies the coefficient words from `bytes` (host) straight into dst_device (capacity in words). Seeded ciphertexts
+   are reported (info->seeded) and refused: expanding the seed needs the host library's PRNG. */
+long sealhip_ciphertext_load(sealhip_context *ctx, const void *bytes, size_t len, sealhip_ciphertext_info *info,
+                             uint64_t *dst_device, size_t capacity_words);
+/* Ciphertext::save_size(compr_mode_type::none) (ciphertext.cpp:135-168) and Ciphertext::save: the stream is written
+   into `bytes` (host) with the coefficient words copied straight from src_device. */
+long sealhip_ciphertext_save_size(const sealhip_context *ctx, uint32_t size, uint32_t k, size_t *bytes);
+long sealhip_ciphertext_save(sealhip_context *ctx, const sealhip_ciphertext_info *info, const uint64_t *src_device,
+                             void *bytes, size_t capacity, size_t *written);
+/* is_data_valid_for (valcheck.cpp:284-317) on device-resident ciphertexts: valid[i] = 1 iff every coefficient of
+   ciphertext i is below its row's prime (what an ingesting service checks before evaluating untrusted input). */
+long sealhip_is_data_valid_for(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
+                               uint8_t *valid);
+
 #ifdef __cplusplus
 }
 #endif

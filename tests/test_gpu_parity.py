@@ -1142,3 +1142,67 @@ def test_f4_batching_unavailable_is_reported(sealhip):
     ctx2 = sealhip.Context(sealhip.SCHEME_BFV, 10, kmods, 1, 65537)
     with pytest.raises(sealhip.LogicError):  # batchencoder.cpp:119-122
         ctx2.batch_encode(ctx2.alloc(n + 1), n + 1, 1, ctx2.alloc(n))
+
+
+# ---------------------------------------------------------------- ciphertext wire format <-> HBM
+def test_f3_ciphertext_load_save_roundtrip_and_validation(sealhip):
+    """Ciphertext::load / save (ciphertext.cpp:170-330) with the words going straight between the byte stream and HBM:
+    the stream the engine writes is byte-identical to the oracle's, loading it back gives the same words, the loaded
+    ciphertext evaluates to the same result as the directly uploaded one, and invalid inputs are refused with the
+    reference's error classes."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wire_format", os.path.join(os.path.dirname(HERE), "oracle", "wire_format.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    logn, n, t = 12, 4096, 65537
+    kmods = O.coeff_modulus_create(n, [36, 36, 37])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    ids = {3: (1, 2, 3, 4), 2: (5, 6, 7, 8), 1: (9, 10, 11, 12)}
+    for k, pid in ids.items():
+        ctx.set_parms_id(k, pid)
+    rng = np.random.default_rng(12)
+    k, size = 2, 2
+    a = _rand_ct(rng, kmods[:k], size, n, 1)[0]
+    b = _rand_ct(rng, kmods[:k], size, n, 1)[0]
+    raw_a = W.save_ciphertext(ids[k], False, size, n, k, 1.0, a.reshape(-1))
+    da = ctx.alloc(a.size)
+    info = ctx.load_ciphertext(raw_a, da)
+    assert (info.size, info.coeff_modulus_size, info.is_ntt_form, info.seeded) == (size, k, 0, 0)
+    assert np.array_equal(da.download(a.shape), a)
+    assert ctx.save_ciphertext(info, da) == raw_a  # byte-identical stream
+    # evaluate on the loaded ciphertext, save the result, load it back
+    prod = ctx.alloc(3 * k * n)
+    ev.multiply(da, 2, ctx.upload(b), 2, k, 1, prod)
+    direct = ctx.alloc(3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, 1, direct)
+    assert np.array_equal(prod.download(), direct.download())
+    pinfo = sealhip.CiphertextInfo()
+    pinfo.parms_id[:] = ids[k]
+    pinfo.size, pinfo.coeff_modulus_size, pinfo.is_ntt_form, pinfo.scale, pinfo.poly_modulus_degree = 3, k, 0, 1.0, n
+    raw_p = ctx.save_ciphertext(pinfo, prod)
+    parsed = W.load_ciphertext(raw_p)
+    assert parsed["size"] == 3 and parsed["k"] == k and np.array_equal(parsed["words"], prod.download())
+    back = ctx.alloc(3 * k * n)
+    assert ctx.load_ciphertext(raw_p, back).size == 3 and np.array_equal(back.download(), prod.download())
+    # validation (valcheck.cpp:67-105, :228-240, :284-317)
+    assert ctx.is_data_valid_for(da, size, k, 1).all()
+    bad = a.copy()
+    bad[1, 1, 7] = kmods[1]
+    both = ctx.upload(np.stack([a, bad]))
+    assert list(ctx.is_data_valid_for(both, size, k, 2)) == [True, False]
+    with pytest.raises(sealhip.LogicError, match="ciphertext data is invalid"):  # unknown parms_id
+        ctx.load_ciphertext(W.save_ciphertext((7, 7, 7, 7), False, size, n, k, 1.0, a.reshape(-1)), da)
+    with pytest.raises(sealhip.LogicError, match="ciphertext data is invalid"):  # k does not match the level
+        ctx.load_ciphertext(W.save_ciphertext(ids[3], False, size, n, k, 1.0, a.reshape(-1)), da)
+    with pytest.raises(sealhip.LogicError, match="ciphertext data is invalid"):  # size 1
+        ctx.load_ciphertext(W.save_ciphertext(ids[k], False, 1, n, k, 1.0, a.reshape(-1)[: k * n]), da)
+    with pytest.raises(sealhip.LogicError, match="ciphertext data is invalid"):  # buffer shorter than size*k*N
+        ctx.load_ciphertext(W.save_ciphertext(ids[k], False, size, n, k, 1.0, a.reshape(-1)[:-1]), da)
+    with pytest.raises(sealhip.LogicError, match="unexpected size"):
+        ctx.load_ciphertext(W.save_ciphertext(ids[k], False, size, n, k, 1.0, np.concatenate([a.reshape(-1), a[0, 0]])), da)
+    with pytest.raises(sealhip.LogicError, match="seeded"):
+        ctx.load_ciphertext(W.save_ciphertext(ids[k], False, 2, n, k, 1.0, a.reshape(-1)[: k * n], seed=bytes(64)), da)
+    with pytest.raises(ValueError, match="too small"):
+        ctx.load_ciphertext(raw_a, da, capacity_words=a.size - 1)

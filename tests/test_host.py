@@ -149,3 +149,68 @@ def test_cpp_host_adapter_compiles_and_links(tmp_path):
 
     out = subprocess.run([_build_adapter(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "host-only context ok" in out.stdout, out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------- ciphertext wire format (host parsing, no GPU)
+def _wire():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wire_format", os.path.join(ROOT, "oracle", "wire_format.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_f3_header_known_answers_of_the_reference_tests():
+    """native/tests/seal/serialization.cpp:48-130 restated: the header is 16 bytes, a default one is valid, a wrong
+    magic / major version / compression mode is not, and a SEAL 3.4 header is upgraded on load."""
+    W = _wire()
+    assert W.HEADER.size == 16 == W.HEADER_SIZE
+    assert W.is_valid_header(W.header(256))
+    bad = bytearray(W.header(256))
+    bad[0:2] = (0x1212).to_bytes(2, "little")
+    assert not W.is_valid_header(bytes(bad))
+    assert not W.is_valid_header(W.header(256, version=(2, 5)))
+    assert not W.is_valid_header(W.header(256, compr_mode=2))
+    h = W.load_header(W.header(256))
+    assert (h["magic"], h["header_size"], h["version_major"], h["version_minor"], h["reserved"], h["size"]) == \
+        (0xA15E, 0x10, 3, 5, 0, 256)
+    up = W.load_header(W.header_3_4(0xF3F3))
+    assert up["size"] == 0xF3F3 and up["compr_mode"] == 0 and W.is_valid_header(W.header(up["size"], up["compr_mode"]))
+    assert W.load_header(W.header_3_4(0xF3F3), try_upgrade=False)["header_size"] != 0x10  # no upgrade requested
+
+
+def test_f3_peek_matches_the_oracle_and_reports_errors_like_the_reference():
+    import sealhip as S
+
+    W = _wire()
+    rng = np.random.default_rng(0)
+    n, k, size = 64, 3, 2
+    words = rng.integers(0, 2**40, size=size * k * n, dtype=np.uint64)
+    pid = (11, 22, 33, 44)
+    raw = W.save_ciphertext(pid, True, size, n, k, 2.0**40, words)
+    assert len(raw) == 16 + 65 + 16 + 8 + 8 * len(words)  # Ciphertext::save_size, ciphertext.cpp:135-168
+    back = W.load_ciphertext(raw)
+    assert back["parms_id"] == pid and back["is_ntt_form"] and np.array_equal(back["words"], words)
+    info = S.ciphertext_peek(raw)
+    assert tuple(info.parms_id) == pid and info.is_ntt_form == 1 and info.size == size
+    assert info.coeff_modulus_size == k and info.poly_modulus_degree == n and info.scale == 2.0**40
+    assert info.data_words == len(words) and info.total_bytes == len(raw) and info.seeded == 0
+    assert S.ciphertext_peek(raw + b"trailing bytes of the next object").total_bytes == len(raw)
+    # seeded form: one polynomial + 64 bytes of seed (ciphertext.cpp:189-208)
+    seeded = W.save_ciphertext(pid, False, 2, n, k, 1.0, words[: k * n], seed=bytes(range(64)))
+    si = S.ciphertext_peek(seeded)
+    assert si.seeded == 1 and si.data_words == k * n
+    # a SEAL 3.4 outer header is upgraded (serialization.cpp:147-164)
+    old = W.header_3_4(len(raw)) + raw[16:]
+    assert S.ciphertext_peek(old).total_bytes == len(raw)
+    with pytest.raises(S.LogicError, match="loaded SEALHeader is invalid"):
+        S.ciphertext_peek(b"\x12\x12" + raw[2:])
+    with pytest.raises(S.LogicError, match="incompatible version"):
+        S.ciphertext_peek(raw[:3] + b"\x02" + raw[4:])
+    with pytest.raises(S.LogicError, match="loaded SEALHeader is invalid"):
+        S.ciphertext_peek(raw[:5] + b"\x01" + raw[6:])  # deflate: the reference build has no zlib
+    with pytest.raises(RuntimeError, match="I/O error"):
+        S.ciphertext_peek(raw[:-8])
+    with pytest.raises(RuntimeError, match="I/O error"):
+        S.ciphertext_peek(raw[:10])
