@@ -1190,6 +1190,31 @@ long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t co
     });
 }
 
+long sealhip_ciphertext_resize(sealhip_context *ctx, uint32_t k, const uint64_t *src, uint32_t src_size, uint64_t *dst,
+                               uint32_t dst_size, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(src);
+    REQUIRE_PTR(dst);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if ((dst_size < 2 && dst_size != 0) || dst_size > 16 || src_size > 16)
+            throw std::invalid_argument("invalid size"); // ciphertext.cpp:111-114
+        if (count == 0 || dst_size == 0)
+            return;
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        const uint32_t keep = std::min(src_size, dst_size);
+        u64 *d = reinterpret_cast<u64 *>(dst);
+        if (dst_size > keep)
+            SEALHIP_CHECK(hipMemsetAsync(d, 0, count * dst_size * poly * sizeof(u64), e.stream));
+        if (keep)
+            check_launch(launch_copy_rows(e, reinterpret_cast<const u64 *>(src), src_size * poly, d, dst_size * poly, count,
+                                          static_cast<int>(keep * k)),
+                         "resize");
+    });
+}
+
 /* ------------------------------------------------------------------ ciphertext wire format */
 
 long sealhip_context_set_parms_id(sealhip_context *ctx, uint32_t k, const uint64_t parms_id[4])

@@ -123,6 +123,7 @@ SYMBOLS = {
     "sealhip_ciphertext_save_size": [_vp, _u32, _u32, C.POINTER(_sz)],
     "sealhip_ciphertext_save": [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)],
     "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
 }
 
 
@@ -560,6 +561,77 @@ class Evaluator:
 
     def sub_plain_inplace(self, ct, size, k, count, plain, plain_stride=None):
         self.add_plain_inplace(ct, size, k, count, plain, plain_stride, subtract=True)
+
+    def resize(self, src, src_size, dst_size, k, count, dst=None):
+        """Ciphertext::resize (ciphertext.cpp:84-124) over a batch; returns the destination buffer"""
+        if dst is None:
+            dst = self.ctx.alloc(count * dst_size * k * self.ctx.n)
+        _check(lib().sealhip_ciphertext_resize(self.ctx.handle, k, _ptr(src), src_size, _ptr(dst), dst_size, count))
+        return dst
+
+    def add_many(self, cts, size, k, count, out):
+        """Evaluator::add_many (evaluator.cpp:153-172): out = cts[0] + cts[1] + ... (left to right)"""
+        if not cts:
+            raise ValueError("encrypteds cannot be empty")
+        self.add(cts[0], size, cts[1], size, k, count, out) if len(cts) > 1 else self.resize(cts[0], size, size, k, count, out)
+        for c in cts[2:]:
+            self.add(out, size, c, size, k, count, out)
+
+    def multiply_many(self, cts, k, count, relin_keys):
+        """Evaluator::multiply_many (evaluator.cpp:1180-1255), BFV, size-2 operands: the reference's queue order
+        (pairs left to right, odd one appended, then products of products appended until one is left), each product
+        relinearized. Returns the device buffer of the result ([count][2][k][N])."""
+        if not cts:
+            raise ValueError("encrypteds vector must not be empty")
+        if self.ctx.scheme != SCHEME_BFV:
+            raise LogicError("unsupported scheme")
+        if len(cts) == 1:
+            return self.resize(cts[0], 2, 2, k, count)
+
+        def product(a, b):
+            wide = self.ctx.alloc(count * 3 * k * self.ctx.n)
+            self.multiply(a, 2, b, 2, k, count, wide)
+            self.relinearize_inplace(wide, 3, k, count, relin_keys)
+            out = self.resize(wide, 3, 2, k, count)
+            wide.free()
+            return out
+
+        queue = [product(cts[i], cts[i + 1]) for i in range(0, len(cts) - 1, 2)]
+        if len(cts) & 1:
+            queue.append(cts[-1])
+        i = 0
+        while i < len(queue) - 1:
+            queue.append(product(queue[i], queue[i + 1]))
+            i += 2
+        return queue[-1]
+
+    def exponentiate(self, ct, exponent, k, count, relin_keys):
+        """Evaluator::exponentiate_inplace (evaluator.cpp:1257-1288): multiply_many over `exponent` copies"""
+        if exponent == 0:
+            raise ValueError("exponent cannot be 0")
+        return self.multiply_many([ct] * int(exponent), k, count, relin_keys)
+
+    def mod_switch_to(self, ct, size, k, k_target, count):
+        """Evaluator::mod_switch_to_inplace (evaluator.cpp:1038-1088): mod_switch_to_next until level k_target"""
+        if k_target > k:
+            raise ValueError("cannot switch to higher level modulus")
+        cur = ct
+        while k > k_target:
+            nxt = self.ctx.alloc(count * size * (k - 1) * self.ctx.n)
+            self.mod_switch_to_next(cur, size, k, count, nxt)
+            cur, k = nxt, k - 1
+        return cur
+
+    def rescale_to(self, ct, size, k, k_target, count):
+        """Evaluator::rescale_to_inplace (evaluator.cpp:1128-1178), CKKS"""
+        if k_target > k:
+            raise ValueError("cannot switch to higher level modulus")
+        cur = ct
+        while k > k_target:
+            nxt = self.ctx.alloc(count * size * (k - 1) * self.ctx.n)
+            self.rescale_to_next(cur, size, k, count, nxt)
+            cur, k = nxt, k - 1
+        return cur
 
     def check_not_transparent(self, ct, size, k, count):
         """evaluator.cpp:265-271 (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT)"""

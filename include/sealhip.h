@@ -273,6 +273,12 @@ long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_b
 long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain);
 long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values);
 
+/* Ciphertext::resize (ciphertext.cpp:84-124) over a device-resident batch: dst[count][dst_size][k][N] receives the first
+   min(src_size, dst_size) polynomials of every src[count][src_size][k][N]; added polynomials are zero (IntArray::resize).
+   What a chain needs between relinearize (which leaves the batch stride at its old size) and the next multiply. */
+long sealhip_ciphertext_resize(sealhip_context *ctx, uint32_t k, const uint64_t *src, uint32_t src_size, uint64_t *dst,
+                               uint32_t dst_size, size_t count);
+
 /* ---------------------------------------------------------------- ciphertext wire format */
 /* What Ciphertext::save_members writes ahead of the coefficient words (ciphertext.cpp:170-188). */
 typedef struct sealhip_ciphertext_info

@@ -1206,3 +1206,60 @@ def test_f3_ciphertext_load_save_roundtrip_and_validation(sealhip):
         ctx.load_ciphertext(W.save_ciphertext(ids[k], False, 2, n, k, 1.0, a.reshape(-1)[: k * n], seed=bytes(64)), da)
     with pytest.raises(ValueError, match="too small"):
         ctx.load_ciphertext(raw_a, da, capacity_words=a.size - 1)
+
+
+# ---------------------------------------------------------------- host-side trees over the device ops
+def test_f1_multiply_many_exponentiate_add_many_resize(sealhip):
+    """Evaluator::multiply_many / exponentiate / add_many (evaluator.cpp:153-172, 1180-1288) and Ciphertext::resize on
+    device-resident batches: the same queue order as the reference, every step bit-exact against the oracle's
+    multiply + relinearize; mod_switch_to walks the chain."""
+    logn, n, t = 10, 1024, 65537
+    kmods = O.coeff_modulus_create(n, [45] * 5)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(2)
+    k, count, d = 4, 2, 4
+    key = np.stack([np.stack([rand_rows(rng, kmods, n) for _ in range(2)]) for _ in range(d)])
+    rk = sealhip.KSwitchKeys(ctx, key)
+    cts = [np.stack([_rand_ct(rng, kmods[:k], 2, n, 1)[0] for _ in range(count)]) for _ in range(5)]
+
+    def ref_product(a, b):
+        out = np.zeros((count, 2, k, n), dtype=np.uint64)
+        keys = (C.c_void_p * 1)(key.ctypes.data)
+        for i in range(count):
+            wide = np.zeros((3, k, n), dtype=np.uint64)
+            assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(wide)) == 0
+            assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(wide), 3, keys) == 0
+            out[i] = wide[:2]
+        return out
+
+    queue = [ref_product(cts[0], cts[1]), ref_product(cts[2], cts[3]), cts[4]]
+    i = 0
+    while i < len(queue) - 1:
+        queue.append(ref_product(queue[i], queue[i + 1]))
+        i += 2
+    got = ev.multiply_many([ctx.upload(c) for c in cts], k, count, [rk])
+    assert np.array_equal(got.download((count, 2, k, n)), queue[-1])
+    # exponentiate(3) = multiply_many of three copies: (x*x) relinearized, then times x
+    x = cts[0]
+    want = ref_product(ref_product(x, x), x)  # queue: [x*x, x] -> (x*x)*x
+    got = ev.exponentiate(ctx.upload(x), 3, k, count, [rk])
+    assert np.array_equal(got.download((count, 2, k, n)), want)
+    # add_many
+    out = ctx.alloc(count * 2 * k * n)
+    ev.add_many([ctx.upload(c) for c in cts[:3]], 2, k, count, out)
+    mods = np.array(kmods[:k], dtype=np.uint64)[None, None, :, None]
+    assert np.array_equal(out.download(cts[0].shape), ((cts[0] + cts[1]) % mods + cts[2]) % mods)
+    # resize: grow to 3 (new polynomial zero), shrink back
+    grown = ev.resize(ctx.upload(x), 2, 3, k, count).download((count, 3, k, n))
+    assert np.array_equal(grown[:, :2], x) and not grown[:, 2].any()
+    assert np.array_equal(ev.resize(ctx.upload(grown), 3, 2, k, count).download(x.shape), x)
+    # mod_switch_to: two levels down = two mod_switch_to_next
+    low = ev.mod_switch_to(ctx.upload(x), 2, k, k - 2, count).download((count, 2, k - 2, n))
+    for i in range(count):
+        a1 = np.zeros((2, k - 1, n), dtype=np.uint64)
+        a2 = np.zeros((2, k - 2, n), dtype=np.uint64)
+        assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(x[i]), 2, O.ptr(a1)) == 0
+        assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k - 1, O.ptr(a1), 2, O.ptr(a2)) == 0
+        assert np.array_equal(low[i], a2), i
