@@ -149,6 +149,59 @@ def main():
                     "multiply_plain_ct_per_s": B / dt_mp,
                     "multiply_plain_ntt_equiv_frac": rows * 2 * 16 * n / dt_mp / 8e12,
                     "is_transparent_ct_per_s": B / dt_tr, "is_transparent_hbm_roofline_frac": (rows // 2) * 8 * n / dt_tr / 8e12})
+    if want("f234"):
+        # SURVEY 8(f2)/(f3)/(f4) rows at cfg3 size. Streaming + NTT work priced against the HBM roofline with the
+        # bytes each operation has to move (inputs read once, outputs written once); the wire format is host-bound.
+        logn, n, t = 15, 1 << 15, 786433
+        pr = bench.CFG3_PRIMES
+        ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, t)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        B, k = 1024, 7
+        a_ntt = mk(ctx, (B, k, n), pr[:k], dev)
+        sk = mk(ctx, (8, n), pr, dev)
+        e32 = torch.randint(-19, 20, (B, n), dtype=torch.int32, device=dev)
+        ct = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
+        dt_sym = timed(lambda: ctx.encrypt_zero_symmetric(k, False, a_ntt, e32, sk, B, ct), 5)
+        pk = mk(ctx, (2, k, n), pr[:k], dev)
+        u32 = torch.randint(-1, 2, (B, n), dtype=torch.int32, device=dev)
+        e2 = torch.randint(-19, 20, (B, 2, n), dtype=torch.int32, device=dev)
+        dt_asym = timed(lambda: ctx.encrypt_zero_asymmetric(k, False, pk, u32, e2, B, ct), 5)
+        plain = torch.randint(0, t, (B, n), dtype=torch.int64, device=dev)
+        dt_ap = timed(lambda: ev.add_plain_inplace(ct, 2, k, B, plain), 10)
+        vals = torch.randint(0, t, (4 * B, n), dtype=torch.int64, device=dev)
+        pl = torch.empty_like(vals)
+        dt_enc = timed(lambda: ctx.batch_encode(vals, n, 4 * B, pl), 10)
+        dt_dec = timed(lambda: ctx.batch_decode(pl, 4 * B, vals), 10)
+        dt_val = timed(lambda: ctx.is_data_valid_for(ct, 2, k, B), 10)
+        ctx.set_parms_id(k, (1, 2, 3, 4))
+        info = S.CiphertextInfo()
+        info.parms_id[:] = (1, 2, 3, 4)
+        info.size, info.coeff_modulus_size, info.poly_modulus_degree, info.scale = 2, k, n, 1.0
+        raw = ctx.save_ciphertext(info, ct[0])
+        one = torch.empty((2, k, n), dtype=torch.int64, device=dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.load_ciphertext(raw, one, capacity_words=one.numel())
+        dt_load = (time.perf_counter() - t0) / 20
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.save_ciphertext(info, one)
+        dt_save = (time.perf_counter() - t0) / 20
+        row = 8 * n
+        out.append({"config": "f2/f3/f4 rows at cfg3 size (BFV N=2^15, k=7, t=786433)",
+                    # symmetric: read a (k rows) + sk, write c0, c1 (2k rows), inverse NTT of 2k rows (16N each)
+                    "encrypt_zero_symmetric_ct_per_s": B / dt_sym,
+                    "encrypt_zero_symmetric_hbm_frac": B * (3 * k * row + 2 * k * 2 * row) / dt_sym / 8e12,
+                    # asymmetric: NTT(u) k rows, 2k products written, inverse NTT of 2k rows, + e
+                    "encrypt_zero_asymmetric_ct_per_s": B / dt_asym,
+                    "encrypt_zero_asymmetric_hbm_frac": B * (k * 2 * row + 2 * k * 2 * row + 2 * k * 2 * row + 2 * k * 2 * row) / dt_asym / 8e12,
+                    "add_plain_ct_per_s": B / dt_ap, "add_plain_hbm_frac": B * (row + 2 * k * row) / dt_ap / 8e12,
+                    "batch_encode_plain_per_s": 4 * B / dt_enc, "batch_encode_hbm_frac": 4 * B * 4 * row / dt_enc / 8e12,
+                    "batch_decode_plain_per_s": 4 * B / dt_dec, "batch_decode_hbm_frac": 4 * B * 6 * row / dt_dec / 8e12,
+                    "is_data_valid_for_ct_per_s": B / dt_val, "is_data_valid_for_hbm_frac": B * 2 * k * row / dt_val / 8e12,
+                    "wire_load_GBps_pageable_host": len(raw) / dt_load / 1e9, "wire_save_GBps_pageable_host": len(raw) / dt_save / 1e9,
+                    "wire_bytes_per_ct": len(raw)})
     if want("pcie"):
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
