@@ -508,9 +508,13 @@ namespace sealhip
             tab[row | i] = reverse_bits(static_cast<std::uint32_t>((m - pos - 1) >> 1), logn);
             pos = (pos * 3) & (m - 1);
         }
+        // second half of the table: the inverse permutation (encode gathers through it: coalesced stores)
+        tab.resize(2 * n);
+        for (std::size_t i = 0; i < n; i++)
+            tab[n + tab[i]] = static_cast<std::uint32_t>(i);
         SEALHIP_CHECK(hipSetDevice(device));
-        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_batch_map), sizeof(std::uint32_t) * n));
-        SEALHIP_CHECK(hipMemcpy(d_batch_map, tab.data(), sizeof(std::uint32_t) * n, hipMemcpyHostToDevice));
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_batch_map), sizeof(std::uint32_t) * 2 * n));
+        SEALHIP_CHECK(hipMemcpy(d_batch_map, tab.data(), sizeof(std::uint32_t) * 2 * n, hipMemcpyHostToDevice));
         return d_batch_map;
     }
 

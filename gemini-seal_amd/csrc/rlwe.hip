@@ -125,7 +125,8 @@ namespace sealhip
             }
         }
 
-        // BatchEncoder slot permutation: ENCODE plain[map[i]] = i < nvalues ? values[i] : 0 (batchencoder.cpp:142-149);
+        // BatchEncoder slot permutation: ENCODE plain[map[i]] = i < nvalues ? values[i] : 0 (batchencoder.cpp:142-149), done as a
+        // gather through the inverse table stored behind map;
         // DECODE values[i] = plain[map[i]] (:371-375). One lane per (item, slot).
         template <bool ENCODE>
         __global__ __launch_bounds__(kThreads) void batch_permute_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
@@ -139,7 +140,10 @@ namespace sealhip
             {
                 const std::size_t item = i >> logn, s = i & (n - 1);
                 if (ENCODE)
-                    out[(item << logn) + map[s]] = s < nvalues ? in[item * in_item_stride + s] : 0;
+                {
+                    const std::uint32_t src = map[n + s]; // inverse permutation: plain[s] = values[map^{-1}(s)]
+                    out[(item << logn) + s] = src < nvalues ? in[item * in_item_stride + src] : 0;
+                }
                 else
                     out[(item << logn) + s] = in[item * in_item_stride + map[s]];
             }
