@@ -1190,6 +1190,32 @@ long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t co
     });
 }
 
+long sealhip_ckks_encode(sealhip_context *ctx, uint32_t k, const double *values, size_t n_values, size_t count, double scale,
+                         uint64_t *plain)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    if (n_values)
+        REQUIRE_PTR(values);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_ckks_encode(e, static_cast<int>(k), values, n_values, count, scale, reinterpret_cast<u64 *>(plain));
+    });
+}
+
+long sealhip_ckks_decode(sealhip_context *ctx, uint32_t k, const uint64_t *plain, size_t count, double scale, double *values)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    REQUIRE_PTR(values);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        op_ckks_decode(e, static_cast<int>(k), reinterpret_cast<const u64 *>(plain), count, scale, values);
+    });
+}
+
 long sealhip_ciphertext_resize(sealhip_context *ctx, uint32_t k, const uint64_t *src, uint32_t src_size, uint64_t *dst,
                                uint32_t dst_size, size_t count)
 {

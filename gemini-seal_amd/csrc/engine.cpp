@@ -183,6 +183,14 @@ namespace sealhip
             (void)hipFree(p);
         if (d_batch_map)
             (void)hipFree(d_batch_map);
+        if (d_ckks_map)
+            (void)hipFree(d_ckks_map);
+        if (d_ckks_roots)
+            (void)hipFree(d_ckks_roots);
+        if (d_ckks_inv_roots)
+            (void)hipFree(d_ckks_inv_roots);
+        for (auto &kv : ckks_decode)
+            (void)hipFree(kv.second);
         if (ws)
             (void)hipFree(ws);
         if (d_tickets)
@@ -516,6 +524,131 @@ namespace sealhip
         SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_batch_map), sizeof(std::uint32_t) * 2 * n));
         SEALHIP_CHECK(hipMemcpy(d_batch_map, tab.data(), sizeof(std::uint32_t) * 2 * n, hipMemcpyHostToDevice));
         return d_batch_map;
+    }
+
+    void Engine::ckks_tables()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (d_ckks_map)
+            return;
+        const std::size_t slots = n >> 1, m = n << 1;
+        std::vector<std::uint32_t> tab(2 * n);
+        std::uint64_t pos = 1;
+        for (std::size_t i = 0; i < slots; i++) // ckks.cpp:39-56, generator 5
+        {
+            tab[i] = reverse_bits(static_cast<std::uint32_t>((pos - 1) >> 1), logn);
+            tab[slots | i] = reverse_bits(static_cast<std::uint32_t>((m - pos - 1) >> 1), logn);
+            pos = (pos * 5) & (m - 1);
+        }
+        for (std::size_t i = 0; i < n; i++)
+            tab[n + tab[i]] = static_cast<std::uint32_t>(i);
+        std::vector<double> roots(2 * n), inv(2 * n);
+        for (std::size_t i = 0; i < n; i++) // :62-69
+        {
+            double re, im;
+            complex_root(m, reverse_bits(static_cast<std::uint32_t>(i), logn), re, im);
+            roots[2 * i] = re;
+            roots[2 * i + 1] = im;
+            inv[2 * i] = re;
+            inv[2 * i + 1] = -im;
+        }
+        SEALHIP_CHECK(hipSetDevice(device));
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_ckks_roots), sizeof(double) * 2 * n));
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_ckks_inv_roots), sizeof(double) * 2 * n));
+        SEALHIP_CHECK(hipMemcpy(d_ckks_roots, roots.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+        SEALHIP_CHECK(hipMemcpy(d_ckks_inv_roots, inv.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+        std::uint32_t *dm = nullptr;
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dm), sizeof(std::uint32_t) * 2 * n));
+        SEALHIP_CHECK(hipMemcpy(dm, tab.data(), sizeof(std::uint32_t) * 2 * n, hipMemcpyHostToDevice));
+        d_ckks_map = dm;
+    }
+
+    namespace
+    {
+        std::vector<u64> big_product(const std::vector<u64> &moduli, int k)
+        {
+            std::vector<u64> q(static_cast<std::size_t>(k), 0);
+            q[0] = 1;
+            for (int i = 0; i < k; i++)
+            {
+                u128 carry = 0;
+                for (int l = 0; l < k; l++)
+                {
+                    const u128 v = static_cast<u128>(q[l]) * moduli[i] + carry;
+                    q[l] = static_cast<u64>(v);
+                    carry = v >> 64;
+                }
+            }
+            return q;
+        }
+    } // namespace
+
+    int Engine::total_coeff_modulus_bit_count(int k)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = total_bits.find(k);
+        if (it != total_bits.end())
+            return it->second;
+        const std::vector<u64> q = big_product(key_moduli, k);
+        int bits = 0;
+        for (int l = k; l-- > 0;)
+            if (q[l])
+            {
+                bits = 64 * l + 64 - __builtin_clzll(q[l]);
+                break;
+            }
+        total_bits[k] = bits;
+        return bits;
+    }
+
+    const CkksDecodeDev *Engine::ckks_decode_consts(int k)
+    {
+        if (k < 1 || k > kCkksMaxLimbs || k > n_key)
+            throw std::invalid_argument("CKKS decode supports at most 32 coefficient-modulus primes");
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = ckks_decode.find(k);
+        if (it != ckks_decode.end())
+            return it->second;
+        auto h = std::make_unique<CkksDecodeDev>();
+        std::memset(h.get(), 0, sizeof(CkksDecodeDev));
+        h->k = k;
+        const std::vector<u64> q = big_product(key_moduli, k);
+        u128 carry = 1; // (q + 1) >> 1
+        std::vector<u64> plus(static_cast<std::size_t>(k) + 1, 0);
+        for (int l = 0; l < k; l++)
+        {
+            carry += q[l];
+            plus[l] = static_cast<u64>(carry);
+            carry >>= 64;
+        }
+        plus[k] = static_cast<u64>(carry);
+        for (int l = 0; l < k; l++)
+        {
+            h->q[l] = q[l];
+            h->half[l] = (plus[l] >> 1) | (plus[l + 1] << 63);
+        }
+        for (int i = 0; i < k; i++)
+        {
+            const u64 qi = key_moduli[i];
+            u128 rem = 0;
+            for (int l = k; l-- > 0;) // q / q_i
+            {
+                const u128 cur = (rem << 64) | q[l];
+                h->punct[i * kCkksMaxLimbs + l] = static_cast<u64>(cur / qi);
+                rem = cur % qi;
+            }
+            u128 r = 0;
+            for (int l = k; l-- > 0;)
+                r = ((r << 64) | h->punct[i * kCkksMaxLimbs + l]) % qi;
+            if (!invmod(static_cast<u64>(r), qi, h->inv_punct[i]))
+                throw std::invalid_argument("coefficient moduli are not coprime");
+        }
+        SEALHIP_CHECK(hipSetDevice(device));
+        CkksDecodeDev *dev = nullptr;
+        SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(CkksDecodeDev)));
+        SEALHIP_CHECK(hipMemcpy(dev, h.get(), sizeof(CkksDecodeDev), hipMemcpyHostToDevice));
+        ckks_decode.emplace(k, dev);
+        return dev;
     }
 
     void Engine::ws_reserve(std::size_t bytes)

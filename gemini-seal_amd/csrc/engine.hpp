@@ -126,6 +126,17 @@ namespace sealhip
         u64 invP[kMaxModuli], invP_shoup[kMaxModuli];        // [k]  P^{-1} mod q_i
     };
 
+    // ---- CKKSEncoder::decode constants for the first k primes (RNSBase of the level, rns.cpp:237-290; context.cpp:370-376)
+    constexpr int kCkksMaxLimbs = 32;
+    struct CkksDecodeDev
+    {
+        int k;
+        u64 q[kCkksMaxLimbs];         // total_coeff_modulus, little-endian limbs
+        u64 half[kCkksMaxLimbs];      // upper_half_threshold = (q + 1) >> 1
+        u64 inv_punct[kCkksMaxLimbs]; // (q / q_i)^{-1} mod q_i
+        u64 punct[kCkksMaxLimbs * kCkksMaxLimbs]; // q / q_i, limbs of row i at i * kCkksMaxLimbs
+    };
+
     struct LevelTools
     {
         std::unique_ptr<HostRnsTool> host_rns; // BFV + CKKS (CKKS only uses inv_q_last_mod_q)
@@ -174,6 +185,14 @@ namespace sealhip
         // parms_id of level k (k = n_key: key level), registered by the binding (SEALContext computes them with Blake2,
         // encryptionparams.cpp:132-166); used by the wire-format loader to find a ciphertext's level
         std::map<int, std::array<std::uint64_t, 4>> parms_ids;
+        // CKKSEncoder tables (ckks.cpp:37-76): slot map + its inverse (2N words), roots and inverse roots (N complex each)
+        std::uint32_t *d_ckks_map = nullptr;
+        double *d_ckks_roots = nullptr, *d_ckks_inv_roots = nullptr;
+        std::map<int, CkksDecodeDev *> ckks_decode;
+        std::map<int, int> total_bits; // significant bits of q_0...q_{k-1} (context.cpp:178)
+        void ckks_tables();
+        const CkksDecodeDev *ckks_decode_consts(int k);
+        int total_coeff_modulus_bit_count(int k);
         int plain_prime = -1;                  // prime id of the plain modulus when batching is possible (context.cpp:262-275)
         std::uint32_t *d_batch_map = nullptr;  // BatchEncoder::matrix_reps_index_map_ (batchencoder.cpp:70-94)
         const std::uint32_t *batch_map();
@@ -400,6 +419,19 @@ namespace sealhip
     // batchencoder.cpp:113-154 / :339-376 (needs a prime plain modulus = 1 mod 2N: Engine::plain_prime >= 0)
     void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain);
     void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values);
+
+    // CKKSEncoder (ckks_encoder.hip)
+    hipError_t launch_ckks_encode_front(const Engine &e, const double *values, std::size_t n_values, std::size_t count,
+                                        double n_inv_scale, double *cv, u64 *out, int rows, const std::uint32_t *map,
+                                        const double *inv_roots, int *max_bits);
+    hipError_t launch_ckks_decode_back(const Engine &e, const u64 *coeff, const CkksDecodeDev *d, int k, std::size_t count,
+                                       double inv_scale, double *res, double *values, const std::uint32_t *map,
+                                       const double *roots);
+    // values: count x n_values complex doubles (device); plain: count x k x N, NTT form
+    void op_ckks_encode(Engine &e, int k, const double *values, std::size_t n_values, std::size_t count, double scale,
+                        u64 *plain);
+    // values out: count x N/2 complex doubles
+    void op_ckks_decode(Engine &e, int k, const u64 *plain, std::size_t count, double scale, double *values);
 
     std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
                                         bool strict, int device);

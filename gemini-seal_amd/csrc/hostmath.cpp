@@ -1,6 +1,8 @@
 // hostmath.cpp -- see hostmath.hpp
 #include "hostmath.hpp"
 
+#include <cmath>
+
 #include <algorithm>
 
 namespace sealhip
@@ -157,6 +159,44 @@ namespace sealhip
         for (int i = 0; i < bit_count; i++)
             r |= ((x >> i) & 1u) << (bit_count - 1 - i);
         return r;
+    }
+
+    void complex_root(std::size_t m, std::size_t index, double &re, double &im)
+    {
+        static const double PI_ = 3.1415926535897932384626433832795028842; // croots.h:27
+        index &= m - 1;
+        double a, b;
+        if (index <= m / 8)
+        {
+            const double th = 2 * PI_ * static_cast<double>(index) / static_cast<double>(m); // std::polar(1.0, th)
+            // one libm entry point for both parts: glibc's sincos and sin/cos differ in the last bit for a few angles (1 of
+            // 1025 at m = 8192), and an optimising compiler picks either for std::polar; the oracle calls sincos too
+            ::sincos(th, &im, &re);
+        }
+        else if (index <= m / 4)
+        {
+            complex_root(m, m / 4 - index, a, b);
+            re = b;
+            im = a;
+        }
+        else if (index <= m / 2)
+        {
+            complex_root(m, m / 2 - index, a, b);
+            re = -a;
+            im = b;
+        }
+        else if (index <= 3 * m / 4)
+        {
+            complex_root(m, index - m / 2, a, b);
+            re = -a;
+            im = -b;
+        }
+        else
+        {
+            complex_root(m, m - index, a, b);
+            re = a;
+            im = -b;
+        }
     }
 
     void HostNttTables::build(int logn_, u64 p_)

@@ -42,6 +42,8 @@ namespace sealhip
     // smallest of all primitive degree-th roots of unity mod p (numth.cpp:398-424)
     bool minimal_primitive_root(u64 degree, u64 p, u64 &root);
     std::uint32_t reverse_bits(std::uint32_t x, int bit_count);
+    // util::ComplexRoots::get_root (util/croots.cpp:17-70): exp(2 pi i index / degree) through the 8-fold symmetry
+    void complex_root(std::size_t degree, std::size_t index, double &re, double &im);
 
     // Twiddle tables of one prime. Device layout (ours, not the reference's): for each direction an
     // array of N pairs {w, floor(w*2^64/p)} indexed by the bit-reversed exponent, i.e. entry i holds

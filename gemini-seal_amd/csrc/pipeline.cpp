@@ -5,6 +5,8 @@
 // one stream, so temporaries are reused in stream order without host synchronisation.
 #include "engine.hpp"
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -692,6 +694,68 @@ namespace sealhip
             check(launch_copy_rows(e, plain + off * N, N, tmp, N, m, 1), "copy(plain)");
             check(launch_ntt(e, tmp, m, map, false, kNttCanonical), "ntt(plain)");
             check(launch_batch_permute(e, false, tmp, N, N, values + off * N, e.batch_map(), m), "batch gather");
+        }
+    }
+    // ---------------------------------------------------------------- CKKSEncoder
+    void op_ckks_encode(Engine &e, int k, const double *values, std::size_t n_values, std::size_t count, double scale,
+                        u64 *plain)
+    {
+        if (e.scheme != 2)
+            throw std::invalid_argument("unsupported scheme"); // ckks.cpp:27-30
+        if (n_values > e.n / 2)
+            throw std::invalid_argument("values_size is too large"); // ckks.h:419-422
+        const int total_bits = e.total_coeff_modulus_bit_count(k);
+        if (scale <= 0 || (static_cast<int>(std::log2(scale)) + 1 >= total_bits))
+            throw std::invalid_argument("scale out of bounds"); // :440-444
+        e.ckks_tables();
+        const RowMap map_q = e.level_host(k).map_q;
+        const std::size_t N = e.n;
+        double n_inv = 1.0 / static_cast<double>(N); // :484-487
+        n_inv *= scale;
+        const std::size_t chunk = plan_chunk(e, count, N * 2 * sizeof(double), 2);
+        int h_max = 1;
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            int *d_max = reinterpret_cast<int *>(e.ws_alloc(1));
+            double *cv = reinterpret_cast<double *>(e.ws_alloc(2 * N * m));
+            SEALHIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), e.stream));
+            check(launch_ckks_encode_front(e, values + off * n_values * 2, n_values, m, n_inv, cv,
+                                           plain + off * static_cast<std::size_t>(k) * N, k, e.d_ckks_map, e.d_ckks_inv_roots, d_max),
+                  "ckks encode");
+            int got = 0;
+            SEALHIP_CHECK(hipMemcpyAsync(&got, d_max, sizeof(int), hipMemcpyDeviceToHost, e.stream));
+            SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+            h_max = std::max(h_max, got);
+        }
+        if (h_max >= total_bits)
+            throw std::invalid_argument("encoded values are too large"); // :501-504
+        check(launch_ntt(e, plain, count * k, map_q, false, kNttCanonical), "ntt(plain)"); // :609-613
+    }
+
+    void op_ckks_decode(Engine &e, int k, const u64 *plain, std::size_t count, double scale, double *values)
+    {
+        if (e.scheme != 2)
+            throw std::invalid_argument("unsupported scheme");
+        if (scale <= 0 || (static_cast<int>(std::log2(scale)) >= e.total_coeff_modulus_bit_count(k)))
+            throw std::invalid_argument("scale out of bounds"); // ckks.h:651-656
+        e.ckks_tables();
+        const CkksDecodeDev *consts = e.ckks_decode_consts(k);
+        const RowMap map_q = e.level_host(k).map_q;
+        const std::size_t N = e.n, poly = static_cast<std::size_t>(k) * N;
+        const double inv_scale = 1.0 / scale; // :668
+        const std::size_t chunk = plan_chunk(e, count, poly * sizeof(u64) + N * 2 * sizeof(double), 2);
+        for (std::size_t off = 0; off < count; off += chunk)
+        {
+            const std::size_t m = std::min(chunk, count - off);
+            e.ws_reset();
+            u64 *copy = e.ws_alloc(poly * m);
+            double *res = reinterpret_cast<double *>(e.ws_alloc(2 * N * m));
+            check(launch_copy_rows(e, plain + off * poly, poly, copy, poly, m, k), "copy(plain)");
+            check(launch_ntt(e, copy, m * k, map_q, true, kNttCanonical), "intt(plain)"); // :674-678
+            check(launch_ckks_decode_back(e, copy, consts, k, m, inv_scale, res, values + off * N, e.d_ckks_map, e.d_ckks_roots),
+                  "ckks decode");
         }
     }
 } // namespace sealhip

@@ -124,6 +124,8 @@ SYMBOLS = {
     "sealhip_ciphertext_save": [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)],
     "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
+    "sealhip_ckks_encode": [_vp, _u32, _vp, _sz, _sz, C.c_double, _vp],
+    "sealhip_ckks_decode": [_vp, _u32, _vp, _sz, C.c_double, _vp],
 }
 
 
@@ -385,6 +387,27 @@ class Context:
         stride = self.n if plain_stride is None else plain_stride
         _check(lib().sealhip_multiply_add_plain_with_scaling_variant(self.handle, k, _ptr(plain), stride, _ptr(ct), size,
                                                                      count, 1 if subtract else 0))
+
+    def ckks_encode(self, values, k, scale, plain=None):
+        """CKKSEncoder::encode (ckks.h:405-617): values = numpy complex array [count][n_values] -> device plaintexts
+        [count][k][N] (NTT form)"""
+        values = np.ascontiguousarray(values, dtype=np.complex128)
+        count, nv = values.shape
+        dv = DeviceBuffer(self, values.size * 2).upload(values.view(np.uint64))
+        if plain is None:
+            plain = self.alloc(count * k * self.n)
+        _check(lib().sealhip_ckks_encode(self.handle, k, _ptr(dv), nv, count, float(scale), _ptr(plain)))
+        self.synchronize()
+        dv.free()
+        return plain
+
+    def ckks_decode(self, plain, k, count, scale):
+        """CKKSEncoder::decode (ckks.h:623-747) -> numpy complex array [count][N/2]"""
+        out = self.alloc(count * self.n)
+        _check(lib().sealhip_ckks_decode(self.handle, k, _ptr(plain), count, float(scale), _ptr(out)))
+        res = out.download().view(np.complex128).reshape(count, self.n // 2)
+        out.free()
+        return res
 
     # ---- SURVEY 8(f3): ciphertext wire format
     def set_parms_id(self, k, parms_id):

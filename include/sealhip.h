@@ -273,6 +273,15 @@ long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_b
 long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain);
 long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values);
 
+/* CKKSEncoder::encode (ckks.h:405-617) / decode (:623-747), double precision. values: complex numbers as (re, im) pairs
+   of doubles in device memory. encode: values[count][n_values] (n_values <= N/2; the other slots are zero) -> plain
+   [count][k][N] in NTT form at `scale`; decode: plain[count][k][N] -> values[count][N/2]. Every floating-point operation
+   is issued in the reference's order without contraction, so the outputs equal the reference's bits given the same root
+   tables (host libm). E_INVALIDARG: "scale out of bounds", "encoded values are too large", "values_size is too large". */
+long sealhip_ckks_encode(sealhip_context *ctx, uint32_t k, const double *values, size_t n_values, size_t count, double scale,
+                         uint64_t *plain);
+long sealhip_ckks_decode(sealhip_context *ctx, uint32_t k, const uint64_t *plain, size_t count, double scale, double *values);
+
 /* Ciphertext::resize (ciphertext.cpp:84-124) over a device-resident batch: dst[count][dst_size][k][N] receives the first
    min(src_size, dst_size) polynomials of every src[count][src_size][k][N]; added polynomials are zero (IntArray::resize).
    What a chain needs between relinearize (which leaves the batch stride at its old size) and the next multiply. */

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * oracle/sealref.c -- CPU restatement of the Gemini-SEAL hot path (TEST INFRASTRUCTURE ONLY).
  * See sealref.h for scope, parity status and the rules about who may load this file.
@@ -6,6 +7,7 @@
 #include "sealref.h"
 
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 typedef unsigned __int128 u128;
@@ -1803,6 +1805,323 @@ void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain,
         values[i] = tmp[map[i]];
     free(tmp);
     free(map);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CKKSEncoder (ckks.cpp:14-77, ckks.h:405-747). Double-precision FFT; every floating-point operation
+ * is written in the order the reference's std::complex<double> arithmetic performs it (no contraction, no re-association),
+ * so a second implementation that keeps this order produces the same bits.
+ * ---------------------------------------------------------------------------------------- */
+static void croot(size_t m, size_t index, double *re, double *im) /* util/croots.cpp:42-70 */
+{
+    static const double PI_ = 3.1415926535897932384626433832795028842;
+    index &= m - 1;
+    if (index <= m / 8)
+    {
+        const double th = 2 * PI_ * (double)index / (double)m; /* std::polar(1.0, th), croots.cpp:35-39 */
+        sincos(th, im, re); /* what gcc -O3 makes of the cos/sin pair; differs from sin()/cos() in a few last bits */
+    }
+    else if (index <= m / 4)
+    {
+        double a, b;
+        croot(m, m / 4 - index, &a, &b);
+        *re = b;
+        *im = a;
+    }
+    else if (index <= m / 2)
+    {
+        double a, b;
+        croot(m, m / 2 - index, &a, &b);
+        *re = -a;
+        *im = b; /* -conj */
+    }
+    else if (index <= 3 * m / 4)
+    {
+        double a, b;
+        croot(m, index - m / 2, &a, &b);
+        *re = -a;
+        *im = -b;
+    }
+    else
+    {
+        double a, b;
+        croot(m, m - index, &a, &b);
+        *re = a;
+        *im = -b;
+    }
+}
+
+int ref_ckks_encoder_init(ref_ckks_encoder *enc, int logn)
+{
+    const size_t n = (size_t)1 << logn, slots = n >> 1, m = n << 1;
+    if (logn < 2)
+        return -1;
+    enc->logn = logn;
+    enc->n = n;
+    enc->index_map = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    enc->roots = (double *)malloc(sizeof(double) * 2 * n);
+    enc->inv_roots = (double *)malloc(sizeof(double) * 2 * n);
+    uint64_t pos = 1;
+    for (size_t i = 0; i < slots; i++) /* ckks.cpp:39-56, generator 5 */
+    {
+        enc->index_map[i] = bitrev32((uint32_t)((pos - 1) >> 1), logn);
+        enc->index_map[slots | i] = bitrev32((uint32_t)((m - pos - 1) >> 1), logn);
+        pos = (pos * 5) & (m - 1);
+    }
+    for (size_t i = 0; i < n; i++) /* :62-69 */
+    {
+        double re, im;
+        croot(m, bitrev32((uint32_t)i, logn), &re, &im);
+        enc->roots[2 * i] = re;
+        enc->roots[2 * i + 1] = im;
+        enc->inv_roots[2 * i] = re;
+        enc->inv_roots[2 * i + 1] = -im;
+    }
+    return 0;
+}
+
+void ref_ckks_encoder_free(ref_ckks_encoder *enc)
+{
+    free(enc->index_map);
+    free(enc->roots);
+    free(enc->inv_roots);
+}
+
+/* significant bits of q_0 * ... * q_{rows-1} (context.cpp:178) */
+static int total_bit_count(const ref_context *c, size_t rows)
+{
+    uint64_t q[64];
+    big_product(c, rows, q);
+    for (size_t l = rows; l-- > 0;)
+        if (q[l])
+            return (int)(64 * l) + 64 - __builtin_clzll(q[l]);
+    return 0;
+}
+
+/* ckks.h:405-617. values: n_values complex numbers (re, im interleaved), n_values <= n/2; out: rows x n, NTT form.
+ * returns 0, -1 scale out of bounds, -2 encoded values are too large */
+int ref_ckks_encode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const double *values, size_t n_values,
+                    double scale, uint64_t *out)
+{
+    const size_t n = enc->n, slots = n >> 1;
+    const int logn = enc->logn, total_bits = total_bit_count(c, rows);
+    if (scale <= 0 || ((int)log2(scale) + 1 >= total_bits))
+        return -1;
+    double *cv = (double *)calloc(2 * n, sizeof(double));
+    for (size_t i = 0; i < n_values; i++) /* :452-456 */
+    {
+        cv[2 * enc->index_map[i]] = values[2 * i];
+        cv[2 * enc->index_map[i] + 1] = values[2 * i + 1];
+        cv[2 * enc->index_map[i + slots]] = values[2 * i];
+        cv[2 * enc->index_map[i + slots] + 1] = -values[2 * i + 1];
+    }
+    size_t tt = 1;
+    for (int i = 0; i < logn; i++) /* :458-482 */
+    {
+        const size_t mm = (size_t)1 << (logn - i), h = mm / 2;
+        size_t k_start = 0;
+        for (size_t j = 0; j < h; j++)
+        {
+            const double sr = enc->inv_roots[2 * (h + j)], si = enc->inv_roots[2 * (h + j) + 1];
+            for (size_t k = k_start; k < k_start + tt; k++)
+            {
+                const double ur = cv[2 * k], ui = cv[2 * k + 1], vr = cv[2 * (k + tt)], vi = cv[2 * (k + tt) + 1];
+                const double dr = ur - vr, di = ui - vi;
+                cv[2 * k] = ur + vr;
+                cv[2 * k + 1] = ui + vi;
+                cv[2 * (k + tt)] = dr * sr - di * si;
+                cv[2 * (k + tt) + 1] = dr * si + di * sr;
+            }
+            k_start += 2 * tt;
+        }
+        tt *= 2;
+    }
+    double n_inv = 1.0 / (double)n;
+    n_inv *= scale;
+    int max_bits = 1;
+    for (size_t i = 0; i < n; i++) /* :489-500 */
+    {
+        cv[2 * i] *= n_inv;
+        cv[2 * i + 1] *= n_inv;
+        const double d = fmax(fabs(cv[2 * i]), 1.0);
+        const int b = (int)log2(d) + 2;
+        if (b > max_bits)
+            max_bits = b;
+    }
+    if (max_bits >= total_bits)
+    {
+        free(cv);
+        return -2;
+    }
+    const double two_pow_64 = 18446744073709551616.0;
+    for (size_t i = 0; i < n; i++)
+    {
+        double coeffd = round(cv[2 * i]);
+        const int negative = signbit(coeffd) != 0;
+        coeffd = fabs(coeffd);
+        for (size_t j = 0; j < rows; j++)
+        {
+            const ref_modulus *m = &c->key_mod[j];
+            uint64_t r;
+            if (max_bits <= 64) /* :515-540 */
+                r = (uint64_t)coeffd % m->value;
+            else if (max_bits <= 128) /* :541-568 */
+                r = ref_barrett_reduce_128((uint64_t)fmod(coeffd, two_pow_64), (uint64_t)(coeffd / two_pow_64), m);
+            else /* :569-607 with RNSBase::decompose (rns.cpp:292-325) */
+            {
+                uint64_t limbs[64] = { 0 };
+                size_t nl = 0;
+                for (double x = coeffd; x >= 1; x /= two_pow_64)
+                    limbs[nl++] = (uint64_t)fmod(x, two_pow_64);
+                uint64_t hi = limbs[rows - 1];
+                if (rows > 1)
+                    for (size_t l = rows - 1; l--;)
+                        hi = ref_barrett_reduce_128(limbs[l], hi, m);
+                else
+                    hi %= m->value;
+                r = hi;
+            }
+            out[j * n + i] = negative ? (r ? m->value - r : 0) : r; /* negate_uint_mod */
+        }
+    }
+    for (size_t j = 0; j < rows; j++) /* :609-613 */
+        ref_ntt_forward(out + j * n, &c->key_tables[j], 0);
+    free(cv);
+    return 0;
+}
+
+/* ckks.h:623-747. plain: rows x n in NTT form; values: n/2 complex numbers out. returns 0 / -1 scale out of bounds */
+int ref_ckks_decode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const uint64_t *plain, double scale,
+                    double *values)
+{
+    const size_t n = enc->n, slots = n >> 1;
+    const int logn = enc->logn;
+    if (scale <= 0 || ((int)log2(scale) >= total_bit_count(c, rows)))
+        return -1;
+    const double inv_scale = 1.0 / scale;
+    uint64_t *copy = (uint64_t *)malloc(sizeof(uint64_t) * rows * n);
+    memcpy(copy, plain, sizeof(uint64_t) * rows * n);
+    for (size_t j = 0; j < rows; j++) /* :674-678 */
+        ref_ntt_inverse(copy + j * n, &c->key_tables[j]);
+    /* RNSBase::compose_array (rns.cpp:386-450): x = sum_i (x_i * (Q/q_i)^{-1} mod q_i) * (Q/q_i) mod Q */
+    uint64_t Q[64], half[65], punct[64][64], invp[64];
+    big_product(c, rows, Q);
+    {
+        /* upper_half_threshold = (Q + 1) >> 1 (context.cpp:370-376) */
+        unsigned __int128 carry = 1;
+        for (size_t l = 0; l < rows; l++)
+        {
+            carry += Q[l];
+            half[l] = (uint64_t)carry;
+            carry >>= 64;
+        }
+        half[rows] = (uint64_t)carry;
+        for (size_t l = 0; l < rows; l++)
+            half[l] = (half[l] >> 1) | (half[l + 1] << 63);
+    }
+    for (size_t i = 0; i < rows; i++)
+    {
+        const uint64_t qi = c->key_mod[i].value;
+        big_divide_word(Q, rows, qi, punct[i]);
+        uint64_t r = big_mod_word(punct[i], rows, qi);
+        ref_try_invert_uint_mod(r, qi, &invp[i]);
+    }
+    double *res = (double *)calloc(2 * n, sizeof(double));
+    const double two_pow_64 = 18446744073709551616.0;
+    for (size_t ci = 0; ci < n; ci++)
+    {
+        uint64_t acc[65] = { 0 };
+        for (size_t i = 0; i < rows; i++)
+        {
+            const uint64_t t = ref_multiply_uint_mod(copy[i * n + ci], invp[i], &c->key_mod[i]);
+            unsigned __int128 carry = 0;
+            for (size_t l = 0; l < rows; l++) /* acc += t * punct_i */
+            {
+                carry += (unsigned __int128)t * punct[i][l] + acc[l];
+                acc[l] = (uint64_t)carry;
+                carry >>= 64;
+            }
+            acc[rows] += (uint64_t)carry;
+            /* acc < 2Q: one conditional subtraction (add_uint_uint_mod) */
+            int ge = acc[rows] != 0;
+            if (!ge)
+            {
+                ge = 1;
+                for (size_t l = rows; l-- > 0;)
+                    if (acc[l] != Q[l])
+                    {
+                        ge = acc[l] > Q[l];
+                        break;
+                    }
+            }
+            if (ge)
+            {
+                unsigned __int128 borrow = 0;
+                for (size_t l = 0; l < rows; l++)
+                {
+                    const unsigned __int128 d = (unsigned __int128)acc[l] - Q[l] - borrow;
+                    acc[l] = (uint64_t)d;
+                    borrow = (d >> 64) & 1;
+                }
+                acc[rows] = 0;
+            }
+        }
+        int upper = 1; /* is_greater_than_or_equal_uint(acc, upper_half_threshold) */
+        for (size_t l = rows; l-- > 0;)
+            if (acc[l] != half[l])
+            {
+                upper = acc[l] > half[l];
+                break;
+            }
+        double r = 0.0, scaled = inv_scale; /* :686-715 */
+        for (size_t j = 0; j < rows; j++, scaled *= two_pow_64)
+        {
+            if (upper)
+            {
+                if (acc[j] > Q[j])
+                {
+                    const uint64_t diff = acc[j] - Q[j];
+                    r += diff ? (double)diff * scaled : 0.0;
+                }
+                else
+                {
+                    const uint64_t diff = Q[j] - acc[j];
+                    r -= diff ? (double)diff * scaled : 0.0;
+                }
+            }
+            else
+                r += acc[j] ? (double)acc[j] * scaled : 0.0;
+        }
+        res[2 * ci] = r;
+    }
+    size_t tt = n;
+    for (int i = 0; i < logn; i++) /* :723-741 */
+    {
+        const size_t mm = (size_t)1 << i;
+        tt >>= 1;
+        for (size_t j = 0; j < mm; j++)
+        {
+            const size_t j1 = 2 * j * tt;
+            const double sr = enc->roots[2 * (mm + j)], si = enc->roots[2 * (mm + j) + 1];
+            for (size_t k = j1; k < j1 + tt; k++)
+            {
+                const double ur = res[2 * k], ui = res[2 * k + 1], xr = res[2 * (k + tt)], xi = res[2 * (k + tt) + 1];
+                const double vr = xr * sr - xi * si, vi = xr * si + xi * sr;
+                res[2 * k] = ur + vr;
+                res[2 * k + 1] = ui + vi;
+                res[2 * (k + tt)] = ur - vr;
+                res[2 * (k + tt) + 1] = ui - vi;
+            }
+        }
+    }
+    for (size_t i = 0; i < slots; i++) /* :743-746 */
+    {
+        values[2 * i] = res[2 * enc->index_map[i]];
+        values[2 * i + 1] = res[2 * enc->index_map[i] + 1];
+    }
+    free(res);
+    free(copy);
+    return 0;
 }
 
 void ref_generate_kswitch_key(const ref_context *c, const uint64_t *sk_ntt, const uint64_t *new_key_ntt,

@@ -225,6 +225,24 @@ void ref_multiply_add_plain_with_scaling_variant(const ref_context *c, size_t k,
 void ref_batch_index_map(int logn, uint32_t *map);
 void ref_batch_encode(const ref_ntt_tables *plain_tables, const uint64_t *values, size_t count, uint64_t *plain);
 void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, uint64_t *values);
+/* ---- CKKSEncoder (ckks.cpp:14-77, ckks.h:405-747), double precision ---- */
+typedef struct
+{
+    int logn;
+    size_t n;
+    uint32_t *index_map; /* matrix_reps_index_map_, generator 5 */
+    double *roots;       /* n complex numbers (re, im): roots_[i] = zeta^{bitrev(i)}, zeta = exp(2 pi i / 2n) */
+    double *inv_roots;   /* conjugates */
+} ref_ckks_encoder;
+int ref_ckks_encoder_init(ref_ckks_encoder *enc, int logn);
+void ref_ckks_encoder_free(ref_ckks_encoder *enc);
+/* values: n_values <= n/2 complex numbers (re, im interleaved); out: rows x n in NTT form over key primes 0..rows-1.
+ * 0 ok, -1 scale out of bounds, -2 encoded values are too large */
+int ref_ckks_encode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const double *values, size_t n_values,
+                    double scale, uint64_t *out);
+/* plain: rows x n (NTT form) -> n/2 complex numbers */
+int ref_ckks_decode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const uint64_t *plain, double scale,
+                    double *values);
 /* Encryptor::encrypt (BFV, symmetric): encrypt_zero + multiply_add_plain_with_scaling_variant (util/scalingvariant.cpp:15-52) */
 void ref_bfv_encrypt_symmetric(const ref_context *c, size_t k, const uint64_t *sk_ntt, const uint64_t *plain,
                                uint64_t *state, uint64_t *ct);

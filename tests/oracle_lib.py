@@ -38,6 +38,11 @@ class NttTables(C.Structure):
     ]
 
 
+class CkksEncoder(C.Structure):
+    _fields_ = [("logn", C.c_int), ("n", szt), ("index_map", C.POINTER(C.c_uint32)), ("roots", C.POINTER(C.c_double)),
+                ("inv_roots", C.POINTER(C.c_double))]
+
+
 class BaseConverter(C.Structure):
     _fields_ = [
         ("isize", szt),
@@ -208,11 +213,46 @@ def lib():
     L.ref_batch_encode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
     L.ref_batch_decode.restype = None
     L.ref_batch_decode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
+    L.ref_ckks_encoder_init.argtypes = [C.POINTER(CkksEncoder), C.c_int]
+    L.ref_ckks_encoder_free.argtypes = [C.POINTER(CkksEncoder)]
+    L.ref_ckks_encoder_free.restype = None
+    L.ref_ckks_encode.argtypes = [C.POINTER(Context), C.POINTER(CkksEncoder), szt, C.c_void_p, szt, C.c_double, C.c_void_p]
+    L.ref_ckks_decode.argtypes = [C.POINTER(Context), C.POINTER(CkksEncoder), szt, C.c_void_p, C.c_double, C.c_void_p]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]
     _LIB = L
     return L
+
+
+class CkksRef:
+    """CKKSEncoder restated (ckks.cpp:14-77, ckks.h:405-747) on top of a RefContext"""
+
+    def __init__(self, ref):
+        self.ref, self.enc = ref, CkksEncoder()
+        assert lib().ref_ckks_encoder_init(C.byref(self.enc), int(ref.c.logn)) == 0
+        self.n = int(ref.c.n)
+
+    def encode(self, values, rows, scale):
+        values = np.ascontiguousarray(values, dtype=np.complex128)
+        out = np.zeros((rows, self.n), dtype=np.uint64)
+        rc = lib().ref_ckks_encode(C.byref(self.ref.c), C.byref(self.enc), rows, values.ctypes.data_as(C.c_void_p),
+                                   len(values), scale, ptr(out))
+        return rc, out
+
+    def decode(self, plain, scale):
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros(self.n // 2, dtype=np.complex128)
+        rc = lib().ref_ckks_decode(C.byref(self.ref.c), C.byref(self.enc), plain.shape[0], ptr(plain), scale,
+                                   out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return out
+
+    def __del__(self):
+        try:
+            lib().ref_ckks_encoder_free(C.byref(self.enc))
+        except Exception:
+            pass
 
 
 def ptr(a):

@@ -554,3 +554,56 @@ def test_f4_batch_encoder_reference_kats_and_slot_semantics():
     half = n // 2
     want = np.concatenate([np.roll(a[:half], -1), np.roll(a[half:], -1)])
     assert np.array_equal(back, want)
+
+
+# ---------------------------------------------------------------- CKKSEncoder
+@pytest.mark.parametrize("logn,bits,scale_log2", [(6, [40] * 4, 16), (7, [60] * 4, 40), (6, [60] * 4, 110), (6, [60] * 4, 130),
+                                                  (10, [30] * 5, 40)])
+def test_f4_ckks_encoder_roundtrip_like_the_reference_tests(logn, bits, scale_log2):
+    """native/tests/seal/ckks.cpp:18-246 restated: integer-valued random vectors (|v| < 2^30, also complex), scales 2^16,
+    2^40, 2^110 and 2^130 (the three decomposition paths of ckks.h:515-607), |decode(encode(v)) - v| < 0.5; a short
+    input leaves the other slots at zero; the all-c vector encodes to the constant polynomial round(c * scale)."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    ref = O.RefContext(2, logn, kmods, nsp=1)
+    ck = O.CkksRef(ref)
+    rows, scale = len(bits) - 1, 2.0 ** scale_log2
+    rng = np.random.default_rng(logn + scale_log2)
+    bound = 1 << (30 if scale_log2 <= 40 and bits[0] >= 40 else 8)
+    v = rng.integers(-bound, bound, size=n // 2) + 1j * rng.integers(-bound, bound, size=n // 2)
+    rc, plain = ck.encode(v, rows, scale)
+    assert rc == 0
+    back = ck.decode(plain, scale)
+    assert np.max(np.abs(back - v)) < 0.5
+    rc, plain = ck.encode(v[:5], rows, scale)
+    back = ck.decode(plain, scale)
+    assert np.max(np.abs(back[:5] - v[:5])) < 0.5 and np.max(np.abs(back[5:])) < 0.5
+    # constant vector -> constant polynomial
+    rc, plain = ck.encode(np.full(n // 2, 3.0 + 0j), rows, scale)
+    assert rc == 0
+    for r in range(rows):
+        row = plain[r].copy()
+        L.ref_ntt_inverse(O.ptr(row), ref.tables(r))
+        assert int(row[0]) == int(3 * scale) % kmods[r] and not row[1:].any()
+    # errors (ckks.h:440-444, :501-504)
+    assert ck.encode(v, rows, 2.0 ** 300)[0] == -1
+    assert ck.encode(v * 2.0 ** 20, 1, 2.0 ** (bits[0] - 12))[0] == -2
+
+
+def test_f4_ckks_encoder_slotwise_product():
+    """The encoding is a ring homomorphism: the negacyclic product of two encodings decodes (at scale^2) to the slot-wise
+    product, which pins the index map (generator 5) and the root tables against the NTT-side arithmetic."""
+    logn, n = 7, 128
+    kmods = O.coeff_modulus_create(n, [50] * 4)
+    ref = O.RefContext(2, logn, kmods, nsp=1)
+    ck = O.CkksRef(ref)
+    rng = np.random.default_rng(3)
+    a = rng.integers(-1000, 1000, size=n // 2) + 1j * rng.integers(-1000, 1000, size=n // 2)
+    b = rng.integers(-1000, 1000, size=n // 2) + 1j * rng.integers(-1000, 1000, size=n // 2)
+    scale = 2.0 ** 30
+    pa, pb = ck.encode(a, 3, scale)[1], ck.encode(b, 3, scale)[1]
+    prod = np.zeros_like(pa)
+    for r in range(3):
+        L.ref_dyadic_product_coeffmod(O.ptr(pa[r]), O.ptr(pb[r]), n, C.byref(ref.c.key_mod[r]), O.ptr(prod[r]))
+    got = ck.decode(prod, scale * scale)
+    assert np.max(np.abs(got - a * b)) < 1e-3 * np.max(np.abs(a * b))

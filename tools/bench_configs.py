@@ -188,6 +188,16 @@ def main():
         for _ in range(20):
             ctx.save_ciphertext(info, one)
         dt_save = (time.perf_counter() - t0) / 20
+        # CKKSEncoder at cfg4 size (N=2^15, k=11): 256 plaintexts of N/2 complex slots
+        cctx = S.Context(S.SCHEME_CKKS, 15, P15_12, 1, 0)
+        cctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        CB, ck = 256, 11
+        cv = torch.randn((CB, n // 2, 2), dtype=torch.float64, device=dev) * 1000.0
+        cpl = torch.empty((CB, ck, n), dtype=torch.int64, device=dev)
+        cout = torch.empty((CB, n // 2, 2), dtype=torch.float64, device=dev)
+        lib = S.lib()
+        dt_cenc = timed(lambda: S._check(lib.sealhip_ckks_encode(cctx.handle, ck, cv.data_ptr(), n // 2, CB, 2.0 ** 40, cpl.data_ptr())), 5)
+        dt_cdec = timed(lambda: S._check(lib.sealhip_ckks_decode(cctx.handle, ck, cpl.data_ptr(), CB, 2.0 ** 40, cout.data_ptr())), 5)
         row = 8 * n
         out.append({"config": "f2/f3/f4 rows at cfg3 size (BFV N=2^15, k=7, t=786433)",
                     # symmetric: read a (k rows) + sk, write c0, c1 (2k rows), inverse NTT of 2k rows (16N each)
@@ -201,7 +211,10 @@ def main():
                     "batch_decode_plain_per_s": 4 * B / dt_dec, "batch_decode_hbm_frac": 4 * B * 6 * row / dt_dec / 8e12,
                     "is_data_valid_for_ct_per_s": B / dt_val, "is_data_valid_for_hbm_frac": B * 2 * k * row / dt_val / 8e12,
                     "wire_load_GBps_pageable_host": len(raw) / dt_load / 1e9, "wire_save_GBps_pageable_host": len(raw) / dt_save / 1e9,
-                    "wire_bytes_per_ct": len(raw)})
+                    "wire_bytes_per_ct": len(raw),
+                    # CKKS encode: read N/2 complex, FFT over N complex (32N B per pass), write k rows + NTT of k rows
+                    "ckks_encode_plain_per_s_cfg4": CB / dt_cenc, "ckks_encode_hbm_frac": CB * (8 * n + 32 * n + ck * 3 * 8 * n) / dt_cenc / 8e12,
+                    "ckks_decode_plain_per_s_cfg4": CB / dt_cdec, "ckks_decode_hbm_frac": CB * (ck * 3 * 8 * n + 32 * n + 8 * n) / dt_cdec / 8e12})
     if want("pcie"):
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
