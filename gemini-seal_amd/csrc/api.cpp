@@ -25,6 +25,8 @@ namespace sealhip
                    std::size_t capacity_words);
     std::size_t wire_save_size(std::uint32_t size, std::uint32_t k, std::size_t n);
     std::size_t wire_save(Engine &e, const sealhip_ciphertext_info &ci, const u64 *src, void *bytes, std::size_t capacity);
+    std::uint32_t wire_load_kswitch_key(Engine &e, const void *bytes, std::size_t len, std::uint32_t index, u64 **d_out,
+                                        std::size_t *words_out, std::uint64_t *dim1_out);
 } // namespace sealhip
 
 struct sealhip_context
@@ -1289,6 +1291,31 @@ long sealhip_ciphertext_save(sealhip_context *ctx, const sealhip_ciphertext_info
     return guarded([&] {
         Engine &e = device_engine(ctx);
         *written = wire_save(e, *info, reinterpret_cast<const u64 *>(src_device), bytes, capacity);
+    });
+}
+
+long sealhip_kswitch_key_load_stream(sealhip_context *ctx, const void *bytes, size_t len, uint32_t index,
+                                     sealhip_kswitch_key **key, uint64_t *n_slots)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(bytes);
+    REQUIRE_PTR(key);
+    *key = nullptr;
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        u64 *dev = nullptr;
+        std::size_t words = 0;
+        std::uint64_t dim1 = 0;
+        const std::uint32_t digits = wire_load_kswitch_key(e, bytes, len, index, &dev, &words, &dim1);
+        if (n_slots)
+            *n_slots = dim1;
+        if (!digits)
+            return;
+        auto k = std::make_unique<sealhip_kswitch_key>();
+        k->key.n_digits = digits;
+        k->key.words = words;
+        k->key.d_data = dev;
+        *key = k.release();
     });
 }
 

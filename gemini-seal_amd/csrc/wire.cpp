@@ -208,4 +208,87 @@ namespace sealhip
         }
         return total;
     }
+    // KSwitchKeys::load (kswitchkeys.cpp:87-150): outer header, parms_id, keys_dim1, then per index keys_dim2 and that many
+    // PublicKey streams, each a complete Ciphertext stream (publickey.h:107-111). The digits of keys_[index] are
+    // concatenated straight into one device buffer, which is the K1 layout (keygenerator.cpp:325-369) the key switch reads.
+    // Returns the number of digits; 0 when the slot is empty (a GaloisKeys object holds only the generated elements).
+    std::uint32_t wire_load_kswitch_key(Engine &e, const void *bytes, std::size_t len, std::uint32_t index, u64 **d_out,
+                                        std::size_t *words_out, std::uint64_t *dim1_out)
+    {
+        const unsigned char *p = static_cast<const unsigned char *>(bytes);
+        const Header outer = read_header(p, len);
+        if (outer.size > len || outer.size < sizeof(Header) + 32 + 8)
+            throw std::runtime_error("I/O error");
+        const unsigned char *end = p + outer.size;
+        p += sizeof(Header);
+        std::uint64_t pid[4], dim1;
+        std::memcpy(pid, p, 32);
+        std::memcpy(&dim1, p + 32, 8);
+        p += 40;
+        *dim1_out = dim1;
+        const auto key_id = e.parms_ids.find(e.n_key);
+        if (key_id == e.parms_ids.end() || std::memcmp(key_id->second.data(), pid, 32) != 0)
+            throw std::logic_error("kswitch_keys is not valid for encryption parameters"); // is_metadata_valid_for, valcheck.cpp
+        if (index >= dim1)
+            throw std::invalid_argument("key index out of range");
+        const std::size_t digit_words = static_cast<std::size_t>(2) * e.n_key * e.n;
+        const std::uint32_t max_digits = static_cast<std::uint32_t>((e.k_first + e.nsp - 1) / e.nsp);
+        for (std::uint64_t i = 0; i <= index; i++)
+        {
+            if (static_cast<std::size_t>(end - p) < 8)
+                throw std::runtime_error("I/O error");
+            std::uint64_t dim2;
+            std::memcpy(&dim2, p, 8);
+            p += 8;
+            if (dim2 > 64)
+                throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+            u64 *dev = nullptr;
+            if (i == index)
+            {
+                if (dim2 == 0)
+                    return 0;
+                if (dim2 > max_digits)
+                    throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), dim2 * digit_words * sizeof(u64)));
+            }
+            for (std::uint64_t j = 0; j < dim2; j++)
+            {
+                try
+                {
+                    const Parsed ps = parse(p, static_cast<std::size_t>(end - p));
+                    if (i == index)
+                    {
+                        if (std::memcmp(ps.info.parms_id, pid, 32) != 0 || ps.info.size != 2 ||
+                            ps.info.coeff_modulus_size != static_cast<std::uint32_t>(e.n_key) ||
+                            ps.info.poly_modulus_degree != e.n || !ps.info.is_ntt_form)
+                            throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                        if (ps.info.seeded)
+                            throw std::logic_error("seeded key: expand the seed on the host before loading");
+                        if (ps.info.data_words != digit_words)
+                            throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                        SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words, ps.words, digit_words * sizeof(u64),
+                                                     hipMemcpyHostToDevice, e.stream));
+                    }
+                    p += ps.info.total_bytes;
+                }
+                catch (...)
+                {
+                    if (dev)
+                    {
+                        (void)hipStreamSynchronize(e.stream);
+                        (void)hipFree(dev);
+                    }
+                    throw;
+                }
+            }
+            if (i == index)
+            {
+                SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+                *d_out = dev;
+                *words_out = dim2 * digit_words;
+                return static_cast<std::uint32_t>(dim2);
+            }
+        }
+        return 0;
+    }
 } // namespace sealhip

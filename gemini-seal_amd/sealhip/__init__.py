@@ -124,6 +124,7 @@ SYMBOLS = {
     "sealhip_ciphertext_save": [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz)],
     "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
+    "sealhip_kswitch_key_load_stream": [_vp, _vp, _sz, _u32, C.POINTER(_vp), C.POINTER(_u64)],
     "sealhip_ckks_encode": [_vp, _u32, _vp, _sz, _sz, C.c_double, _vp],
     "sealhip_ckks_decode": [_vp, _u32, _vp, _sz, C.c_double, _vp],
 }
@@ -244,6 +245,19 @@ class KSwitchKeys:
         h = C.c_void_p()
         _check(lib().sealhip_kswitch_key_load(ctx.handle, src, n_digits, 1 if from_host else 0, C.byref(h)))
         self.handle = h.value
+
+    @classmethod
+    def from_stream(cls, ctx, raw, index):
+        """KSwitchKeys::load (kswitchkeys.cpp:87-150): keys_[index] of a serialized RelinKeys / GaloisKeys object, its digits
+        copied straight from the byte stream into HBM. Returns None when the slot is empty."""
+        buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        h, slots = C.c_void_p(), _u64(0)
+        _check(lib().sealhip_kswitch_key_load_stream(ctx.handle, C.addressof(buf), len(raw), index, C.byref(h), C.byref(slots)))
+        if not h.value:
+            return None
+        self = cls.__new__(cls)
+        self.ctx, self.handle, self.n_slots = ctx, h.value, slots.value
+        return self
 
     def __del__(self):
         try:

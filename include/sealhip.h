@@ -320,6 +320,12 @@ long sealhip_ciphertext_load(sealhip_context *ctx, const void *bytes, size_t len
 long sealhip_ciphertext_save_size(const sealhip_context *ctx, uint32_t size, uint32_t k, size_t *bytes);
 long sealhip_ciphertext_save(sealhip_context *ctx, const sealhip_ciphertext_info *info, const uint64_t *src_device,
                              void *bytes, size_t capacity, size_t *written);
+/* KSwitchKeys::load (kswitchkeys.cpp:87-150; RelinKeys / GaloisKeys streams, uncompressed): loads keys_[index] -- RelinKeys:
+   index = key_power - 2 (relinkeys.h:61-68), GaloisKeys: index = (galois_elt - 1) / 2 (galoiskeys.h:52-55) -- with its
+   decomposition digits concatenated straight from the stream into HBM. *key = NULL when that slot is empty; n_slots (may
+   be NULL) receives keys_.size(). Needs the key level's parms_id registered (k = n_key_moduli). */
+long sealhip_kswitch_key_load_stream(sealhip_context *ctx, const void *bytes, size_t len, uint32_t index,
+                                     sealhip_kswitch_key **key, uint64_t *n_slots);
 /* is_data_valid_for (valcheck.cpp:284-317) on device-resident ciphertexts: valid[i] = 1 iff every coefficient of
    ciphertext i is below its row's prime (what an ingesting service checks before evaluating untrusted input). */
 long sealhip_is_data_valid_for(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,

@@ -71,3 +71,14 @@ def load_ciphertext(raw):
     rest = raw[p + 24 + 8 * count:]
     return dict(parms_id=parms_id, is_ntt_form=is_ntt, size=size, n=n, k=k, scale=scale, words=words,
                 seed=bytes(rest) if rest else None)
+
+
+def save_kswitch_keys(parms_id, keys, n, n_key):
+    """KSwitchKeys::save_members (kswitchkeys.cpp:43-85): keys[index] = list of digits, each a (2, n_key, n) uint64 array
+    (a PublicKey = size-2 NTT-form ciphertext at the key level, publickey.h:107-111); an empty list = unused slot"""
+    body = struct.pack("<4Q", *parms_id) + struct.pack("<Q", len(keys))
+    for digits in keys:
+        body += struct.pack("<Q", len(digits))
+        for d in digits:
+            body += save_ciphertext(parms_id, True, 2, n, n_key, 1.0, np.ascontiguousarray(d, dtype="<u8").reshape(-1))
+    return header(16 + len(body)) + body

@@ -1330,3 +1330,44 @@ def test_f4_ckks_encoder_errors(sealhip):
     bfv = sealhip.Context(sealhip.SCHEME_BFV, 10, kmods, 1, 65537)
     with pytest.raises(ValueError, match="unsupported scheme"):
         bfv.ckks_encode(v, 2, 2.0 ** 20)
+
+
+def test_f3_kswitch_keys_stream_to_hbm(sealhip):
+    """KSwitchKeys::load (kswitchkeys.cpp:87-150) for RelinKeys / GaloisKeys streams: the digits of keys_[index] go from the
+    byte stream straight into HBM in the K1 layout; relinearizing with the stream-loaded key equals relinearizing with the
+    directly uploaded one; empty slots, wrong parms_id and malformed members are reported like the reference does."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wire_format", os.path.join(os.path.dirname(HERE), "oracle", "wire_format.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    logn, n, t = 11, 2048, 65537
+    kmods = O.coeff_modulus_create(n, [40] * 4)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(9)
+    n_key, k, d = 4, 3, 3
+    key_id = (21, 22, 23, 24)
+    ctx.set_parms_id(n_key, key_id)
+    key = np.stack([np.stack([rand_rows(rng, kmods, n) for _ in range(2)]) for _ in range(d)])
+    other = np.stack([np.stack([rand_rows(rng, kmods, n) for _ in range(2)]) for _ in range(d)])
+    raw = W.save_kswitch_keys(key_id, [list(key), [], list(other)], n, n_key)  # slot 1 unused (as in GaloisKeys)
+    rk = sealhip.KSwitchKeys.from_stream(ctx, raw, 0)
+    assert rk is not None and rk.n_slots == 3
+    assert sealhip.KSwitchKeys.from_stream(ctx, raw, 1) is None
+    rk2 = sealhip.KSwitchKeys.from_stream(ctx, raw, 2)
+    count = 2
+    ct = np.stack([_rand_ct(rng, kmods[:k], 3, n, 1)[0] for _ in range(count)])
+    for loaded, host in ((rk, key), (rk2, other)):
+        a, b = ctx.upload(ct), ctx.upload(ct)
+        ev.relinearize_inplace(a, 3, k, count, [loaded])
+        ev.relinearize_inplace(b, 3, k, count, [sealhip.KSwitchKeys(ctx, host)])
+        assert np.array_equal(a.download(), b.download())
+    with pytest.raises(ValueError, match="out of range"):
+        sealhip.KSwitchKeys.from_stream(ctx, raw, 3)
+    with pytest.raises(sealhip.LogicError, match="not valid"):
+        sealhip.KSwitchKeys.from_stream(ctx, W.save_kswitch_keys((1, 1, 1, 1), [list(key)], n, n_key), 0)
+    with pytest.raises(sealhip.LogicError, match="not valid"):  # a digit at the wrong level
+        sealhip.KSwitchKeys.from_stream(ctx, W.save_kswitch_keys(key_id, [[key[0][:, :3]]], n, 3), 0)
+    with pytest.raises(RuntimeError, match="I/O error"):
+        sealhip.KSwitchKeys.from_stream(ctx, raw[: len(raw) // 2], 2)
