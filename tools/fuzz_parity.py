@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential run of the HIP path against the CPU oracle (test infrastructure): random ring sizes, prime
 counts and sizes, special-prime counts, schemes, batch sizes; multiply -> relinearize -> mod_switch/rescale -> apply_galois,
-plus add/sub and multiply_plain. Usage: python tools/fuzz_parity.py [iterations] [seed]"""
+encrypt_zero (both kinds, both forms), add/sub_plain, BatchEncoder, CKKSEncoder. Usage: python tools/fuzz_parity.py [iterations] [seed]"""
 import ctypes as C
 import os
 import sys
@@ -71,6 +71,59 @@ def one(rng, it):
         assert np.array_equal(got_l[i], lo), ("mod_switch", it, i)
         assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(e2), elt, O.ptr(key)) == 0
         assert np.array_equal(got_g[i], e2), ("galois", it, i)
+    # encrypt-side arithmetic with the same samples on both sides, both output forms
+    rows = int(rng.choice([k, k + nsp]))
+    sk = rand_ct(rng, kmods, 1, n, 1)[0, 0]
+    an = rand_ct(rng, kmods[:rows], 1, n, count)[:, 0].copy()
+    e1 = rng.integers(-19, 20, size=(count, n)).astype(np.int32)
+    pk = rand_ct(rng, kmods[:rows], 2, n, 1)[0]
+    u = rng.integers(-1, 2, size=(count, n)).astype(np.int32)
+    e2n = rng.integers(-19, 20, size=(count, 2, n)).astype(np.int32)
+    form = bool(rng.integers(0, 2))
+    oz = ctx.alloc(count * 2 * rows * n)
+    ctx.encrypt_zero_symmetric(rows, form, ctx.upload(an), ctx.upload_i32(e1), ctx.upload(sk), count, oz)
+    got_s = oz.download((count, 2, rows, n))
+    ctx.encrypt_zero_asymmetric(rows, form, ctx.upload(pk), ctx.upload_i32(u), ctx.upload_i32(e2n), count, oz)
+    got_a = oz.download((count, 2, rows, n))
+    for i in range(count):
+        exp = np.zeros((2, rows, n), dtype=np.uint64)
+        L.ref_encrypt_zero_symmetric_given(C.byref(ref.c), rows, O.ptr(sk), int(form), O.ptr(an[i]), O.ptr(e1[i]), O.ptr(exp))
+        assert np.array_equal(got_s[i], exp), ("encrypt_zero_symmetric", it, i)
+        L.ref_encrypt_zero_asymmetric_given(C.byref(ref.c), rows, O.ptr(pk), int(form), O.ptr(u[i]), O.ptr(e2n[i]), O.ptr(exp))
+        assert np.array_equal(got_a[i], exp), ("encrypt_zero_asymmetric", it, i)
+    if scheme == 1:
+        plain = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+        dct = ctx.upload(a)
+        sub = bool(rng.integers(0, 2))
+        ev.add_plain_inplace(dct, 2, k, count, ctx.upload(plain), subtract=sub)
+        got_p = dct.download(a.shape)
+        for i in range(count):
+            exp = a[i].copy()
+            L.ref_multiply_add_plain_with_scaling_variant(C.byref(ref.c), k, O.ptr(plain[i]), int(sub), O.ptr(exp[0]))
+            assert np.array_equal(got_p[i], exp), ("add_plain", it, i)
+        if ctx.using_batching:  # BatchEncoder (65537 = 1 mod 2N up to N = 2^15)
+            tb = O.Tables(logn, t)
+            pl = ctx.alloc(count * n)
+            ctx.batch_encode(ctx.upload(plain), n, count, pl)
+            got_e = pl.download((count, n))
+            back = ctx.alloc(count * n)
+            ctx.batch_decode(pl, count, back)
+            assert np.array_equal(back.download((count, n)), plain), ("batch round trip", it)
+            for i in range(count):
+                exp = np.zeros(n, dtype=np.uint64)
+                L.ref_batch_encode(C.byref(tb.t), O.ptr(plain[i]), n, O.ptr(exp))
+                assert np.array_equal(got_e[i], exp), ("batch_encode", it, i)
+    else:  # CKKSEncoder, equality of words and of decoded doubles
+        ck = O.CkksRef(ref)
+        sc = 2.0 ** int(rng.integers(10, max(11, sum(bits[:k]) - 45)))
+        v = rng.integers(-1000, 1000, size=(count, n // 2)) + 1j * rng.integers(-1000, 1000, size=(count, n // 2))
+        pl = ctx.ckks_encode(v, k, sc)
+        got_e = pl.download((count, k, n))
+        dec = ctx.ckks_decode(pl, k, count, sc)
+        for i in range(count):
+            rc, exp = ck.encode(v[i], k, sc)
+            assert rc == 0 and np.array_equal(got_e[i], exp), ("ckks_encode", it, i)
+            assert np.array_equal(dec[i].view(np.uint64), ck.decode(exp, sc).view(np.uint64)), ("ckks_decode", it, i)
     return "%s logn=%d k=%d nsp=%d count=%d bits=%s" % ("BFV" if scheme == 1 else "CKKS", logn, k, nsp, count, bits)
 
 
