@@ -1153,6 +1153,14 @@ long sealhip_evaluator_add_plain(sealhip_context *ctx, uint32_t k, uint64_t *ct,
         const RowMap map = e.map_for(static_cast<int>(k), SEALHIP_BASE_Q);
         u64 *c = reinterpret_cast<u64 *>(ct);
         const u64 *p = reinterpret_cast<const u64 *>(plain);
+        if (plain_item_stride == static_cast<std::size_t>(k) * e.n)
+        {
+            // a batch of plaintexts laid out back to back is a batch of size-1 operands of add/sub (evaluator.cpp:131-143)
+            check_launch(launch_ct_linear(e, subtract ? CtLinearOp::Sub : CtLinearOp::Add, c, static_cast<int>(size), p, 1, 0, c,
+                                          count, map),
+                         "add_plain");
+            return;
+        }
         for (std::size_t i = 0; i < count; i++)
             check_launch(launch_poly_op(e, subtract ? PolyOp::Sub : PolyOp::Add, c + i * item, p + i * plain_item_stride, 0,
                                         c + i * item, k, map),
