@@ -37,6 +37,12 @@ struct sealhip_kswitch_key
 {
     KSwitchKey key;
 };
+struct sealhip_graph
+{
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long generation = 0; // Engine::alloc_generation at capture: the graph holds arena addresses
+};
 
 namespace
 {
@@ -120,6 +126,7 @@ namespace
         if (e.device < 0)
             throw std::logic_error("host-only context: there is no CPU fallback, create the context on a HIP device");
         g_locks.push_back(std::make_unique<OpLock>(e));
+        (void)hipGetLastError(); // an error an earlier call already reported must not be attributed to this one's launches
         SEALHIP_CHECK(hipSetDevice(e.device));
         return e;
     }
@@ -1075,6 +1082,73 @@ long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uin
         check_launch(launch_decrypt_scale_and_round(e, lt.d_rns, lt.h_rns, reinterpret_cast<const u64 *>(in),
                                                     reinterpret_cast<u64 *>(out), count),
                      "decrypt_scale_and_round");
+    });
+}
+
+/* ------------------------------------------------------------------ HIP graphs */
+
+long sealhip_graph_capture_begin(sealhip_context *ctx)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        if (e.capturing)
+            throw std::logic_error("a capture is already in progress on this context");
+        if (e.prof_on)
+            throw std::logic_error("disable the launch profiler before capturing");
+        SEALHIP_CHECK(hipStreamBeginCapture(e.stream, hipStreamCaptureModeRelaxed));
+        e.capturing = true;
+    });
+}
+
+long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(graph);
+    *graph = nullptr;
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        if (!e.capturing)
+            throw std::logic_error("no capture in progress");
+        e.capturing = false;
+        auto g = std::make_unique<sealhip_graph>();
+        SEALHIP_CHECK(hipStreamEndCapture(e.stream, &g->graph));
+        if (!g->graph)
+            throw std::logic_error("the capture was invalidated (an operation allocated or synchronised): run the sequence "
+                                   "once before capturing");
+        const hipError_t err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (err != hipSuccess)
+        {
+            (void)hipGraphDestroy(g->graph);
+            throw HipError(err, hipGetErrorString(err));
+        }
+        g->generation = e.alloc_generation;
+        *graph = g.release();
+    });
+}
+
+long sealhip_graph_launch(sealhip_context *ctx, sealhip_graph *graph)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(graph);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        if (graph->generation != e.alloc_generation)
+            throw std::logic_error("the graph is stale: the workspace was re-allocated by a larger operation after the capture");
+        SEALHIP_CHECK(hipGraphLaunch(graph->exec, e.stream));
+    });
+}
+
+long sealhip_graph_destroy(sealhip_context *ctx, sealhip_graph *graph)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(graph);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        (void)hipGraphExecDestroy(graph->exec);
+        (void)hipGraphDestroy(graph->graph);
+        delete graph;
     });
 }
 

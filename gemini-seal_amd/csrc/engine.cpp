@@ -131,6 +131,8 @@ namespace sealhip
         const std::size_t need = nrows + 1;
         if (need > tickets_cap)
         {
+            if (capturing)
+                return nullptr; // reported by the launcher; run the sequence once before capturing
             if (d_tickets)
             {
                 if (hipStreamSynchronize(stream) != hipSuccess || hipFree(d_tickets) != hipSuccess)
@@ -141,6 +143,7 @@ namespace sealhip
             std::size_t cap = 1;
             while (cap < need)
                 cap <<= 1;
+            alloc_generation++;
             if (hipMalloc(reinterpret_cast<void **>(&d_tickets), cap * sizeof(unsigned)) != hipSuccess)
                 return nullptr;
             tickets_cap = cap;
@@ -655,6 +658,8 @@ namespace sealhip
     {
         if (bytes <= ws_bytes)
             return;
+        if (capturing)
+            throw std::logic_error("the workspace would grow during a graph capture: run the sequence once before capturing");
         SEALHIP_CHECK(hipSetDevice(device));
         if (ws)
         {
@@ -665,6 +670,7 @@ namespace sealhip
         }
         SEALHIP_CHECK(hipMalloc(&ws, bytes));
         ws_bytes = bytes;
+        alloc_generation++;
     }
 
     u64 *Engine::ws_alloc(std::size_t words)

@@ -178,6 +178,8 @@ namespace sealhip
         // device
         hipStream_t stream = nullptr;
         bool own_stream = false;
+        mutable unsigned long long alloc_generation = 0; // bumps when the arena or the ticket buffer is re-allocated
+        bool capturing = false; // between sealhip_graph_capture_begin / _end: no allocation, no synchronisation
         PrimeDev *d_primes = nullptr;
         std::vector<void *> owned;
         std::map<int, std::unique_ptr<LevelTools>> levels;

@@ -125,6 +125,10 @@ SYMBOLS = {
     "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
     "sealhip_kswitch_key_load_stream": [_vp, _vp, _sz, _u32, C.POINTER(_vp), C.POINTER(_u64)],
+    "sealhip_graph_capture_begin": [_vp],
+    "sealhip_graph_capture_end": [_vp, C.POINTER(_vp)],
+    "sealhip_graph_launch": [_vp, _vp],
+    "sealhip_graph_destroy": [_vp, _vp],
     "sealhip_ckks_encode": [_vp, _u32, _vp, _sz, _sz, C.c_double, _vp],
     "sealhip_ckks_decode": [_vp, _u32, _vp, _sz, C.c_double, _vp],
 }
@@ -263,6 +267,24 @@ class KSwitchKeys:
         try:
             if self.handle:
                 lib().sealhip_kswitch_key_destroy(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Graph:
+    """An instantiated hipGraph of engine launches (sealhip_graph)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch(self):
+        _check(lib().sealhip_graph_launch(self.ctx.handle, self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().sealhip_graph_destroy(self.ctx.handle, self.handle)
                 self.handle = None
         except Exception:
             pass
@@ -422,6 +444,20 @@ class Context:
         res = out.download().view(np.complex128).reshape(count, self.n // 2)
         out.free()
         return res
+
+    # ---- HIP graphs: capture a fixed sequence of operations on fixed buffers, replay it as one launch
+    def capture(self, fn):
+        """Runs fn() once eagerly (allocations, tables), then captures a second run from the context's stream."""
+        fn()
+        self.synchronize()
+        _check(lib().sealhip_graph_capture_begin(self.handle))
+        try:
+            fn()
+        finally:
+            h = C.c_void_p()
+            hr = lib().sealhip_graph_capture_end(self.handle, C.byref(h))
+        _check(hr)
+        return Graph(self, h.value)
 
     # ---- SURVEY 8(f3): ciphertext wire format
     def set_parms_id(self, k, parms_id):

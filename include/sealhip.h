@@ -238,6 +238,18 @@ long sealhip_decryptor_dot_product_ct_sk(sealhip_context *ctx, uint32_t k, const
 /* RNSTool::decrypt_scale_and_round (rns.cpp:1070-1126), BFV: in[count][k][N] -> out[count][N] coefficients mod t */
 long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uint64_t *in, size_t count, uint64_t *out);
 
+/* ---------------------------------------------------------------- HIP graphs for launch-bound small batches */
+/* Small batches are bound by kernel launches (one multiply+relinearize of a single N=2^15 ciphertext is ~25 launches):
+   a fixed sequence of operations on fixed device buffers can be captured once from the context's stream and replayed as
+   one hipGraph launch. Run the sequence once before capturing (tables, the arena and the NTT tickets are allocated on
+   first use; allocation and synchronisation are not capturable); entry points that synchronise (is_transparent,
+   ckks_encode, the wire format) cannot be captured. */
+typedef struct sealhip_graph sealhip_graph;
+long sealhip_graph_capture_begin(sealhip_context *ctx);
+long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph);
+long sealhip_graph_launch(sealhip_context *ctx, sealhip_graph *graph);
+long sealhip_graph_destroy(sealhip_context *ctx, sealhip_graph *graph);
+
 /* ---------------------------------------------------------------- encrypt-side arithmetic */
 /* util::encrypt_zero_symmetric (util/rlwe.cpp:204-300) with the random samples handed in (sampling and the CSPRNG
    stay on the host): ct[count][2][rows][N] = ([-(a*s + e)]_q, a) over key primes 0..rows-1 (rows = n_key_moduli for

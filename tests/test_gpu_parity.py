@@ -1371,3 +1371,58 @@ def test_f3_kswitch_keys_stream_to_hbm(sealhip):
         sealhip.KSwitchKeys.from_stream(ctx, W.save_kswitch_keys(key_id, [[key[0][:, :3]]], n, 3), 0)
     with pytest.raises(RuntimeError, match="I/O error"):
         sealhip.KSwitchKeys.from_stream(ctx, raw[: len(raw) // 2], 2)
+
+
+# ---------------------------------------------------------------- HIP graphs for launch-bound small batches
+def test_graph_capture_replay_is_bit_exact(sealhip):
+    """A multiply -> relinearize -> mod_switch chain on fixed buffers captured into one hipGraph: replays with new input
+    data in the same buffers equal the oracle; capturing without a warm run, or replaying after the arena was
+    re-allocated, is refused."""
+    logn, n, t = 13, 8192, 65537
+    kmods = O.coeff_modulus_create(n, [50] * 4)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=t)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(13)
+    k, count = 3, 2
+    key = np.stack([np.stack([rand_rows(rng, kmods, n) for _ in range(2)]) for _ in range(k)])
+    rk = sealhip.KSwitchKeys(ctx, key)
+    da, db = ctx.alloc(count * 2 * k * n), ctx.alloc(count * 2 * k * n)
+    wide, two, low = ctx.alloc(count * 3 * k * n), ctx.alloc(count * 2 * k * n), ctx.alloc(count * 2 * (k - 1) * n)
+
+    def chain():
+        ev.multiply(da, 2, db, 2, k, count, wide)
+        ev.relinearize_inplace(wide, 3, k, count, [rk])
+        ev.resize(wide, 3, 2, k, count, two)
+        ev.mod_switch_to_next(two, 2, k, count, low)
+
+    fresh = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    with pytest.raises((sealhip.LogicError, RuntimeError, MemoryError)):  # nothing allocated yet: not capturable
+        sealhip._check(sealhip.lib().sealhip_graph_capture_begin(fresh.handle))
+        try:
+            sealhip.Evaluator(fresh).multiply(fresh.alloc(2 * k * n), 2, fresh.alloc(2 * k * n), 2, k, 1, fresh.alloc(3 * k * n))
+        finally:
+            h = C.c_void_p()
+            sealhip._check(sealhip.lib().sealhip_graph_capture_end(fresh.handle, C.byref(h)))
+    da.upload(_rand_ct(rng, kmods[:k], 2, n, count))
+    db.upload(_rand_ct(rng, kmods[:k], 2, n, count))
+    g = ctx.capture(chain)
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    for trial in range(3):
+        a, b = _rand_ct(rng, kmods[:k], 2, n, count), _rand_ct(rng, kmods[:k], 2, n, count)
+        da.upload(a)
+        db.upload(b)
+        g.launch()
+        got = low.download((count, 2, k - 1, n))
+        for i in range(count):
+            w = np.zeros((3, k, n), dtype=np.uint64)
+            assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(w)) == 0
+            assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(w), 3, keys) == 0
+            lo = np.zeros((2, k - 1, n), dtype=np.uint64)
+            assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(w[:2].copy()), 2, O.ptr(lo)) == 0
+            assert np.array_equal(got[i], lo), (trial, i)
+    # a larger operation re-allocates the arena: the graph holds stale addresses and says so
+    big = 64
+    ev.multiply(ctx.alloc(big * 2 * k * n), 2, ctx.alloc(big * 2 * k * n), 2, k, big, ctx.alloc(big * 3 * k * n))
+    with pytest.raises(sealhip.LogicError, match="stale"):
+        g.launch()

@@ -243,6 +243,32 @@ def main():
         dt = timed(step, 3)
         out.append({"config": "cfg3 with PCIe: pinned host -> device (2 x 3.67 MB/ct), multiply+relinearize, device -> host (3.67 MB/ct), batch 256, one stream (no overlap)",
                     "ct_mul_relin_per_s_pcie_inclusive": B / dt})
+    if want("latency"):
+        # small-batch behaviour of cfg3: time of one multiply+relinearize call for 1..64 ciphertext pairs (launch/latency bound)
+        logn, n = 15, 1 << 15
+        pr = bench.CFG3_PRIMES
+        ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ev = S.Evaluator(ctx)
+        k = 7
+        key = mk(ctx, (k, 2, 8, n), pr, dev)
+        rk = S.KSwitchKeys(ctx, key, n_digits=k, from_host=False)
+        res = {}
+        for B in (1, 2, 4, 8, 16, 64, 256):
+            x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
+            o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+
+            def step():
+                ev.multiply(x, 2, y, 2, k, B, o)
+                ev.relinearize_inplace(o, 3, k, B, [rk])
+            dt = timed(step, 20)
+            res["batch_%d" % B] = {"ms_per_call": dt * 1e3, "ct_per_s": B / dt}
+            if B <= 16:  # the same call sequence replayed as one hipGraph launch
+                g = ctx.capture(step)
+                dtg = timed(g.launch, 50)
+                res["batch_%d" % B].update({"ms_per_call_hipgraph": dtg * 1e3, "ct_per_s_hipgraph": B / dtg})
+                del g
+        out.append({"config": "cfg3 small batches: one multiply+relinearize call, device-resident", **res})
     if want("pcie_overlap"):
         # the same boundary with the copies on their own HIP streams: chunks of 64 ciphertext pairs, double-buffered
         # device staging, H2D(c+1) and D2H(c-1) run while chunk c computes
