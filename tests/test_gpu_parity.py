@@ -1426,3 +1426,31 @@ def test_graph_capture_replay_is_bit_exact(sealhip):
     ev.multiply(ctx.alloc(big * 2 * k * n), 2, ctx.alloc(big * 2 * k * n), 2, k, big, ctx.alloc(big * 3 * k * n))
     with pytest.raises(sealhip.LogicError, match="stale"):
         g.launch()
+
+
+def test_new_entry_points_accept_empty_batches(sealhip):
+    """count = 0 (and n_values = 0) are no-ops everywhere, like the reference's loops over empty ranges"""
+    n = 1024
+    kmods = O.coeff_modulus_create(n, [40, 40, 40])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, 10, kmods, 1, 65537)
+    ev = sealhip.Evaluator(ctx)
+    buf = ctx.alloc(4 * 2 * 2 * n)
+    i32 = ctx.upload_i32(np.zeros(2 * n, dtype=np.int32))
+    ctx.encrypt_zero_symmetric(2, True, buf, i32, buf, 0, buf)
+    ctx.encrypt_zero_asymmetric(2, False, buf, i32, i32, 0, buf)
+    ev.add_plain_inplace(buf, 2, 2, 0, buf)
+    ctx.batch_encode(buf, n, 0, buf)
+    ctx.batch_decode(buf, 0, buf)
+    ev.resize(buf, 2, 3, 2, 0, buf)
+    assert ctx.is_data_valid_for(buf, 2, 2, 0).size == 0
+    # zero values: every slot is zero -> the zero plaintext
+    vals = ctx.upload(np.zeros(n, dtype=np.uint64))
+    out = ctx.alloc(n)
+    ctx.batch_encode(vals, 0, 1, out)
+    assert not out.download().any()
+    ck = sealhip.Context(sealhip.SCHEME_CKKS, 10, kmods, 1, 0)
+    z = ck.ckks_encode(np.zeros((1, 0), dtype=np.complex128), 2, 2.0 ** 20)
+    assert not z.download().any()
+    assert ck.ckks_encode(np.zeros((0, 4), dtype=np.complex128), 2, 2.0 ** 20).words == 0
+    ctx.synchronize()
+    ck.synchronize()
