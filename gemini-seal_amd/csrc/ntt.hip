@@ -708,21 +708,38 @@ namespace sealhip
 
         // XCD-aware block -> (row, half) map (speed only; any placement gives the same result). Blocks are dealt
         // round-robin over the 8 XCDs, each with its own 4 MB L2. Rows are enumerated prime-major
-        // (v = prime_slot * npolys + poly) and XCD x gets the contiguous range [x*chunk, (x+1)*chunk): it then
-        // touches at most two primes, so their twiddle tables (512 KB each at N=2^15) stay L2-resident instead of
-        // all rows_per_poly tables thrashing every L2 (measured: HBM reads 583 -> 377 KB per row at N=2^15).
-        // The two halves of a row are consecutive slots of one XCD.
-        __device__ __forceinline__ bool half_block_map(unsigned bid, std::size_t nrows, int rows_per_poly,
-                                                       std::size_t chunk, std::size_t &row, int &half)
+        // (v = position * npolys + poly, positions = the LIVE slots of a polynomial in slot order) and XCD x gets the
+        // contiguous range [x*chunk, (x+1)*chunk): it then touches at most two primes, so their twiddle tables (512 KB
+        // each at N=2^15) stay L2-resident instead of all rows_per_poly tables thrashing every L2 (measured: HBM reads
+        // 583 -> 377 KB per row at N=2^15). Slots mapped to kSkipRow are left out of the enumeration: counting them
+        // left the XCD that owned a skipped slot idle (the key-switch launches skip one slot in k+1, and the CKKS
+        // special-row launches transform one slot in k+1: one XCD did all the work).
+        // The two halves of a row are consecutive blocks of one XCD.
+        struct LiveSlots
+        {
+            int n;
+            unsigned short slot[kMaxRows];
+        };
+        inline LiveSlots live_slots(const RowMap &map)
+        {
+            LiveSlots ls{};
+            for (int r = 0; r < map.rows; r++)
+                if (map.prime[r] != kSkipRow)
+                    ls.slot[ls.n++] = static_cast<unsigned short>(r);
+            return ls;
+        }
+        // -> false when the block has nothing to do; else the polynomial index and the position among the live slots
+        __device__ __forceinline__ bool half_block_map(unsigned bid, std::size_t npolys, int n_live, std::size_t chunk,
+                                                       std::size_t &poly, int &position, int &half)
         {
             const unsigned xcd = bid & 7u;
             const std::size_t slot = bid >> 3;
             half = static_cast<int>(slot & 1);
             const std::size_t v = static_cast<std::size_t>(xcd) * chunk + (slot >> 1);
-            if ((slot >> 1) >= chunk || v >= nrows)
+            if ((slot >> 1) >= chunk || v >= npolys * static_cast<std::size_t>(n_live))
                 return false;
-            const std::size_t npolys = nrows / rows_per_poly;
-            row = (v % npolys) * rows_per_poly + (v / npolys);
+            poly = v % npolys;
+            position = static_cast<int>(v / npolys);
             return true;
         }
 
@@ -753,19 +770,19 @@ namespace sealhip
         template <int LOGN, bool STRICT, int REDUCE>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
-            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src, std::size_t chunk)
+            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src, std::size_t chunk,
+            LiveSlots live)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
             extern __shared__ u64 lds[];
             const int tid = threadIdx.x;
-            int half;
-            std::size_t row;
-            if (!half_block_map(blockIdx.x, nrows, map.rows, chunk, row, half))
+            int half, position;
+            std::size_t poly;
+            if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
                 return;
+            const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
-            if (pid == kSkipRow)
-                return;
             const PrimeDev P = primes[pid];
             const u64 p = P.p, two_p = P.two_p, rdp = P.rdp;
             const u64 *tw = P.fwd;
@@ -1043,19 +1060,19 @@ namespace sealhip
                                                                                   RowMap map, std::size_t nrows,
                                                                                   std::size_t chunk,
                                                                                   const u64 *__restrict__ src,
-                                                                                  std::size_t src_poly_stride)
+                                                                                  std::size_t src_poly_stride,
+                                                                                  LiveSlots live)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
             extern __shared__ u64 lds[];
             const int tid = threadIdx.x;
-            int half;
-            std::size_t row;
-            if (!half_block_map(blockIdx.x, nrows, map.rows, chunk, row, half))
+            int half, position;
+            std::size_t poly;
+            if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
                 return;
+            const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
-            if (pid == kSkipRow)
-                return;
             const PrimeDev P = primes[pid];
             const u64 p = P.p, two_p = P.two_p;
             const u64 *tw = P.inv;
@@ -1163,14 +1180,17 @@ namespace sealhip
             const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
             if (nrows % map.rows != 0)
                 return hipErrorInvalidValue;
-            const std::size_t chunk = (nrows + 7) / 8;
+            const LiveSlots live = live_slots(map);
+            if (live.n == 0)
+                return hipSuccess;
+            const std::size_t chunk = ((nrows / map.rows) * live.n + 7) / 8; // live rows per XCD
             const std::size_t blocks = chunk * 16;
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
             {
                 ProfScope prof(e, "ntt_inv_half", transformed_rows(nrows, map));
                 ntt_inv_half_kernel<LOGN><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, chunk, src, src_poly_stride);
+                    data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -1203,7 +1223,10 @@ namespace sealhip
 #endif
             if (nrows % map.rows != 0)
                 return hipErrorInvalidValue;
-            const std::size_t chunk = (nrows + 7) / 8; // rows per XCD
+            const LiveSlots live = live_slots(map);
+            if (live.n == 0)
+                return hipSuccess;
+            const std::size_t chunk = ((nrows / map.rows) * live.n + 7) / 8; // live rows per XCD
             const std::size_t blocks = chunk * 16;
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
@@ -1249,7 +1272,7 @@ namespace sealhip
             ProfScope prof(e, "ntt_fwd_half", transformed_rows(nrows, map));
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
     ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>( \
-        data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk)
+        data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk, live)
             const int red = src.base[0] ? src.reduce_mode : 0;
             if (flags & kNttStrict)
             {
