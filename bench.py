@@ -161,7 +161,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SEALHIP_BENCH_BATCH", "4096")),
                     help="independent ciphertext pairs per GPU (BASELINE config 3: 4096)")
-    ap.add_argument("--ntt-polys", type=int, default=1024, help="polynomials (x7 rows) in the NTT-only section")
+    ap.add_argument("--ntt-polys", type=int, default=4096,
+                    help="polynomials (x7 rows) in the NTT-only section; 4096 = the batch of the step (the rate grows "
+                         "with the launch: 31 %% of the roofline at 7 k rows, 36-38 %% at 29-57 k, DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
