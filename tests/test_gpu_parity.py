@@ -1454,3 +1454,66 @@ def test_new_entry_points_accept_empty_batches(sealhip):
     assert ck.ckks_encode(np.zeros((0, 4), dtype=np.complex128), 2, 2.0 ** 20).words == 0
     ctx.synchronize()
     ck.synchronize()
+
+
+def test_full_size_batched_pipeline_semantics_cfg3(sealhip):
+    """Everything either side of the hot path at BASELINE config 3's parameters (N = 2^15, {55} x 8 primes, t = 786433),
+    all arithmetic on the device in STRICT mode: BatchEncoder encode -> public-key encryption (encrypt_zero_asymmetric
+    at key level, divide_and_round_q_last, scaling variant) -> multiply -> relinearize -> mod_switch_to_next -> decrypt
+    (dot product with the secret key, scale-and-round) -> BatchEncoder decode == the slot-wise product of the inputs;
+    add_plain / multiply_plain shift and scale the slots as documented."""
+    logn, n, t, nsp = 15, 1 << 15, 786433, 1
+    kmods = O.coeff_modulus_create(n, [55] * 8)  # CoeffModulus::Create(N, {55} x 8): config 3's primes
+    ref = O.RefContext(1, logn, kmods, nsp=nsp, t=t, mode=1)
+    cl = O.Client(ref, seed=15)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, nsp, t, mode=sealhip.MODE_STRICT)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(15)
+    n_key, k, count = cl.n_key, cl.k, 2
+    dsk = ctx.upload(cl.sk)
+    pk = ctx.alloc(2 * n_key * n)
+    ctx.encrypt_zero_symmetric(n_key, True, ctx.upload(rand_rows(rng, kmods, n)[None]),
+                               ctx.upload_i32(rng.integers(-6, 7, size=(1, n))), dsk, 1, pk)
+    va = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    vb = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+
+    def encode(v):
+        p = ctx.alloc(count * n)
+        ctx.batch_encode(ctx.upload(v), n, count, p)
+        return p
+
+    def encrypt(plain):
+        big = ctx.alloc(count * 2 * n_key * n)
+        ctx.encrypt_zero_asymmetric(n_key, False, pk, ctx.upload_i32(rng.integers(-1, 2, size=(count, n))),
+                                    ctx.upload_i32(rng.integers(-6, 7, size=(count, 2, n))), count, big)
+        ctx.divide_and_round_q_last_inplace(n_key, big, count * 2)
+        ct = ctx.upload(big.download((count, 2, n_key, n))[:, :, :k].copy())
+        ev.add_plain_inplace(ct, 2, k, count, plain)
+        return ct
+
+    def decrypt_decode(dct, size, kk):
+        pw = ctx.upload(cl.sk_powers(size - 1))
+        dot = ctx.alloc(count * kk * n)
+        ctx.dot_product_ct_sk(dct, size, kk, count, pw, False, dot)
+        pl = ctx.alloc(count * n)
+        ctx.decrypt_scale_and_round(kk, dot, count, pl)
+        out = ctx.alloc(count * n)
+        ctx.batch_decode(pl, count, out)
+        return out.download((count, n))
+
+    pa, pb = encode(va), encode(vb)
+    ca, cb = encrypt(pa), encrypt(pb)
+    assert np.array_equal(decrypt_decode(ca, 2, k), va)
+    prod = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ca, 2, cb, 2, k, count, prod)
+    rk = sealhip.KSwitchKeys(ctx, cl.relin_key())
+    ev.relinearize_inplace(prod, 3, k, count, [rk])
+    two = ev.resize(prod, 3, 2, k, count)
+    low = ctx.alloc(count * 2 * (k - 1) * n)
+    ev.mod_switch_to_next(two, 2, k, count, low)
+    assert np.array_equal(decrypt_decode(low, 2, k - 1), (va * vb) % t)
+    # plaintext operations on the encrypted slots
+    ev.add_plain_inplace(ca, 2, k, count, pb)
+    assert np.array_equal(decrypt_decode(ca, 2, k), (va + vb) % t)
+    ev.multiply_plain_inplace(cb, 2, k, count, pa, plain_stride=n, ntt_form=False)
+    assert np.array_equal(decrypt_decode(cb, 2, k), (va * vb) % t)
