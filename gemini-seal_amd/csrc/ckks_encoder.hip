@@ -96,6 +96,60 @@ namespace sealhip
             }
         }
 
+        // two layers in global memory per launch: one lane per quadruple. Every element goes through the same two
+        // butterflies with the same operands as in two single-layer launches, so the bits are unchanged.
+        // INV layers (i, i+1), tt = 2^i: elements k, k+tt, k+2tt, k+3tt; FWD layers (i, i+1), tt = n >> (i+1):
+        // elements k, k+tt/2, k+tt, k+tt+tt/2.
+        template <bool INV>
+        __global__ __launch_bounds__(kThreads) void fft_layer2_kernel(double2 *__restrict__ data,
+                                                                      const double2 *__restrict__ roots, int logn, int layer,
+                                                                      std::size_t total)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t half = std::size_t(1) << (logn - 1), quads = half >> 1;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total; i += stride)
+            {
+                const std::size_t item = i >> (logn - 2), q = i & (quads - 1);
+                double2 *base = data + (item << logn);
+                if (INV)
+                {
+                    const int sh = layer;
+                    const std::size_t tt = std::size_t(1) << sh;
+                    const std::size_t g = q >> sh, kk = q & (tt - 1);
+                    double2 *p = base + (g << (sh + 2)) + kk;
+                    double2 e0 = p[0], e1 = p[tt], e2 = p[2 * tt], e3 = p[3 * tt];
+                    const std::size_t h0 = half >> layer, h1 = half >> (layer + 1);
+                    bfly<true>(e0, e1, roots[h0 + 2 * g]);
+                    bfly<true>(e2, e3, roots[h0 + 2 * g + 1]);
+                    const double2 s2 = roots[h1 + g];
+                    bfly<true>(e0, e2, s2);
+                    bfly<true>(e1, e3, s2);
+                    p[0] = e0;
+                    p[tt] = e1;
+                    p[2 * tt] = e2;
+                    p[3 * tt] = e3;
+                }
+                else
+                {
+                    const int sh = logn - layer - 2; // log2 of tt/2
+                    const std::size_t t2 = std::size_t(1) << sh;
+                    const std::size_t j = q >> sh, kk = q & (t2 - 1);
+                    double2 *p = base + (j << (sh + 2)) + kk;
+                    double2 e0 = p[0], e1 = p[t2], e2 = p[2 * t2], e3 = p[3 * t2];
+                    const std::size_t m0 = std::size_t(1) << layer, m1 = m0 << 1;
+                    const double2 s0 = roots[m0 + j];
+                    bfly<false>(e0, e2, s0);
+                    bfly<false>(e1, e3, s0);
+                    bfly<false>(e0, e1, roots[m1 + 2 * j]);
+                    bfly<false>(e2, e3, roots[m1 + 2 * j + 1]);
+                    p[0] = e0;
+                    p[t2] = e1;
+                    p[2 * t2] = e2;
+                    p[3 * t2] = e3;
+                }
+            }
+        }
+
         // L consecutive layers whose pairs stay inside a contiguous tile of 2^L numbers, in LDS: the first L layers of
         // the inverse transform, the last L of the forward one.
         template <bool INV>
@@ -306,15 +360,22 @@ namespace sealhip
             const std::size_t tiles = count << (logn - L);
             const std::size_t lds = sizeof(double2) << L;
             const std::size_t bflies = count << (logn - 1);
+            const std::size_t quads = bflies / 2;
             if (INV)
             {
                 fft_local_kernel<true><<<static_cast<unsigned>(tiles), kThreads, lds, e.stream>>>(data, roots, logn, L);
-                for (int layer = L; layer < logn; layer++)
+                int layer = L;
+                for (; layer + 1 < logn; layer += 2)
+                    fft_layer2_kernel<true><<<grid_for(quads), kThreads, 0, e.stream>>>(data, roots, logn, layer, quads);
+                if (layer < logn)
                     fft_layer_kernel<true><<<grid_for(bflies), kThreads, 0, e.stream>>>(data, roots, logn, layer, bflies);
             }
             else
             {
-                for (int layer = 0; layer < logn - L; layer++)
+                int layer = 0;
+                for (; layer + 1 < logn - L; layer += 2)
+                    fft_layer2_kernel<false><<<grid_for(quads), kThreads, 0, e.stream>>>(data, roots, logn, layer, quads);
+                if (layer < logn - L)
                     fft_layer_kernel<false><<<grid_for(bflies), kThreads, 0, e.stream>>>(data, roots, logn, layer, bflies);
                 fft_local_kernel<false><<<static_cast<unsigned>(tiles), kThreads, lds, e.stream>>>(data, roots, logn, L);
             }

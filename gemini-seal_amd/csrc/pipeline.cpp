@@ -752,8 +752,13 @@ namespace sealhip
             e.ws_reset();
             u64 *copy = e.ws_alloc(poly * m);
             double *res = reinterpret_cast<double *>(e.ws_alloc(2 * N * m));
-            check(launch_copy_rows(e, plain + off * poly, poly, copy, poly, m, k), "copy(plain)");
-            check(launch_ntt(e, copy, m * k, map_q, true, kNttCanonical), "intt(plain)"); // :674-678
+            if (ntt_can_gather(e)) // the single-pass inverse kernel reads the plaintext rows where they are
+                check(launch_intt_from(e, copy, plain + off * poly, poly, m * k, map_q, kNttCanonical), "intt(plain)");
+            else
+            {
+                check(launch_copy_rows(e, plain + off * poly, poly, copy, poly, m, k), "copy(plain)");
+                check(launch_ntt(e, copy, m * k, map_q, true, kNttCanonical), "intt(plain)"); // :674-678
+            }
             check(launch_ckks_decode_back(e, copy, consts, k, m, inv_scale, res, values + off * N, e.d_ckks_map, e.d_ckks_roots),
                   "ckks decode");
         }
