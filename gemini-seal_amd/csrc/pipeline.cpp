@@ -148,7 +148,21 @@ namespace sealhip
                     need_any = need_any || (a != b && ps > pd);
                     need_barrett = need_barrett || (a != b && ps >= 2 * pd);
                 }
-            const int modup_mode = need_barrett ? 1 : (need_any ? 2 : 0);
+            int modup_mode = need_barrett ? 1 : (need_any ? 2 : 0);
+            if (modup_mode == 2)
+            {
+                // A gathered word is then below 2p of its destination prime. The lazy forward transform takes such an input
+                // as it is (the first operand of a butterfly is never reduced before the last layer, the second goes through
+                // mulmodLazy, ntt.cpp:245-261): with p < 2^58 nothing can wrap (2p(log n + 1) < 2^64), the extended
+                // polynomial never leaves this function, and the inner product reduces to the canonical residue either
+                // way -- so the conditional subtraction of all loaded words (6 % of the kernel's vector instructions, and
+                // the kernel runs at the package power cap) is dropped. Larger primes keep it.
+                u64 pmax = 0;
+                for (int r = 0; r < rows; r++)
+                    pmax = std::max(pmax, e.key_moduli[h.row_prime[r]]);
+                if (pmax < (u64(1) << 58))
+                    modup_mode = 0;
+            }
             if (!gather)
                 check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
             for (int j = 0; j < nd; j++)
