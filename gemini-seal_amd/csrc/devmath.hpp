@@ -396,9 +396,12 @@ namespace sealhip
     };
     // IL inverse (Gentleman-Sande) lazy butterflies in lock step (BackwardLazy, ntt.cpp:265-272):
     // x' = u + v - (2p if >= 2p), y' = (u - v + 2p) * w lazily. Same instruction discipline as butterflies_fwd_hs.
-    template <bool WU, int IL>
+    // MODE 0: the reference's sequence (addend = 2p). MODE 1 / 2 (the caller allows any representative and has checked
+    // that nothing can wrap): the sum is left unreduced / reduced with barrett_lazy to [0, 2p), and `addend` is a
+    // multiple of p not below the largest second operand, so that u - v + addend stays non-negative.
+    template <bool WU, int IL, int MODE = 0>
     __device__ __forceinline__ void butterflies_inv_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
-                                                       u64 neg_p, u64 two_p)
+                                                       u64 neg_p, u64 two_p, u64 rdp = 0)
     {
         static_assert(IL >= 2, "the carry of step 3 is read in step 5: at least two other instructions in between");
         const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
@@ -410,7 +413,12 @@ namespace sealhip
         {
             dlt[j] = u[j] - y[j] + two_p;
             u64 tt = u[j] + y[j];
-            u[j] = tt >= two_p ? tt - two_p : tt;
+            if (MODE == 0)
+                u[j] = tt >= two_p ? tt - two_p : tt;
+            else if (MODE == 1)
+                u[j] = tt;
+            else
+                u[j] = barrett_lazy_hs(tt, rdp, neg_p);
         }
 #pragma unroll
         for (int j = 0; j < IL; j++)

@@ -48,6 +48,7 @@ namespace sealhip
 
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
+    constexpr int kNttAnyRep = 8;    // inverse: the consumer canonicalises, any representative below 2p may be stored
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
 
     struct NttRound

@@ -909,7 +909,25 @@ namespace sealhip
         // in, ntt.cpp:393-402) needs both halves and is applied by ntt_inv_top_kernel, a pure streaming
         // pass (or, inside the pipelines, by the consumer kernel).
         // ---- inverse rounds as stage pipelines (mirror of RoundStage / RoundPipe; layers ascend W = 1, 2, 3, 4)
-        template <int T, int R, bool UNIFORM, int K>
+        // Lazy-sum schedule of the inverse (only when the caller accepts any representative of the stored values and every
+        // prime of the launch is small enough, launch_half_inv): the conditional subtraction of the sum output is dropped
+        // on all but two of the T on-chip layers; those two (the middle one and the last) reduce with barrett_lazy
+        // instead. Values entering layer l are below 2^shift(l) * p; the difference operand gets that bound added.
+        template <int T>
+        struct InvLazy
+        {
+            static constexpr int r1 = (T - 1) / 2;
+            static constexpr int mode(int l)
+            {
+                return (l == r1 || l == T - 1) ? 2 : 1;
+            }
+            static constexpr int shift(int l)
+            {
+                return 1 + (l <= r1 ? l : l - r1 - 1);
+            }
+            static constexpr int max_shift = 1 + (r1 > T - 2 - r1 ? r1 : T - 2 - r1);
+        };
+        template <int T, int R, bool UNIFORM, int K, bool LZ = false>
         struct RoundStageInv
         {
             static constexpr int PER = 16 / kIL;
@@ -936,8 +954,9 @@ namespace sealhip
                     ws[j] = Wv.y;
                 }
             }
+            static constexpr int layer = (T - 12) + 4 * (3 - R) + (W - 1); // 0-based on-chip layer index
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
-                                                       u64 neg_p)
+                                                       u64 neg_p, u64 rdp)
             {
                 u64 u[kIL], y[kIL];
 #pragma unroll
@@ -946,7 +965,11 @@ namespace sealhip
                     u[j] = x[slot(j)];
                     y[j] = x[slot(j) | bit];
                 }
-                butterflies_inv_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // BackwardLazy, ntt.cpp:265-272
+                if constexpr (LZ)
+                    butterflies_inv_hs<UNIFORM, kIL, InvLazy<T>::mode(layer)>(u, y, w, ws, neg_p,
+                                                                             (0 - neg_p) << InvLazy<T>::shift(layer), rdp);
+                else
+                    butterflies_inv_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // BackwardLazy, ntt.cpp:265-272
 #pragma unroll
                 for (int j = 0; j < kIL; j++)
                 {
@@ -955,20 +978,21 @@ namespace sealhip
                 }
             }
         };
-        template <int T, int R, bool UNIFORM, int K = 0>
+        template <int T, int R, bool UNIFORM, bool LZ, int K = 0>
         struct RoundPipeInv
         {
             static constexpr int NST = 4 * (16 / kIL);
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
-                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p)
+                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p,
+                                                       u64 rdp)
             {
                 u64 wn[kIL], wsn[kIL];
                 if constexpr (K + 1 < NST)
-                    RoundStageInv<T, R, UNIFORM, K + 1>::load(wn, wsn, tw, jb, N);
+                    RoundStageInv<T, R, UNIFORM, K + 1, LZ>::load(wn, wsn, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                RoundStageInv<T, R, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
+                RoundStageInv<T, R, UNIFORM, K, LZ>::run(x, w, ws, two_p, neg_p, rdp);
                 if constexpr (K + 1 < NST)
-                    RoundPipeInv<T, R, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
+                    RoundPipeInv<T, R, UNIFORM, LZ, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, rdp);
             }
         };
 
@@ -994,15 +1018,17 @@ namespace sealhip
                 base += 1 << (f - 1 - W);
             }
         }
-        template <int T, int G>
+        template <int T, int G, bool LZ>
         __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
         {
             constexpr int f = T - 12;
+            static_assert(f - 1 < InvLazy<T>::r1, "the first layers are never the reducing ones");
             int base = 0;
 #pragma unroll
             for (int W = 0; W < f; W++)
             {
                 const int bit = 1 << W;
+                const u64 addend = LZ ? (0 - neg_p) << InvLazy<T>::shift(W) : two_p; // layer index = W
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
                 {
@@ -1012,30 +1038,31 @@ namespace sealhip
                     const u64x2 Wv = tg[base + (e >> (W + 1))];
                     const u64 u = x[s], v = x[s | bit];
                     u64 tt = u + v;
-                    tt = tt >= two_p ? tt - two_p : tt;
+                    if (!LZ)
+                        tt = tt >= two_p ? tt - two_p : tt;
                     x[s] = tt;
-                    x[s | bit] = mulmod_lazy_hs<false>(u - v + two_p, Wv.x, Wv.y, neg_p);
+                    x[s | bit] = mulmod_lazy_hs<false>(u - v + addend, Wv.x, Wv.y, neg_p);
                 }
                 base += 1 << (f - 1 - W);
             }
         }
-        template <int T, int ST, int I = 0>
+        template <int T, int ST, bool LZ, int I = 0>
         struct FirstStage
         {
             __device__ static __forceinline__ void load(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
             {
                 h_first_tw<T, ST * FinalStage<T>::SG + I>(tg + I * FinalStage<T>::NTW, tw, jb, N);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    FirstStage<T, ST, I + 1>::load(tg, tw, jb, N);
+                    FirstStage<T, ST, LZ, I + 1>::load(tg, tw, jb, N);
             }
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
             {
-                h_first_group_regs<T, ST * FinalStage<T>::SG + I>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p);
+                h_first_group_regs<T, ST * FinalStage<T>::SG + I, LZ>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    FirstStage<T, ST, I + 1>::run(x, tg, neg_p, two_p);
+                    FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p);
             }
         };
-        template <int T, int ST>
+        template <int T, int ST, bool LZ>
         struct FirstPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
@@ -1043,18 +1070,18 @@ namespace sealhip
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS && FinalStage<T>::PIPE)
-                    FirstStage<T, ST + 1>::load(next, tw, jb, N);
+                    FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                FirstStage<T, ST>::run(x, cur, neg_p, two_p);
+                FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS && !FinalStage<T>::PIPE) // f = 3: two stages do not fit
-                    FirstStage<T, ST + 1>::load(next, tw, jb, N);
+                    FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FirstPipe<T, ST + 1>::run(x, next, tw, jb, N, neg_p, two_p);
+                    FirstPipe<T, ST + 1, LZ>::run(x, next, tw, jb, N, neg_p, two_p);
             }
         };
 
-        template <int LOGN>
+        template <int LOGN, bool LZ>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
@@ -1087,7 +1114,7 @@ namespace sealhip
                 // the first stage with them
                 const int jloc = Arr<T, 4>::tid_index(fresh(tid));
                 u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
-                FirstStage<T, 0>::load(tg0, tw, gbase + jloc, N);
+                FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
@@ -1096,22 +1123,23 @@ namespace sealhip
                     x[s + 1] = v.y;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                FirstPipe<T, 0>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
+                FirstPipe<T, 0, LZ>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
             }
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
             u64 w0[kIL], ws0[kIL];
+            const u64 rdp = LZ ? P.rdp : 0; // only the reducing layers of the lazy schedule read it
             RoundStageInv<T, 3, false, 0>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 4, 3>(x, lds, fresh(tid));
-            RoundPipeInv<T, 3, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
+            RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
             RoundStageInv<T, 2, false, 0>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 3, 2>(x, lds, fresh(tid));
-            RoundPipeInv<T, 2, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
+            RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp);
             RoundStageInv<T, 1, true, 0>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh(tid));
-            RoundPipeInv<T, 1, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
+            RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
             {
                 const int jb = Arr<T, 1>::tid_index(fresh(tid));
 #pragma unroll
@@ -1189,8 +1217,19 @@ namespace sealhip
                 return hipErrorInvalidValue;
             {
                 ProfScope prof(e, "ntt_inv_half", transformed_rows(nrows, map));
-                ntt_inv_half_kernel<LOGN><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
-                    data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
+                // lazy-sum schedule (InvLazy): the stored values keep their residue class and stay below 2p, but not the
+                // reference's representative -- only where the caller says so (kNttAnyRep: its inputs are below 2p and
+                // the consuming kernel canonicalises) and no live prime can wrap
+                static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_INV") != nullptr;
+                bool lazy = (flags & kNttAnyRep) != 0 && !exact_only;
+                for (int i = 0; lazy && i < live.n; i++)
+                    lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
+                if (lazy)
+                    ntt_inv_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
+                else
+                    ntt_inv_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -1313,7 +1352,11 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN>),
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (err != hipSuccess)
+                return err;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         }
 

@@ -123,8 +123,10 @@ namespace sealhip
             std::size_t src_stride = target_stride;
             if (ckks)
             {
+                // (valid ciphertext rows are below p and the canonicalising top kernel follows: any representative will do)
                 if (ntt_can_gather(e)) // the inverse kernel reads the target rows where they are
-                    check(launch_intt_from(e, coeff, tg, target_stride, m * k, map_q, kNttCanonical), "intt(target)");
+                    check(launch_intt_from(e, coeff, tg, target_stride, m * k, map_q, kNttCanonical | kNttAnyRep),
+                          "intt(target)");
                 else
                 {
                     check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
@@ -213,12 +215,14 @@ namespace sealhip
                 // special rows first, :2351-2355, and the others inside rescale_special_rns_inplace, :286-289 -- the
                 // order of independent row transforms does not matter), then one fused mod-down kernel
                 const bool defer = ntt_can_defer_top(e, k);
-                check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, defer ? kNttDeferTop : 0), "intt(prod)");
+                // (ks_moddown_bfv reduces what it reads canonically: any representative below 2p will do)
+                check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, defer ? (kNttDeferTop | kNttAnyRep) : 0), "intt(prod)");
                 check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer), "moddown_bfv");
                 continue;
             }
             // (:2351-2355) special rows back to coefficient form (lazy)
-            check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, 0), "intt(special)");
+            // (the mod-down reduces the special rows with barrett_reduce_63 / a Shoup product: canonical either way)
+            check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, kNttAnyRep), "intt(special)");
             // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
             check(launch_ks_moddown_pre(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, 2 * m),
                   "moddown_pre");
@@ -332,7 +336,19 @@ namespace sealhip
             // step (5) (:423-424); with the single-pass kernels the top inverse layer and the canonicalisation are
             // applied by the consumer while it loads (saves one read+write pass over D)
             const bool defer = ntt_can_defer_top(e, k);
-            check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, defer ? kNttDeferTop : kNttCanonical), "intt(D)");
+            if (defer)
+            {
+                // two launches over disjoint rows: the q rows may store any representative (bfv_floor_sk canonicalises
+                // while it applies the deferred top layer), which lets the kernel drop most conditional subtractions;
+                // the 60-bit Bsk rows have no head-room for that and keep the reference's sequence
+                RowMap mq = lt.map_qbsk, mb = lt.map_qbsk;
+                for (int r = 0; r < kb; r++)
+                    (r < k ? mb : mq).prime[r] = kSkipRow;
+                check(launch_ntt(e, D, m * dest * kb, mq, true, kNttDeferTop | kNttAnyRep), "intt(D, q rows)");
+                check(launch_ntt(e, D, m * dest * kb, mb, true, kNttDeferTop), "intt(D, Bsk rows)");
+            }
+            else
+                check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, kNttCanonical), "intt(D)");
             // steps (6)-(8) (:427-444)
             for (int I = 0; I < dest; I++)
                 check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
