@@ -388,7 +388,7 @@ namespace sealhip
 
         template <int T, bool STRICT, int G>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
-                                                      int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+                                                      int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
             constexpr int f = T - 12;
 #pragma unroll
@@ -408,7 +408,7 @@ namespace sealhip
                     const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
                     if (STRICT)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
-                    else if (gb == 0)
+                    else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
                     butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
                 }
@@ -420,7 +420,7 @@ namespace sealhip
                 ulonglong2 v;
                 v.x = x[s];
                 v.y = x[s + 1];
-                if (canon)
+                if (fin & 1)
                 {
                     v.x = v.x >= two_p ? v.x - two_p : v.x;
                     v.y = v.y >= two_p ? v.y - two_p : v.y;
@@ -439,12 +439,12 @@ namespace sealhip
         struct FinalGroups
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
-                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
-                h_final_group<T, STRICT, G>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                h_final_group<T, STRICT, G>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 if ((G & 1) == 1)
                     __builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting every group's twiddle loads
-                FinalGroups<T, STRICT, G + 1, NG>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                FinalGroups<T, STRICT, G + 1, NG>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
         template <int T, bool STRICT, int NG>
@@ -487,7 +487,7 @@ namespace sealhip
 
         template <int T, bool STRICT, int G>
         __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
-                                                           int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+                                                           int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
             constexpr int f = T - 12;
 #pragma unroll
@@ -506,7 +506,7 @@ namespace sealhip
                     const u64x2 Wv = tg[(1 << (f - 1 - W)) - 1 + (e >> (W + 1))];
                     if (STRICT)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
-                    else if (gb == 0)
+                    else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
                     butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
                 }
@@ -518,7 +518,7 @@ namespace sealhip
                 ulonglong2 v;
                 v.x = x[s];
                 v.y = x[s + 1];
-                if (canon)
+                if (fin & 1)
                 {
                     v.x = v.x >= two_p ? v.x - two_p : v.x;
                     v.y = v.y >= two_p ? v.y - two_p : v.y;
@@ -545,12 +545,12 @@ namespace sealhip
         struct StageRun
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
-                                                       u64 p, u64 two_p, u64 neg_p, u64 rdp, bool canon)
+                                                       u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
                 h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
-                                                                         two_p, neg_p, rdp, canon);
+                                                                         two_p, neg_p, rdp, fin);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    StageRun<T, STRICT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                    StageRun<T, STRICT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
         template <int T, bool STRICT, int ST>
@@ -558,16 +558,16 @@ namespace sealhip
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
                                                        u64 *__restrict__ rowp, int jb, int N, u64 p, u64 two_p, u64 neg_p,
-                                                       u64 rdp, bool canon)
+                                                       u64 rdp, int fin)
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS)
                     StageTw<T, ST + 1>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                StageRun<T, STRICT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                StageRun<T, STRICT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FinalPipe<T, STRICT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, canon);
+                    FinalPipe<T, STRICT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
 
@@ -882,11 +882,12 @@ namespace sealhip
             NTT_STAMP(3);
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
             const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
+            // bit 0: canonicalising wrapper; bit 1: leave the last layer's first operand unreduced (kNttAnyRep)
+            const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0);
             if constexpr (FinalStage<T>::PIPE)
-                FinalPipe<T, STRICT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, (flags & kNttCanonical) != 0);
+                FinalPipe<T, STRICT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             else
-                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp,
-                                                                 (flags & kNttCanonical) != 0);
+                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
             if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
@@ -1308,6 +1309,17 @@ namespace sealhip
                 }
             } trace_dump{trace, trace_path, blocks, e.stream};
 #endif
+            if (flags & kNttAnyRep)
+            {
+                // the last layer may keep its first operand unreduced only if the grown values cannot wrap
+                // (below (2 log n + 3) p < 2^64 for p < 2^58) and nothing expects the [0, 4p) output range
+                static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
+                bool ok = !exact_only && (flags & (kNttCanonical | kNttStrict)) == 0;
+                for (int i = 0; ok && i < live.n; i++)
+                    ok = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
+                if (!ok)
+                    flags &= ~kNttAnyRep;
+            }
             ProfScope prof(e, "ntt_fwd_half", transformed_rows(nrows, map));
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
     ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>( \

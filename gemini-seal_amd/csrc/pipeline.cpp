@@ -190,7 +190,8 @@ namespace sealhip
                         const u64 p_dst = e.key_moduli[h.row_prime[r]];
                         ns.code[r] = static_cast<unsigned short>(j | (p_src <= p_dst ? 0 : kSrcReduce));
                     }
-                    check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, 0), "ntt(ext, gathered)");
+                    // (the inner product reduces canonically: any representative of the transformed rows will do)
+                    check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, kNttAnyRep), "ntt(ext, gathered)");
                 }
                 else
                     check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
@@ -327,7 +328,15 @@ namespace sealhip
                             code = static_cast<unsigned short>((s < sa ? 0 : kSrcSecond) | ((s < sa ? s : s - sa) * k + r));
                         ns.code[s * kb + r] = code;
                     }
-                check(launch_ntt_gather(e, X, m * sin * kb, big, ns, 0), "ntt(X, gathered)");
+                // two launches over disjoint rows: the q rows only feed the tensor product, which reduces canonically, so
+                // their last layer may skip its Barrett step (kNttAnyRep); the 60-bit Bsk rows wrap in the reference (F2)
+                // and keep its exact sequence
+                RowMap mq = big, mb = big;
+                for (int s = 0; s < sin; s++)
+                    for (int r = 0; r < kb; r++)
+                        (r < k ? mb : mq).prime[s * kb + r] = kSkipRow;
+                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, kNttAnyRep), "ntt(X, gathered q rows)");
+                check(launch_ntt(e, X, m * sin * kb, mb, false, 0), "ntt(X, Bsk rows)");
             }
             else
                 check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
