@@ -337,9 +337,23 @@ namespace sealhip
                     G2m[static_cast<std::size_t>(j) * k + i] = mont(G2[static_cast<std::size_t>(j) * k + i], b);
                 }
             }
+            for (int j = 0; j < nB; j++)
+            {
+                // Bsk row j is prime id n_key + (j < B ? 2 + j : 0) (m_sk last); fold its top-layer factors into G1
+                const u64 b = hr.Bsk[j];
+                const HostNttTables &tb = tables[n_key + (j < B ? 2 + j : 0)];
+                if (tb.p != b)
+                    throw std::logic_error("internal: Bsk prime order");
+                rd.floor_G1m_top[0][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n, b), b);
+                rd.floor_G1m_top[1][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n_w, b), b);
+            }
             for (int i = 0; i < k; i++)
             {
                 const u64 qi = hr.q[i];
+                rd.floor_F0_top[0][i] = mulmod(rd.floor_F0[i], tables[i].inv_n, qi);
+                rd.floor_F0_top[1][i] = mulmod(rd.floor_F0[i], tables[i].inv_n_w, qi);
+                rd.floor_F0_top_s[0][i] = shoup(rd.floor_F0_top[0][i], qi);
+                rd.floor_F0_top_s[1][i] = shoup(rd.floor_F0_top[1][i], qi);
                 rd.q_mt_inv_s[i] = shoup(rd.q_mt_inv[i], qi);
                 rd.floor_F0_s[i] = shoup(rd.floor_F0[i], qi);
                 rd.pBm[i] = mont(hr.prod_B_mod_q[i], qi);
@@ -384,7 +398,8 @@ namespace sealhip
             //   lift rows:   k terms t_i < q_i plus temp < b_j;  floor Bsk rows: in < b_j plus k terms < q_i;
             //   conv_sk: B terms < b;  out rows: B terms tb_j < b_j plus alpha-term < m_sk
             const u128 lim = static_cast<u128>(1) << 64;
-            const u128 s1 = static_cast<u128>(k) * max_q + max_b;
+            // (with a deferred top layer the Bsk operand of the floor rows is a lazy value below 2 b_j)
+            const u128 s1 = static_cast<u128>(k) * max_q + 2 * static_cast<u128>(max_b);
             const u128 s2 = static_cast<u128>(B + 1) * max_b;
             rd.redc_small = (s1 <= lim && s2 <= lim) ? 1 : 0;
         }

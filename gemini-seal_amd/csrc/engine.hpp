@@ -96,6 +96,10 @@ namespace sealhip
         u64 lift_L2[kMaxModuli + 2];  // prod_q * m_tilde^{-1} mod b_j
         u64 floor_G1[kMaxModuli + 2]; // t * (prod q)^{-1} [* B^_j^{-1} for j < B] mod b_j
         u64 floor_F0[kMaxModuli];     // t * (q^_i)^{-1} mod q_i
+        // the same constants with the deferred top inverse-NTT layer's factor folded in (index 0: lower half of a row,
+        // n^{-1}; index 1: upper half, w * n^{-1}; ntt.cpp:393-402), so the fused floor kernel multiplies once, not twice
+        u64 floor_F0_top[2][kMaxModuli], floor_F0_top_s[2][kMaxModuli];
+        u64 floor_G1m_top[2][kMaxModuli + 2];
         // Montgomery/Shoup companions of the folded constants (suffix m: times 2^64 mod the row's prime; s: Shoup)
         const u64 *lift_L1m, *floor_G2m, *B_to_qm; // [nB][k], [nB][k], [k][B]
         u64 lift_L2m[kMaxModuli + 2], floor_G1m[kMaxModuli + 2];

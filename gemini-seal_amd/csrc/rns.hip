@@ -249,6 +249,18 @@ namespace sealhip
             }
             return r >= p ? r - p : r;
         }
+        // The same pair without the multiplication: its constant (n^{-1} or w * n^{-1}) is folded into the constant the
+        // value is multiplied with next (RnsDev::floor_F0_top / floor_G1m_top). REDUCE brings the value below 2p (operands
+        // of the carry-free dot products must stay below 2^61); a Shoup product takes it as it is.
+        template <bool REDUCE, class PP>
+        __device__ __forceinline__ u64 before_top(u64 u, u64 v, bool is_hi, PP P)
+        {
+            const u64 two_p = P->two_p;
+            u64 r = is_hi ? u - v + two_p : u + v; // < 4p
+            if (REDUCE)
+                r = r >= two_p ? r - two_p : r;
+            return r;
+        }
         template <int KMAX, bool DEFER>
         __global__ __launch_bounds__(kThreads) void bfv_floor_sk2_kernel(const RnsDev *__restrict__ d_,
                                                                          const PrimeDev *__restrict__ primes_,
@@ -294,8 +306,11 @@ namespace sealhip
                 if (KMAX < 0 || i < k)
                 {
                     const auto *Q = primes + d->q_prime[i];
-                    const u64 xin = DEFER ? after_top(ru[i], rv[i], is_hi, Q) : ru[i];
-                    t[i] = mulmod_shoup_hs(xin, kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
+                    if (DEFER) // (u +- v) * (n^{-1} or w n^{-1}) * F0 with ONE canonical Shoup product
+                        t[i] = mulmod_shoup_hs(before_top<false>(ru[i], rv[i], is_hi, Q), kc(d->floor_F0_top[is_hi ? 1 : 0])[i],
+                                               kc(d->floor_F0_top_s[is_hi ? 1 : 0])[i], Q->p);
+                    else
+                        t[i] = mulmod_shoup_hs(ru[i], kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
                 }
             u64 tb[KA + 1];
             u64 fl_sk = 0;
@@ -303,7 +318,7 @@ namespace sealhip
             SplitT ts[KA], tbs[KA + 1];
             if constexpr (KMAX < 0)
                 static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
-            const auto *G1m = kc(d->floor_G1m);
+            const auto *G1m = DEFER ? kc(d->floor_G1m_top[is_hi ? 1 : 0]) : kc(d->floor_G1m);
             const auto *G2m = kc(d->floor_G2m);
 #pragma unroll
             for (int j = 0; j < KA + 2; j++)
@@ -311,7 +326,7 @@ namespace sealhip
                 {
                     const auto *Bp = primes + d->bsk_prime[j];
                     const auto *row = G2m + j * k;
-                    const u64 x = DEFER ? after_top(ru[KA + j], rv[KA + j], is_hi, Bp) : ru[KA + j];
+                    const u64 x = DEFER ? before_top<true>(ru[KA + j], rv[KA + j], is_hi, Bp) : ru[KA + j];
                     u64 lo, hi;
                     if constexpr (KMAX < 0)
                     {
