@@ -41,7 +41,9 @@ struct sealhip_graph
 {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    unsigned long long generation = 0; // Engine::alloc_generation at capture: the graph holds arena addresses
+    Lane *lane = nullptr;                  // the lane it was captured on (its arena addresses are baked in)
+    unsigned long long generation = 0;     // Lane::alloc_generation at capture
+    unsigned long long key_generation = 0; // Engine::key_generation at capture (key addresses are baked in too)
 };
 
 namespace
@@ -54,13 +56,15 @@ namespace
         return code;
     }
 
-    // Every compute entry point holds the context's operation lock until it returns: entry points may be called
-    // from several host threads, but operations of one context are serialised (they share the workspace arena and
-    // the stream); use one context per worker thread for concurrency.
+    // Entry points may be called concurrently from several host threads on one context (the reference's Evaluator is
+    // re-entrant, evaluator.h:1375-1377): every thread works on its own lane (stream + arena, engine.hpp). An operation
+    // holds its lane's lock until it returns; that lock is only ever contended when a graph captured on one thread is
+    // launched from another.
     struct OpLock
     {
+        Engine *engine;
         std::unique_lock<std::recursive_mutex> lock;
-        explicit OpLock(Engine &e) : lock(e.op_mu)
+        explicit OpLock(Engine &e) : engine(&e), lock(e.lane().busy)
         {}
     };
     thread_local std::vector<std::unique_ptr<OpLock>> g_locks;
@@ -74,6 +78,25 @@ namespace
         }
     };
 
+    // An operation that fails while its lane is capturing a graph leaves the stream in capture mode and the graph
+    // half-built: end the capture, drop the graph and say so (the caller must not call _capture_end for it).
+    std::string abort_capture_if_any()
+    {
+        if (g_locks.empty())
+            return "";
+        Engine &e = *g_locks.back()->engine;
+        Lane &l = e.lane();
+        if (!l.capturing)
+            return "";
+        l.capturing = false;
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(l.stream, &g);
+        if (g)
+            (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return " (the graph capture in progress on this thread was aborted and discarded)";
+    }
+
     template <class F>
     long guarded(F &&body)
     {
@@ -85,31 +108,38 @@ namespace
         }
         catch (const HipError &err)
         {
-            return fail(err.code == hipErrorOutOfMemory ? SEALHIP_E_OUTOFMEMORY : SEALHIP_E_UNEXPECTED, err.what());
+            const std::string note = abort_capture_if_any();
+            return fail(err.code == hipErrorOutOfMemory ? SEALHIP_E_OUTOFMEMORY : SEALHIP_E_UNEXPECTED, err.what() + note);
         }
         catch (const std::invalid_argument &err)
         {
-            return fail(SEALHIP_E_INVALIDARG, err.what());
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_E_INVALIDARG, err.what() + note);
         }
         catch (const std::out_of_range &err)
         {
-            return fail(SEALHIP_E_INVALIDARG, err.what());
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_E_INVALIDARG, err.what() + note);
         }
         catch (const std::logic_error &err)
         {
-            return fail(SEALHIP_COR_E_INVALIDOPERATION, err.what());
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_COR_E_INVALIDOPERATION, err.what() + note);
         }
         catch (const std::bad_alloc &)
         {
-            return fail(SEALHIP_E_OUTOFMEMORY, "out of host memory");
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_E_OUTOFMEMORY, "out of host memory" + note);
         }
         catch (const std::exception &err)
         {
-            return fail(SEALHIP_E_UNEXPECTED, err.what());
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_E_UNEXPECTED, err.what() + note);
         }
         catch (...)
         {
-            return fail(SEALHIP_E_UNEXPECTED, "unknown error");
+            const std::string note = abort_capture_if_any();
+            return fail(SEALHIP_E_UNEXPECTED, "unknown error" + note);
         }
     }
 
@@ -125,9 +155,9 @@ namespace
         Engine &e = *ctx->engine;
         if (e.device < 0)
             throw std::logic_error("host-only context: there is no CPU fallback, create the context on a HIP device");
-        g_locks.push_back(std::make_unique<OpLock>(e));
         (void)hipGetLastError(); // an error an earlier call already reported must not be attributed to this one's launches
         SEALHIP_CHECK(hipSetDevice(e.device));
+        g_locks.push_back(std::make_unique<OpLock>(e));
         return e;
     }
 
@@ -259,24 +289,43 @@ long sealhip_context_bsk_size(sealhip_context *ctx, uint32_t k, uint32_t *bsk_si
     });
 }
 
+namespace
+{
+    void adopt_stream(Engine &e, hipStream_t stream, bool own)
+    {
+        Lane &l = e.lane();
+        if (l.capturing)
+            throw std::logic_error("a graph capture is in progress on this thread");
+        SEALHIP_CHECK(hipStreamSynchronize(l.stream));
+        if (l.own_stream)
+            SEALHIP_CHECK(hipStreamDestroy(l.stream));
+        l.stream = stream;
+        l.own_stream = own;
+    }
+} // namespace
+
 long sealhip_set_stream(sealhip_context *ctx, void *hip_stream)
 {
     REQUIRE_PTR(ctx);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
         if (hip_stream)
+            adopt_stream(e, static_cast<hipStream_t>(hip_stream), false);
+        else if (!e.lane().own_stream)
         {
-            if (e.own_stream)
-                SEALHIP_CHECK(hipStreamDestroy(e.stream));
-            e.stream = static_cast<hipStream_t>(hip_stream);
-            e.own_stream = false;
+            hipStream_t s = nullptr;
+            SEALHIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            adopt_stream(e, s, true);
         }
-        else if (!e.own_stream)
-        {
-            SEALHIP_CHECK(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
-            e.own_stream = true;
-        }
+    });
+}
+
+long sealhip_use_default_stream(sealhip_context *ctx)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        adopt_stream(e, nullptr, false); // the legacy NULL stream: ordered against every blocking stream of the device
     });
 }
 
@@ -285,17 +334,18 @@ long sealhip_synchronize(sealhip_context *ctx)
     REQUIRE_PTR(ctx);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
-        if (e.d_tickets)
-        {
-            unsigned flag = 0;
-            SEALHIP_CHECK(hipMemcpy(&flag, e.d_tickets, sizeof(flag), hipMemcpyDeviceToHost));
-            if (flag)
-            {
-                SEALHIP_CHECK(hipMemset(e.d_tickets, 0, sizeof(flag)));
-                throw std::runtime_error("forward NTT: sibling workgroup wait timed out; results of that launch are invalid");
-            }
-        }
+        e.sync_and_check(true);
+    });
+}
+
+long sealhip_debug_ntt_handoff(sealhip_context *ctx, uint32_t spin_limit, int32_t suppress_signal)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        e.sync_and_check(true);
+        e.ntt_spin_limit = spin_limit ? spin_limit : (1u << 24);
+        e.ntt_suppress_signal = suppress_signal != 0;
     });
 }
 
@@ -314,7 +364,7 @@ long sealhip_free(sealhip_context *ctx, void *dptr)
     REQUIRE_PTR(ctx);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream));
         SEALHIP_CHECK(hipFree(dptr));
     });
 }
@@ -326,8 +376,8 @@ long sealhip_memcpy_h2d(sealhip_context *ctx, void *dst_dev, const void *src_hos
     REQUIRE_PTR(src_host);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, e.lane().stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream));
     });
 }
 
@@ -338,8 +388,8 @@ long sealhip_memcpy_d2h(sealhip_context *ctx, void *dst_host, const void *src_de
     REQUIRE_PTR(src_dev);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, e.lane().stream));
+        e.sync_and_check(); // results become host-visible here: a failed launch must not return S_OK
     });
 }
 
@@ -348,7 +398,7 @@ long sealhip_profile_enable(sealhip_context *ctx, int32_t enable)
     REQUIRE_PTR(ctx);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        e.prof_on = enable != 0;
+        e.lane().prof_on = enable != 0;
     });
 }
 
@@ -358,14 +408,14 @@ long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity)
     REQUIRE_PTR(json);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        e.sync_and_check();
         struct Agg
         {
             std::size_t launches = 0;
             double ms = 0, units = 0;
         };
         std::map<std::string, Agg> agg;
-        for (ProfRecord &r : e.prof)
+        for (ProfRecord &r : e.lane().prof)
         {
             float ms = 0;
             if (r.start && r.stop && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess)
@@ -380,7 +430,7 @@ long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity)
             if (r.stop)
                 (void)hipEventDestroy(r.stop);
         }
-        e.prof.clear();
+        e.lane().prof.clear();
         std::string out = "{";
         bool first = true;
         for (auto &kv : agg)
@@ -664,9 +714,9 @@ long sealhip_kswitch_key_load(sealhip_context *ctx, const uint64_t *key, uint32_
         k->key.words = static_cast<std::size_t>(n_digits) * 2 * e.n_key * e.n;
         SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&k->key.d_data), k->key.words * sizeof(u64)));
         hipError_t err = hipMemcpyAsync(k->key.d_data, key, k->key.words * sizeof(u64),
-                                        from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e.stream);
+                                        from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e.lane().stream);
         if (err == hipSuccess)
-            err = hipStreamSynchronize(e.stream);
+            err = hipStreamSynchronize(e.lane().stream);
         if (err != hipSuccess)
         {
             (void)hipFree(k->key.d_data);
@@ -681,7 +731,8 @@ long sealhip_kswitch_key_destroy(sealhip_context *ctx, sealhip_kswitch_key *key)
     REQUIRE_PTR(key);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        e.sync_and_check(true); // any thread's lane may still be reading the key
+        e.key_generation++;     // graphs captured earlier may embed this key's address: they are stale now
         SEALHIP_CHECK(hipFree(key->key.d_data));
         delete key;
     });
@@ -978,15 +1029,15 @@ long sealhip_is_transparent(sealhip_context *ctx, uint32_t k, const uint64_t *ct
             return;
         }
         const std::size_t poly_words = static_cast<std::size_t>(k) * e.n;
-        e.ws_reserve(e.ws_floor + count * sizeof(unsigned) + 512);
+        e.ws_reserve(e.lane().ws_floor + count * sizeof(unsigned) + 512);
         e.ws_reset();
         unsigned *flags = reinterpret_cast<unsigned *>(e.ws_alloc((count * sizeof(unsigned) + 7) / 8));
-        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.stream));
+        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.lane().stream));
         check_launch(launch_nonzero_tail(e, reinterpret_cast<const u64 *>(ct), poly_words * size, poly_words, count, flags),
                      "is_transparent");
         std::vector<unsigned> host(count);
-        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.lane().stream));
+        e.sync_and_check();
         for (size_t i = 0; i < count; i++)
             transparent[i] = host[i] ? 0 : 1;
     });
@@ -1092,12 +1143,12 @@ long sealhip_graph_capture_begin(sealhip_context *ctx)
     REQUIRE_PTR(ctx);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        if (e.capturing)
+        if (e.lane().capturing)
             throw std::logic_error("a capture is already in progress on this context");
-        if (e.prof_on)
+        if (e.lane().prof_on)
             throw std::logic_error("disable the launch profiler before capturing");
-        SEALHIP_CHECK(hipStreamBeginCapture(e.stream, hipStreamCaptureModeRelaxed));
-        e.capturing = true;
+        SEALHIP_CHECK(hipStreamBeginCapture(e.lane().stream, hipStreamCaptureModeRelaxed));
+        e.lane().capturing = true;
     });
 }
 
@@ -1108,11 +1159,11 @@ long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph)
     *graph = nullptr;
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        if (!e.capturing)
+        if (!e.lane().capturing)
             throw std::logic_error("no capture in progress");
-        e.capturing = false;
+        e.lane().capturing = false;
         auto g = std::make_unique<sealhip_graph>();
-        SEALHIP_CHECK(hipStreamEndCapture(e.stream, &g->graph));
+        SEALHIP_CHECK(hipStreamEndCapture(e.lane().stream, &g->graph));
         if (!g->graph)
             throw std::logic_error("the capture was invalidated (an operation allocated or synchronised): run the sequence "
                                    "once before capturing");
@@ -1122,7 +1173,9 @@ long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph)
             (void)hipGraphDestroy(g->graph);
             throw HipError(err, hipGetErrorString(err));
         }
-        g->generation = e.alloc_generation;
+        g->lane = &e.lane();
+        g->generation = e.lane().alloc_generation;
+        g->key_generation = e.key_generation;
         *graph = g.release();
     });
 }
@@ -1133,9 +1186,14 @@ long sealhip_graph_launch(sealhip_context *ctx, sealhip_graph *graph)
     REQUIRE_PTR(graph);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        if (graph->generation != e.alloc_generation)
+        // replay on the lane the graph was captured on (its arena is part of the graph), whichever thread asks
+        Lane &l = *graph->lane;
+        std::lock_guard<std::recursive_mutex> busy(l.busy);
+        if (graph->generation != l.alloc_generation)
             throw std::logic_error("the graph is stale: the workspace was re-allocated by a larger operation after the capture");
-        SEALHIP_CHECK(hipGraphLaunch(graph->exec, e.stream));
+        if (graph->key_generation != e.key_generation)
+            throw std::logic_error("the graph is stale: a key-switch key was destroyed after the capture");
+        SEALHIP_CHECK(hipGraphLaunch(graph->exec, l.stream));
     });
 }
 
@@ -1145,7 +1203,7 @@ long sealhip_graph_destroy(sealhip_context *ctx, sealhip_graph *graph)
     REQUIRE_PTR(graph);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        e.sync_and_check(true);
         (void)hipGraphExecDestroy(graph->exec);
         (void)hipGraphDestroy(graph->graph);
         delete graph;
@@ -1317,7 +1375,7 @@ long sealhip_ciphertext_resize(sealhip_context *ctx, uint32_t k, const uint64_t 
         const uint32_t keep = std::min(src_size, dst_size);
         u64 *d = reinterpret_cast<u64 *>(dst);
         if (dst_size > keep)
-            SEALHIP_CHECK(hipMemsetAsync(d, 0, count * dst_size * poly * sizeof(u64), e.stream));
+            SEALHIP_CHECK(hipMemsetAsync(d, 0, count * dst_size * poly * sizeof(u64), e.lane().stream));
         if (keep)
             check_launch(launch_copy_rows(e, reinterpret_cast<const u64 *>(src), src_size * poly, d, dst_size * poly, count,
                                           static_cast<int>(keep * k)),
@@ -1416,16 +1474,16 @@ long sealhip_is_data_valid_for(sealhip_context *ctx, uint32_t k, const uint64_t 
         map.rows = static_cast<int>(k);
         for (uint32_t r = 0; r < k; r++)
             map.prime[r] = static_cast<unsigned short>(r);
-        e.ws_reserve(e.ws_floor + count * sizeof(unsigned) + 512);
+        e.ws_reserve(e.lane().ws_floor + count * sizeof(unsigned) + 512);
         e.ws_reset();
         unsigned *flags = reinterpret_cast<unsigned *>(e.ws_alloc((count * sizeof(unsigned) + 7) / 8));
-        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.stream));
+        SEALHIP_CHECK(hipMemsetAsync(flags, 0, count * sizeof(unsigned), e.lane().stream));
         check_launch(launch_out_of_range(e, reinterpret_cast<const u64 *>(ct), static_cast<std::size_t>(size) * k * e.n, count,
                                          map, flags),
                      "is_data_valid_for");
         std::vector<unsigned> host(count);
-        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+        SEALHIP_CHECK(hipMemcpyAsync(host.data(), flags, count * sizeof(unsigned), hipMemcpyDeviceToHost, e.lane().stream));
+        e.sync_and_check();
         for (size_t i = 0; i < count; i++)
             valid[i] = host[i] ? 0 : 1;
     });

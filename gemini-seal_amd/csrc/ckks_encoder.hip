@@ -363,21 +363,21 @@ namespace sealhip
             const std::size_t quads = bflies / 2;
             if (INV)
             {
-                fft_local_kernel<true><<<static_cast<unsigned>(tiles), kThreads, lds, e.stream>>>(data, roots, logn, L);
+                fft_local_kernel<true><<<static_cast<unsigned>(tiles), kThreads, lds, e.lane().stream>>>(data, roots, logn, L);
                 int layer = L;
                 for (; layer + 1 < logn; layer += 2)
-                    fft_layer2_kernel<true><<<grid_for(quads), kThreads, 0, e.stream>>>(data, roots, logn, layer, quads);
+                    fft_layer2_kernel<true><<<grid_for(quads), kThreads, 0, e.lane().stream>>>(data, roots, logn, layer, quads);
                 if (layer < logn)
-                    fft_layer_kernel<true><<<grid_for(bflies), kThreads, 0, e.stream>>>(data, roots, logn, layer, bflies);
+                    fft_layer_kernel<true><<<grid_for(bflies), kThreads, 0, e.lane().stream>>>(data, roots, logn, layer, bflies);
             }
             else
             {
                 int layer = 0;
                 for (; layer + 1 < logn - L; layer += 2)
-                    fft_layer2_kernel<false><<<grid_for(quads), kThreads, 0, e.stream>>>(data, roots, logn, layer, quads);
+                    fft_layer2_kernel<false><<<grid_for(quads), kThreads, 0, e.lane().stream>>>(data, roots, logn, layer, quads);
                 if (layer < logn - L)
-                    fft_layer_kernel<false><<<grid_for(bflies), kThreads, 0, e.stream>>>(data, roots, logn, layer, bflies);
-                fft_local_kernel<false><<<static_cast<unsigned>(tiles), kThreads, lds, e.stream>>>(data, roots, logn, L);
+                    fft_layer_kernel<false><<<grid_for(bflies), kThreads, 0, e.lane().stream>>>(data, roots, logn, layer, bflies);
+                fft_local_kernel<false><<<static_cast<unsigned>(tiles), kThreads, lds, e.lane().stream>>>(data, roots, logn, L);
             }
             return hipGetLastError();
         }
@@ -392,12 +392,12 @@ namespace sealhip
             return hipSuccess;
         ProfScope prof(e, "ckks_encode_fft", static_cast<double>(total));
         double2 *c2 = reinterpret_cast<double2 *>(cv);
-        ckks_place_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(reinterpret_cast<const double2 *>(values), n_values, c2, map,
+        ckks_place_kernel<<<grid_for(total), kThreads, 0, e.lane().stream>>>(reinterpret_cast<const double2 *>(values), n_values, c2, map,
                                                                       e.logn, total);
         hipError_t err = run_fft<true>(e, c2, reinterpret_cast<const double2 *>(inv_roots), count);
         if (err != hipSuccess)
             return err;
-        ckks_round_decompose_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(c2, n_inv_scale, out, rows, e.d_primes, e.logn,
+        ckks_round_decompose_kernel<<<grid_for(total), kThreads, 0, e.lane().stream>>>(c2, n_inv_scale, out, rows, e.d_primes, e.logn,
                                                                                 max_bits, total);
         return hipGetLastError();
     }
@@ -412,13 +412,13 @@ namespace sealhip
         ProfScope prof(e, "ckks_decode_fft", static_cast<double>(total));
         double2 *r2 = reinterpret_cast<double2 *>(res);
         if (k <= 4)
-            ckks_compose_kernel<4><<<grid_for(total), kThreads, 0, e.stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
+            ckks_compose_kernel<4><<<grid_for(total), kThreads, 0, e.lane().stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
         else if (k <= 8)
-            ckks_compose_kernel<8><<<grid_for(total), kThreads, 0, e.stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
+            ckks_compose_kernel<8><<<grid_for(total), kThreads, 0, e.lane().stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
         else if (k <= 16)
-            ckks_compose_kernel<16><<<grid_for(total), kThreads, 0, e.stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
+            ckks_compose_kernel<16><<<grid_for(total), kThreads, 0, e.lane().stream>>>(coeff, d, e.d_primes, inv_scale, r2, e.logn, total);
         else
-            ckks_compose_kernel<kCkksMaxLimbs><<<grid_for(total), kThreads, 0, e.stream>>>(coeff, d, e.d_primes, inv_scale, r2,
+            ckks_compose_kernel<kCkksMaxLimbs><<<grid_for(total), kThreads, 0, e.lane().stream>>>(coeff, d, e.d_primes, inv_scale, r2,
                                                                                           e.logn, total);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess)
@@ -426,7 +426,7 @@ namespace sealhip
         err = run_fft<false>(e, r2, reinterpret_cast<const double2 *>(roots), count);
         if (err != hipSuccess)
             return err;
-        ckks_pick_kernel<<<grid_for(total / 2), kThreads, 0, e.stream>>>(r2, reinterpret_cast<double2 *>(values), map, e.logn,
+        ckks_pick_kernel<<<grid_for(total / 2), kThreads, 0, e.lane().stream>>>(r2, reinterpret_cast<double2 *>(values), map, e.logn,
                                                                         total / 2);
         return hipGetLastError();
     }

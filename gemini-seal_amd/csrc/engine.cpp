@@ -4,6 +4,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -34,6 +35,8 @@ namespace sealhip
             return m;
         }
     } // namespace
+
+    unsigned long long next_pool_id();
 
     std::unique_ptr<Engine> make_engine(int scheme, int logn, const u64 *key_moduli, int n_key, int nsp, u64 t,
                                         bool strict, int device)
@@ -94,8 +97,13 @@ namespace sealhip
             return e;
 
         SEALHIP_CHECK(hipSetDevice(device));
-        SEALHIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        e->own_stream = true;
+        e->lanes = std::make_shared<LanePool>();
+        e->lanes->device = device;
+        e->lanes->id = next_pool_id();
+        // sticky device-side failure flag in host-mapped (coherent) memory: no copy is needed to read it after a sync
+        SEALHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_fault), sizeof(unsigned), hipHostMallocMapped));
+        *e->h_fault = 0;
+        SEALHIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_fault), e->h_fault, 0));
         SEALHIP_CHECK(ntt_init_kernels());
         std::vector<PrimeDev> pd(n_primes);
         for (int i = 0; i < n_primes; i++)
@@ -126,48 +134,178 @@ namespace sealhip
         return e;
     }
 
+    // ---------------------------------------------------------------- lanes (per-host-thread execution state)
+    Lane::~Lane()
+    {
+        if (device < 0)
+            return;
+        (void)hipSetDevice(device);
+        if (stream)
+            (void)hipStreamSynchronize(stream);
+        for (ProfRecord &r : prof)
+        {
+            if (r.start)
+                (void)hipEventDestroy(r.start);
+            if (r.stop)
+                (void)hipEventDestroy(r.stop);
+        }
+        if (ws)
+            (void)hipFree(ws);
+        if (d_tickets)
+            (void)hipFree(d_tickets);
+        if (own_stream && stream)
+            (void)hipStreamDestroy(stream);
+    }
+
+    Lane *LanePool::take()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!idle.empty())
+        {
+            Lane *l = idle.back();
+            idle.pop_back();
+            return l;
+        }
+        auto l = std::make_unique<Lane>();
+        l->device = device;
+        SEALHIP_CHECK(hipSetDevice(device));
+        SEALHIP_CHECK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+        l->own_stream = true;
+        all.push_back(std::move(l));
+        return all.back().get();
+    }
+
+    void LanePool::give(Lane *lane)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        idle.push_back(lane);
+    }
+
+    namespace
+    {
+        // the lanes this thread holds, one per context it has called into; returned to their pools when the thread exits
+        struct ThreadLanes
+        {
+            struct Held
+            {
+                std::weak_ptr<LanePool> pool;
+                Lane *lane;
+            };
+            std::vector<Held> held;
+            ~ThreadLanes()
+            {
+                for (Held &h : held)
+                    if (auto p = h.pool.lock())
+                        p->give(h.lane);
+            }
+        };
+        thread_local ThreadLanes t_lanes;
+        // one-entry cache of the last lookup, keyed by the pool's serial number (never reused, unlike its address)
+        thread_local unsigned long long t_cur_pool_id = 0;
+        thread_local Lane *t_cur_lane = nullptr;
+        std::atomic<unsigned long long> g_pool_serial{ 0 };
+    } // namespace
+
+    unsigned long long next_pool_id()
+    {
+        return ++g_pool_serial;
+    }
+
+    Lane &Engine::lane() const
+    {
+        if (!lanes)
+            throw std::logic_error("host-only context: no device");
+        if (t_cur_pool_id == lanes->id)
+            return *t_cur_lane;
+        auto &held = t_lanes.held;
+        for (std::size_t i = 0; i < held.size();)
+        {
+            auto p = held[i].pool.lock();
+            if (!p)
+            {
+                held.erase(held.begin() + static_cast<std::ptrdiff_t>(i)); // the context is gone (and its lanes with it)
+                continue;
+            }
+            if (p.get() == lanes.get())
+            {
+                t_cur_pool_id = lanes->id;
+                t_cur_lane = held[i].lane;
+                return *t_cur_lane;
+            }
+            i++;
+        }
+        Lane *l = lanes->take();
+        held.push_back({ lanes, l });
+        t_cur_pool_id = lanes->id;
+        t_cur_lane = l;
+        return *l;
+    }
+
+    void Engine::sync_and_check(bool all_lanes) const
+    {
+        if (all_lanes)
+        {
+            std::vector<hipStream_t> streams;
+            {
+                std::lock_guard<std::mutex> lock(lanes->mu);
+                for (auto &l : lanes->all)
+                    if (!l->capturing)
+                        streams.push_back(l->stream);
+            }
+            for (hipStream_t s : streams)
+                SEALHIP_CHECK(hipStreamSynchronize(s));
+        }
+        else
+            SEALHIP_CHECK(hipStreamSynchronize(lane().stream));
+        if (h_fault && __atomic_load_n(h_fault, __ATOMIC_ACQUIRE))
+        {
+            __atomic_store_n(h_fault, 0u, __ATOMIC_RELEASE);
+            throw std::runtime_error("forward NTT: sibling workgroup wait timed out; results of that launch are invalid");
+        }
+    }
+
     unsigned *Engine::ntt_tickets(std::size_t nrows) const
     {
-        const std::size_t need = nrows + 1;
-        if (need > tickets_cap)
+        Lane &l = lane();
+        if (nrows > l.tickets_cap)
         {
-            if (capturing)
+            if (l.capturing)
                 return nullptr; // reported by the launcher; run the sequence once before capturing
-            if (d_tickets)
+            if (l.d_tickets)
             {
-                if (hipStreamSynchronize(stream) != hipSuccess || hipFree(d_tickets) != hipSuccess)
+                if (hipStreamSynchronize(l.stream) != hipSuccess || hipFree(l.d_tickets) != hipSuccess)
                     return nullptr;
-                d_tickets = nullptr;
-                tickets_cap = 0;
+                l.d_tickets = nullptr;
+                l.tickets_cap = 0;
             }
             std::size_t cap = 1;
-            while (cap < need)
+            while (cap < nrows)
                 cap <<= 1;
-            alloc_generation++;
-            if (hipMalloc(reinterpret_cast<void **>(&d_tickets), cap * sizeof(unsigned)) != hipSuccess)
+            l.alloc_generation++;
+            if (hipMalloc(reinterpret_cast<void **>(&l.d_tickets), cap * sizeof(unsigned)) != hipSuccess)
                 return nullptr;
-            tickets_cap = cap;
-            if (hipMemsetAsync(d_tickets, 0, sizeof(unsigned), stream) != hipSuccess) // sticky timeout flag
-                return nullptr;
+            l.tickets_cap = cap;
         }
-        if (hipMemsetAsync(d_tickets + 1, 0, nrows * sizeof(unsigned), stream) != hipSuccess)
+        if (hipMemsetAsync(l.d_tickets, 0, nrows * sizeof(unsigned), l.stream) != hipSuccess)
             return nullptr;
-        return d_tickets;
+        return l.d_tickets;
     }
 
     void Engine::prof_begin(const char *tag, double units) const
     {
+        Lane &l = lane();
         ProfRecord r{ tag, nullptr, nullptr, units };
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
             return;
-        (void)hipEventRecord(r.start, stream);
-        prof.push_back(r);
+        (void)hipEventRecord(r.start, l.stream);
+        l.prof.push_back(r);
     }
 
     void Engine::prof_end() const
     {
-        if (!prof.empty() && prof.back().stop)
-            (void)hipEventRecord(prof.back().stop, stream);
+        Lane &l = lane();
+        if (!l.prof.empty() && l.prof.back().stop)
+            (void)hipEventRecord(l.prof.back().stop, l.stream);
     }
 
     Engine::~Engine()
@@ -175,8 +313,14 @@ namespace sealhip
         if (device < 0)
             return;
         (void)hipSetDevice(device);
-        if (stream)
-            (void)hipStreamSynchronize(stream);
+        if (lanes)
+        {
+            // every lane drains its stream and frees its arena; threads that still hold one see an expired pool
+            std::lock_guard<std::mutex> lock(lanes->mu);
+            lanes->all.clear();
+            lanes->idle.clear();
+        }
+        lanes.reset();
         for (auto &kv : levels)
             for (void *p : kv.second->owned)
                 (void)hipFree(p);
@@ -194,12 +338,8 @@ namespace sealhip
             (void)hipFree(d_ckks_inv_roots);
         for (auto &kv : ckks_decode)
             (void)hipFree(kv.second);
-        if (ws)
-            (void)hipFree(ws);
-        if (d_tickets)
-            (void)hipFree(d_tickets);
-        if (own_stream && stream)
-            (void)hipStreamDestroy(stream);
+        if (h_fault)
+            (void)hipHostFree(h_fault);
     }
 
     LevelTools &Engine::level_host(int k)
@@ -259,6 +399,8 @@ namespace sealhip
         std::lock_guard<std::mutex> lock(mu);
         if (lt.d_rns)
             return lt;
+        if (lane().capturing) // the uploads below are synchronous copies: they would invalidate a relaxed capture
+            throw std::logic_error("the constants of this level are not built yet: run the sequence once before capturing");
         SEALHIP_CHECK(hipSetDevice(device));
         const HostRnsTool &hr = *lt.host_rns;
         RnsDev rd{};
@@ -501,6 +643,8 @@ namespace sealhip
         auto it = galois_tables.find(elt);
         if (it != galois_tables.end())
             return it->second;
+        if (lane().capturing)
+            throw std::logic_error("the Galois table of this element is not built yet: run the sequence once before capturing");
         // generate_table_ntt, galois.cpp:18-47
         std::vector<std::uint32_t> tab(n);
         const std::uint32_t nm1 = static_cast<std::uint32_t>(n) - 1;
@@ -669,32 +813,34 @@ namespace sealhip
         return dev;
     }
 
-    void Engine::ws_reserve(std::size_t bytes)
+    void Engine::ws_reserve(std::size_t bytes) const
     {
-        if (bytes <= ws_bytes)
+        Lane &l = lane();
+        if (bytes <= l.ws_bytes)
             return;
-        if (capturing)
+        if (l.capturing)
             throw std::logic_error("the workspace would grow during a graph capture: run the sequence once before capturing");
         SEALHIP_CHECK(hipSetDevice(device));
-        if (ws)
+        if (l.ws)
         {
-            SEALHIP_CHECK(hipStreamSynchronize(stream));
-            SEALHIP_CHECK(hipFree(ws));
-            ws = nullptr;
-            ws_bytes = 0;
+            SEALHIP_CHECK(hipStreamSynchronize(l.stream));
+            SEALHIP_CHECK(hipFree(l.ws));
+            l.ws = nullptr;
+            l.ws_bytes = 0;
         }
-        SEALHIP_CHECK(hipMalloc(&ws, bytes));
-        ws_bytes = bytes;
-        alloc_generation++;
+        SEALHIP_CHECK(hipMalloc(&l.ws, bytes));
+        l.ws_bytes = bytes;
+        l.alloc_generation++;
     }
 
-    u64 *Engine::ws_alloc(std::size_t words)
+    u64 *Engine::ws_alloc(std::size_t words) const
     {
+        Lane &l = lane();
         const std::size_t bytes = (words * sizeof(u64) + 255) & ~static_cast<std::size_t>(255);
-        if (ws_used + bytes > ws_bytes)
+        if (l.ws_used + bytes > l.ws_bytes)
             throw std::logic_error("internal: workspace overflow");
-        u64 *p = reinterpret_cast<u64 *>(static_cast<char *>(ws) + ws_used);
-        ws_used += bytes;
+        u64 *p = reinterpret_cast<u64 *>(static_cast<char *>(l.ws) + l.ws_used);
+        l.ws_used += bytes;
         return p;
     }
 

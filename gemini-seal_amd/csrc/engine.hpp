@@ -49,6 +49,7 @@ namespace sealhip
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
     constexpr int kNttAnyRep = 8;    // inverse: the consumer canonicalises, any representative below 2p may be stored
+    constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
 
     struct NttRound
@@ -168,6 +169,39 @@ namespace sealhip
         double units; // rows (NTT passes) or lanes processed by the launch
     };
 
+    // Per-host-thread execution state of a context: the reference's Evaluator is re-entrant
+    // (native/src/seal/evaluator.h:1375-1377: it holds only the context and an immutable map; temporaries come from the
+    // MemoryPoolHandle of the call), so every host thread that calls into a context gets its own lane -- HIP stream,
+    // temporaries arena, forward-NTT tickets, launch profiler, graph capture state -- and operations of different
+    // threads overlap instead of serialising. Tables, level constants and keys are shared and immutable.
+    struct Lane
+    {
+        int device = -1;
+        hipStream_t stream = nullptr;
+        bool own_stream = false;
+        unsigned long long alloc_generation = 0; // bumps when the arena or the ticket buffer is re-allocated
+        bool capturing = false; // between sealhip_graph_capture_begin / _end: no allocation, no synchronisation
+        bool prof_on = false;
+        std::vector<ProfRecord> prof;
+        unsigned *d_tickets = nullptr; // per-row tickets of the single-pass forward NTT
+        std::size_t tickets_cap = 0;
+        void *ws = nullptr; // workspace arena (stream-ordered reuse)
+        std::size_t ws_bytes = 0, ws_used = 0;
+        std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
+        std::recursive_mutex busy; // held for the duration of an operation (a graph may be launched from another thread)
+        ~Lane();
+    };
+    struct LanePool
+    {
+        std::mutex mu;
+        int device = -1;
+        unsigned long long id = 0; // serial number, unique per process
+        std::vector<std::unique_ptr<Lane>> all;
+        std::vector<Lane *> idle; // lanes whose thread has exited
+        Lane *take();
+        void give(Lane *lane);
+    };
+
     struct Engine
     {
         // parameters
@@ -181,10 +215,18 @@ namespace sealhip
         std::vector<u64> key_moduli, aux_primes;
         std::vector<HostNttTables> tables; // per prime id
         // device
-        hipStream_t stream = nullptr;
-        bool own_stream = false;
-        mutable unsigned long long alloc_generation = 0; // bumps when the arena or the ticket buffer is re-allocated
-        bool capturing = false; // between sealhip_graph_capture_begin / _end: no allocation, no synchronisation
+        std::shared_ptr<LanePool> lanes;
+        Lane &lane() const; // the calling thread's lane of this context (created on first use)
+        // Sticky failure flag of the device code (today: the forward NTT's sibling hand-off timing out), in host-mapped
+        // memory: kernels store to d_fault, every entry point that makes results host-visible reads h_fault after its
+        // stream synchronisation (sync_and_check) and fails with E_UNEXPECTED.
+        unsigned *h_fault = nullptr, *d_fault = nullptr;
+        void sync_and_check(bool all_lanes = false) const;
+        // debug hooks of the NTT hand-off (sealhip_debug_ntt_handoff): spin limit of the sibling wait and
+        // suppression of the "finished reading" signal, to drive the failure path in the tests
+        unsigned ntt_spin_limit = 1u << 24;
+        bool ntt_suppress_signal = false;
+        unsigned long long key_generation = 0; // bumps when a key-switch key is destroyed (graphs embed key pointers)
         PrimeDev *d_primes = nullptr;
         std::vector<void *> owned;
         std::map<int, std::unique_ptr<LevelTools>> levels;
@@ -203,20 +245,12 @@ namespace sealhip
         int plain_prime = -1;                  // prime id of the plain modulus when batching is possible (context.cpp:262-275)
         std::uint32_t *d_batch_map = nullptr;  // BatchEncoder::matrix_reps_index_map_ (batchencoder.cpp:70-94)
         const std::uint32_t *batch_map();
-        std::mutex mu;
-        std::recursive_mutex op_mu; // one operation at a time per context (they share the arena and the stream)
-        // profiler
-        mutable bool prof_on = false;
-        mutable std::vector<ProfRecord> prof;
+        mutable std::mutex mu; // lazily built shared tables (levels, Galois tables, encoder tables, parms_ids)
+        // profiler (per lane)
         void prof_begin(const char *tag, double units) const;
         void prof_end() const;
-        // per-row tickets of the single-pass forward NTT (word 0 = timeout flag, words 1.. = row counters)
-        mutable unsigned *d_tickets = nullptr;
-        mutable std::size_t tickets_cap = 0;
+        // per-row tickets of the single-pass forward NTT (zeroed for the launch, stream-ordered), lane-owned
         unsigned *ntt_tickets(std::size_t nrows) const;
-        // workspace arena (stream-ordered reuse)
-        void *ws = nullptr;
-        std::size_t ws_bytes = 0, ws_used = 0;
 
         ~Engine();
         int n_primes() const
@@ -226,13 +260,13 @@ namespace sealhip
         LevelTools &level(int k);       // builds host + device constants on first use
         LevelTools &level_host(int k);  // host constants only
         const std::uint32_t *galois_table(std::uint32_t elt);
-        std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
-        void ws_reset()
+        void ws_reset() const
         {
-            ws_used = ws_floor;
+            Lane &l = lane();
+            l.ws_used = l.ws_floor;
         }
-        u64 *ws_alloc(std::size_t words);
-        void ws_reserve(std::size_t bytes);
+        u64 *ws_alloc(std::size_t words) const;
+        void ws_reserve(std::size_t bytes) const;
         RowMap map_for(int k, unsigned base);
         int rows_for(int k, unsigned base);
     };
@@ -256,12 +290,12 @@ namespace sealhip
         const Engine &e;
         ProfScope(const Engine &eng, const char *tag, double units) : e(eng)
         {
-            if (e.prof_on)
+            if (e.lane().prof_on)
                 e.prof_begin(tag, units);
         }
         ~ProfScope()
         {
-            if (e.prof_on)
+            if (e.lane().prof_on)
                 e.prof_end();
         }
     };

@@ -396,7 +396,7 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         ProfScope prof(e, "ks_modup", 0);
-        ks_modup_kernel<<<blocks_for(count << e.logn), kThreads, 0, e.stream>>>(
+        ks_modup_kernel<<<blocks_for(count << e.logn), kThreads, 0, e.lane().stream>>>(
             d, e.d_primes, coeff, coeff_stride, ext, ext_stride, ext_digit_stride, count, e.logn, only_digit);
         return hipGetLastError();
     }
@@ -415,7 +415,7 @@ namespace sealhip
         const std::size_t glanes = (groups * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
 #define SEALHIP_KS_MAC(ND)                                                                                          \
     case ND:                                                                                                        \
-        ks_mac_items_kernel<ND><<<blocks_for(glanes), kThreads, 0, e.stream>>>(                                     \
+        ks_mac_items_kernel<ND><<<blocks_for(glanes), kThreads, 0, e.lane().stream>>>(                                     \
             d, e.d_primes, tg, target_stride, ext, ext_stride, ext_digit_stride, key, prod, prod_stride, count,    \
             e.logn);                                                                                                \
         break;
@@ -438,7 +438,7 @@ namespace sealhip
             SEALHIP_KS_MAC(15)
             SEALHIP_KS_MAC(16)
         default: // small batches or more than 16 digits: one lane per (ciphertext, row, coefficient)
-            ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
+            ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
                                                                         ext_digit_stride, key, prod, prod_stride, count,
                                                                         e.logn);
         }
@@ -452,7 +452,7 @@ namespace sealhip
         if (!npolys)
             return hipSuccess;
         ProfScope prof(e, "ks_moddown_pre", 0);
-        ks_moddown_pre_kernel<<<blocks_for(npolys << e.logn), kThreads, 0, e.stream>>>(
+        ks_moddown_pre_kernel<<<blocks_for(npolys << e.logn), kThreads, 0, e.lane().stream>>>(
             d, e.d_primes, prod, prod_stride, temp, temp_stride, npolys, e.logn);
         return hipGetLastError();
     }
@@ -466,10 +466,10 @@ namespace sealhip
         const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << (e.logn - 1); // one lane per coefficient pair
         ProfScope prof(e, "ks_moddown_bfv", 0);
         if (top_deferred)
-            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, prod, prod_stride, ct,
+            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, prod, prod_stride, ct,
                                                                                      ct_item_stride, npolys, e.logn);
         else
-            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.stream>>>(d, e.d_primes, prod, prod_stride, ct,
+            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, prod, prod_stride, ct,
                                                                                       ct_item_stride, npolys, e.logn);
         return hipGetLastError();
     }
@@ -482,7 +482,7 @@ namespace sealhip
             return hipSuccess;
         const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
         ProfScope prof(e, "ks_moddown_post", 0);
-        ks_moddown_post_kernel<<<blocks_for(lanes), kThreads, 0, e.stream>>>(
+        ks_moddown_post_kernel<<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
             d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct);
         return hipGetLastError();
     }

@@ -770,8 +770,8 @@ namespace sealhip
         template <int LOGN, bool STRICT, int REDUCE>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
-            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, NttSource src, std::size_t chunk,
-            LiveSlots live)
+            unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, unsigned spin_limit, NttSource src,
+            std::size_t chunk, LiveSlots live)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
@@ -841,7 +841,7 @@ namespace sealhip
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 1, 2>(x, lds, fresh(tid));
-            if (tid == 0 && tickets)
+            if (tid == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
@@ -869,10 +869,11 @@ namespace sealhip
                 while (__hip_atomic_load(&tickets[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
                 {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 24))
+                    if (++spins > spin_limit)
                     {
-                        // never observed; do not hang the device: flag the launch as failed and fall through
-                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // never observed outside the tests that force it; do not hang the device: flag the launch as
+                        // failed (host-mapped word, read by every host-visible synchronisation point) and fall through
+                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                 }
@@ -1226,10 +1227,10 @@ namespace sealhip
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
                 if (lazy)
-                    ntt_inv_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                    ntt_inv_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
                         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
                 else
-                    ntt_inv_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>(
+                    ntt_inv_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
                         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
@@ -1242,7 +1243,7 @@ namespace sealhip
             if (grid > 256u * 32u)
                 grid = 256u * 32u;
             ProfScope prof(e, "ntt_inv_top", transformed_rows(nrows, map));
-            ntt_inv_top_kernel<<<static_cast<unsigned>(grid), 256, 0, e.stream>>>(data, e.d_primes, map, LOGN, npairs,
+            ntt_inv_top_kernel<<<static_cast<unsigned>(grid), 256, 0, e.lane().stream>>>(data, e.d_primes, map, LOGN, npairs,
                                                                                flags);
             return hipGetLastError();
         }
@@ -1273,6 +1274,8 @@ namespace sealhip
             // SEALHIP_NTT_NO_TICKET=1 is a measurement-only switch (A/B of the hand-off cost); it re-opens the race
             static const bool no_ticket = std::getenv("SEALHIP_NTT_NO_TICKET") != nullptr;
             unsigned *tickets = no_ticket ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
+            if (e.ntt_suppress_signal)
+                flags |= kNttDebugNoSignal; // sealhip_debug_ntt_handoff: drive the time-out path
             if (!tickets && !no_ticket)
                 return hipErrorOutOfMemory;
 #ifdef SEALHIP_NTT_EXPERIMENT
@@ -1307,7 +1310,7 @@ namespace sealhip
                     }
                     (void)hipFree(trace);
                 }
-            } trace_dump{trace, trace_path, blocks, e.stream};
+            } trace_dump{trace, trace_path, blocks, e.lane().stream};
 #endif
             if (flags & kNttAnyRep)
             {
@@ -1322,8 +1325,8 @@ namespace sealhip
             }
             ProfScope prof(e, "ntt_fwd_half", transformed_rows(nrows, map));
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
-    ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.stream>>>( \
-        data, e.d_primes, map, nrows, flags, tickets ? tickets + 1 : nullptr, tickets, src, chunk, live)
+    ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
+        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, src, chunk, live)
             const int red = src.base[0] ? src.reduce_mode : 0;
             if (flags & kNttStrict)
             {
@@ -1450,7 +1453,7 @@ namespace sealhip
         {
             const int threads = 64;
             const unsigned blocks = static_cast<unsigned>((nrows + threads - 1) / threads);
-            ntt_serial_kernel<DIR><<<blocks, threads, 0, e.stream>>>(data, e.d_primes, map, plan.logn, plan.flags, nrows);
+            ntt_serial_kernel<DIR><<<blocks, threads, 0, e.lane().stream>>>(data, e.d_primes, map, plan.logn, plan.flags, nrows);
             return hipGetLastError();
         }
         for (int i = 0; i < plan.npass; i++)
@@ -1464,7 +1467,7 @@ namespace sealhip
             hipError_t err;
             {
                 ProfScope prof(e, DIR == 0 ? "ntt_fwd_pass" : "ntt_inv_pass", transformed_rows(nrows, map));
-                ntt_pass_kernel<DIR><<<static_cast<unsigned>(blocks), threads, lds_bytes, e.stream>>>(data, e.d_primes,
+                ntt_pass_kernel<DIR><<<static_cast<unsigned>(blocks), threads, lds_bytes, e.lane().stream>>>(data, e.d_primes,
                                                                                                       map, ps);
                 err = hipGetLastError();
             }

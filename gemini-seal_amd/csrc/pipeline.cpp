@@ -45,7 +45,7 @@ namespace sealhip
             const std::size_t budget = workspace_budget_bytes();
             std::size_t chunk = budget / (bytes_per_item ? bytes_per_item : 1);
             chunk = std::max<std::size_t>(1, std::min(chunk, count));
-            e.ws_reserve(e.ws_floor + chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
+            e.ws_reserve(e.lane().ws_floor + chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
             return chunk;
         }
 
@@ -464,10 +464,10 @@ namespace sealhip
             std::size_t saved;
             ~FloorGuard()
             {
-                e.ws_floor = saved;
+                e.lane().ws_floor = saved;
             }
-        } guard{ e, e.ws_floor };
-        e.ws_floor = guard.saved + scratch_bytes;
+        } guard{ e, e.lane().ws_floor };
+        e.lane().ws_floor = guard.saved + scratch_bytes;
         for (std::size_t off = 0; off < count; off += items)
         {
             const std::size_t m = std::min(items, count - off);
@@ -479,13 +479,13 @@ namespace sealhip
                 // while the scratch is live
                 const std::size_t ks_item = switch_key_item_bytes(e, k);
                 const std::size_t ks_chunk = std::max<std::size_t>(1, std::min(workspace_budget_bytes() / ks_item, m));
-                e.ws_reserve(e.ws_floor + ks_chunk * ks_item + 4 * 256);
+                e.ws_reserve(e.lane().ws_floor + ks_chunk * ks_item + 4 * 256);
             }
-            u64 *scratch = reinterpret_cast<u64 *>(static_cast<char *>(e.ws) + guard.saved);
+            u64 *scratch = reinterpret_cast<u64 *>(static_cast<char *>(e.lane().ws) + guard.saved);
             check(launch_galois(e, c, scratch, m * 2 * k, lt.map_q, elt, table), "galois");
             check(launch_copy_rows(e, scratch, 2 * poly, c, 2 * poly, m, k), "copy(c0)"); // :1903 / :1917
             SEALHIP_CHECK(hipMemset2DAsync(c + poly, 2 * poly * sizeof(u64), 0, poly * sizeof(u64), m,
-                                           e.stream)); // :1928
+                                           e.lane().stream)); // :1928
             op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
         }
     }
@@ -505,7 +505,7 @@ namespace sealhip
         const std::size_t N = e.n;
         const std::size_t nplains = plain_stride ? count : 1;
         const std::size_t bytes = nplains * k * N * sizeof(u64);
-        e.ws_reserve(e.ws_floor + bytes + 256);
+        e.ws_reserve(e.lane().ws_floor + bytes + 256);
         e.ws_reset();
         u64 *temp = e.ws_alloc(nplains * k * N);
         check(launch_plain_lift(e, plain, plain_stride, temp, nplains, map_q, e.t), "plain_lift");
@@ -759,13 +759,13 @@ namespace sealhip
             e.ws_reset();
             int *d_max = reinterpret_cast<int *>(e.ws_alloc(1));
             double *cv = reinterpret_cast<double *>(e.ws_alloc(2 * N * m));
-            SEALHIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), e.stream));
+            SEALHIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int), e.lane().stream));
             check(launch_ckks_encode_front(e, values + off * n_values * 2, n_values, m, n_inv, cv,
                                            plain + off * static_cast<std::size_t>(k) * N, k, e.d_ckks_map, e.d_ckks_inv_roots, d_max),
                   "ckks encode");
             int got = 0;
-            SEALHIP_CHECK(hipMemcpyAsync(&got, d_max, sizeof(int), hipMemcpyDeviceToHost, e.stream));
-            SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+            SEALHIP_CHECK(hipMemcpyAsync(&got, d_max, sizeof(int), hipMemcpyDeviceToHost, e.lane().stream));
+            SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream));
             h_max = std::max(h_max, got);
         }
         if (h_max >= total_bits)

@@ -343,22 +343,22 @@ namespace sealhip
         switch (op)
         {
         case PolyOp::Dyadic:
-            poly_op_kernel<0><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<0><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         case PolyOp::Add:
-            poly_op_kernel<1><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<1><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         case PolyOp::Sub:
-            poly_op_kernel<2><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<2><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         case PolyOp::Negate:
-            poly_op_kernel<3><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<3><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         case PolyOp::Scalar:
-            poly_op_kernel<4><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<4><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         case PolyOp::Mod63:
-            poly_op_kernel<5><<<grid, kThreads, 0, e.stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
+            poly_op_kernel<5><<<grid, kThreads, 0, e.lane().stream>>>(a, b, scalar, r, e.d_primes, map, e.logn, npairs);
             break;
         }
         return hipGetLastError();
@@ -372,7 +372,7 @@ namespace sealhip
         if (pairs * count == 0)
             return hipSuccess;
         ProfScope prof(e, "tensor_product", 0);
-        tensor_product_kernel<<<grid_for(pairs * count), kThreads, 0, e.stream>>>(
+        tensor_product_kernel<<<grid_for(pairs * count), kThreads, 0, e.lane().stream>>>(
             a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count);
         return hipGetLastError();
     }
@@ -384,7 +384,7 @@ namespace sealhip
         if (pairs * npolys == 0)
             return hipSuccess;
         ProfScope prof(e, "copy_rows", 0);
-        copy_rows_kernel<<<grid_for(pairs * npolys), kThreads, 0, e.stream>>>(src, src_poly_stride, dst,
+        copy_rows_kernel<<<grid_for(pairs * npolys), kThreads, 0, e.lane().stream>>>(src, src_poly_stride, dst,
                                                                              dst_poly_stride, pairs, npolys);
         return hipGetLastError();
     }
@@ -396,7 +396,7 @@ namespace sealhip
         if (total == 0)
             return hipSuccess;
         ProfScope prof(e, "galois", 0);
-        galois_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(in, out, e.d_primes, map, e.logn, total, elt, table);
+        galois_kernel<<<grid_for(total), kThreads, 0, e.lane().stream>>>(in, out, e.d_primes, map, e.logn, total, elt, table);
         return hipGetLastError();
     }
     hipError_t launch_ct_linear(const Engine &e, CtLinearOp op, const u64 *a, int sa, const u64 *b, int sb,
@@ -411,19 +411,19 @@ namespace sealhip
         switch (op)
         {
         case CtLinearOp::Add:
-            ct_linear_kernel<0><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+            ct_linear_kernel<0><<<grid, kThreads, 0, e.lane().stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
                                                                 pairs, count);
             break;
         case CtLinearOp::Sub:
-            ct_linear_kernel<1><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+            ct_linear_kernel<1><<<grid, kThreads, 0, e.lane().stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
                                                                 pairs, count);
             break;
         case CtLinearOp::Negate:
-            ct_linear_kernel<2><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+            ct_linear_kernel<2><<<grid, kThreads, 0, e.lane().stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
                                                                 pairs, count);
             break;
         case CtLinearOp::MulPlain:
-            ct_linear_kernel<3><<<grid, kThreads, 0, e.stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
+            ct_linear_kernel<3><<<grid, kThreads, 0, e.lane().stream>>>(a, sa, b, sb, b_item_stride, out, e.d_primes, map, e.logn,
                                                                 pairs, count);
             break;
         }
@@ -436,7 +436,7 @@ namespace sealhip
         if (item_words <= skip_words || count == 0)
             return hipSuccess;
         ProfScope prof(e, "nonzero_tail", 0);
-        nonzero_tail_kernel<<<grid_for((item_words - skip_words) / 2 * count), kThreads, 0, e.stream>>>(
+        nonzero_tail_kernel<<<grid_for((item_words - skip_words) / 2 * count), kThreads, 0, e.lane().stream>>>(
             ct, item_words, skip_words, count, flags);
         return hipGetLastError();
     }
@@ -447,7 +447,7 @@ namespace sealhip
         if (item_words == 0 || count == 0)
             return hipSuccess;
         ProfScope prof(e, "out_of_range", 0);
-        out_of_range_kernel<<<grid_for(item_words / 2 * count), kThreads, 0, e.stream>>>(ct, item_words, count, e.d_primes,
+        out_of_range_kernel<<<grid_for(item_words / 2 * count), kThreads, 0, e.lane().stream>>>(ct, item_words, count, e.d_primes,
                                                                                         map, e.logn, flags);
         return hipGetLastError();
     }
@@ -459,7 +459,7 @@ namespace sealhip
         if (total == 0)
             return hipSuccess;
         ProfScope prof(e, "plain_lift", 0);
-        plain_lift_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(plain, plain_stride, out, e.d_primes, map, e.logn, t,
+        plain_lift_kernel<<<grid_for(total), kThreads, 0, e.lane().stream>>>(plain, plain_stride, out, e.d_primes, map, e.logn, t,
                                                                     (t + 1) >> 1, nplains);
         return hipGetLastError();
     }
@@ -470,7 +470,7 @@ namespace sealhip
         if (pairs * count == 0)
             return hipSuccess;
         ProfScope prof(e, "dot_sk", 0);
-        dot_sk_kernel<<<grid_for(pairs * count), kThreads, 0, e.stream>>>(ct, size, ct_item_stride, sk_powers, sk_power_stride,
+        dot_sk_kernel<<<grid_for(pairs * count), kThreads, 0, e.lane().stream>>>(ct, size, ct_item_stride, sk_powers, sk_power_stride,
                                                                          out, e.d_primes, map, e.logn, pairs, count,
                                                                          add_c0);
         return hipGetLastError();

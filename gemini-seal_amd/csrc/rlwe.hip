@@ -160,16 +160,16 @@ namespace sealhip
         switch (stage)
         {
         case 0:
-            rlwe_stage_kernel<0><<<grid, kThreads, 0, e.stream>>>(a, e.d_primes, e.logn, total);
+            rlwe_stage_kernel<0><<<grid, kThreads, 0, e.lane().stream>>>(a, e.d_primes, e.logn, total);
             break;
         case 1:
-            rlwe_stage_kernel<1><<<grid, kThreads, 0, e.stream>>>(a, e.d_primes, e.logn, total);
+            rlwe_stage_kernel<1><<<grid, kThreads, 0, e.lane().stream>>>(a, e.d_primes, e.logn, total);
             break;
         case 2:
-            rlwe_stage_kernel<2><<<grid, kThreads, 0, e.stream>>>(a, e.d_primes, e.logn, total);
+            rlwe_stage_kernel<2><<<grid, kThreads, 0, e.lane().stream>>>(a, e.d_primes, e.logn, total);
             break;
         default:
-            rlwe_stage_kernel<3><<<grid, kThreads, 0, e.stream>>>(a, e.d_primes, e.logn, total);
+            rlwe_stage_kernel<3><<<grid, kThreads, 0, e.lane().stream>>>(a, e.d_primes, e.logn, total);
             break;
         }
         return hipGetLastError();
@@ -181,7 +181,7 @@ namespace sealhip
         if (!total)
             return hipSuccess;
         ProfScope prof(e, "scaling_variant", static_cast<double>(total));
-        scaling_variant_kernel<<<grid_for(total), kThreads, 0, e.stream>>>(a, e.d_primes, e.logn, total);
+        scaling_variant_kernel<<<grid_for(total), kThreads, 0, e.lane().stream>>>(a, e.d_primes, e.logn, total);
         return hipGetLastError();
     }
 
@@ -193,10 +193,10 @@ namespace sealhip
             return hipSuccess;
         ProfScope prof(e, "batch_permute", static_cast<double>(total));
         if (encode)
-            batch_permute_kernel<true><<<grid_for(total), kThreads, 0, e.stream>>>(in, out, map, e.logn, in_item_stride,
+            batch_permute_kernel<true><<<grid_for(total), kThreads, 0, e.lane().stream>>>(in, out, map, e.logn, in_item_stride,
                                                                                   nvalues, total);
         else
-            batch_permute_kernel<false><<<grid_for(total), kThreads, 0, e.stream>>>(in, out, map, e.logn, in_item_stride,
+            batch_permute_kernel<false><<<grid_for(total), kThreads, 0, e.lane().stream>>>(in, out, map, e.logn, in_item_stride,
                                                                                    nvalues, total);
         return hipGetLastError();
     }

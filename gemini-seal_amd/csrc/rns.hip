@@ -694,15 +694,15 @@ namespace sealhip
     do                                                                                    \
     {                                                                                     \
         if ((kval) <= 4)                                                                  \
-            KERNEL<4><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                      \
+            KERNEL<4><<<grid, kThreads, 0, e.lane().stream>>>(__VA_ARGS__);                      \
         else if ((kval) <= 8)                                                             \
-            KERNEL<8><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                      \
+            KERNEL<8><<<grid, kThreads, 0, e.lane().stream>>>(__VA_ARGS__);                      \
         else if ((kval) <= 16)                                                            \
-            KERNEL<16><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+            KERNEL<16><<<grid, kThreads, 0, e.lane().stream>>>(__VA_ARGS__);                     \
         else if ((kval) <= 32)                                                            \
-            KERNEL<32><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+            KERNEL<32><<<grid, kThreads, 0, e.lane().stream>>>(__VA_ARGS__);                     \
         else                                                                              \
-            KERNEL<64><<<grid, kThreads, 0, e.stream>>>(__VA_ARGS__);                     \
+            KERNEL<64><<<grid, kThreads, 0, e.lane().stream>>>(__VA_ARGS__);                     \
     } while (0)
 
     hipError_t launch_fastbconv_m_tilde(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
@@ -722,7 +722,7 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         ProfScope prof(e, "sm_mrq", 0);
-        sm_mrq_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,
+        sm_mrq_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,
                                                                             out_stride, count, e.logn);
         return hipGetLastError();
     }
@@ -736,7 +736,7 @@ namespace sealhip
         ProfScope prof(e, "bfv_lift", 0);
         if (h.k <= 32 && !e.unfused_rns)
         {
-#define SEALHIP_LIFT2(KM) bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn)
+#define SEALHIP_LIFT2(KM) bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn)
             switch (h.k)
             {
             case 1: SEALHIP_LIFT2(-1); break;
@@ -801,10 +801,10 @@ namespace sealhip
     do                                                                                                               \
     {                                                                                                                \
         if (deferred_top)                                                                                            \
-            bfv_floor_sk2_kernel<KM, true><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,       \
+            bfv_floor_sk2_kernel<KM, true><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,       \
                                                                            out_stride, count, e.logn);              \
         else                                                                                                         \
-            bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,      \
+            bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,      \
                                                                             out_stride, count, e.logn);             \
     } while (0)
             switch (h.k)
@@ -843,7 +843,7 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         ProfScope prof(e, "divround_bfv", 0);
-        divround_bfv_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, in, in_stride, out,
+        divround_bfv_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,
                                                                                   out_stride, count, e.logn, out_rows);
         return hipGetLastError();
     }
@@ -854,7 +854,7 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         ProfScope prof(e, "rescale_pre", 0);
-        rescale_pre_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(d, e.d_primes, last, last_stride,
+        rescale_pre_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.lane().stream>>>(d, e.d_primes, last, last_stride,
                                                                                  temp, temp_stride, count, e.logn);
         return hipGetLastError();
     }
@@ -866,7 +866,7 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         ProfScope prof(e, "rescale_post", 0);
-        rescale_post_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.stream>>>(
+        rescale_post_kernel<<<blocks_for(count, e.logn), kThreads, 0, e.lane().stream>>>(
             d, e.d_primes, in, in_stride, temp, temp_stride, out, out_stride, count, e.logn);
         return hipGetLastError();
     }
@@ -877,7 +877,7 @@ namespace sealhip
             return hipSuccess;
         ProfScope prof(e, "decrypt_scale_and_round", 0);
         const std::size_t lanes = count << e.logn;
-        decrypt_scale_and_round_kernel<<<static_cast<unsigned>((lanes + kThreads - 1) / kThreads), kThreads, 0, e.stream>>>(
+        decrypt_scale_and_round_kernel<<<static_cast<unsigned>((lanes + kThreads - 1) / kThreads), kThreads, 0, e.lane().stream>>>(
             d, e.d_primes, in, out, count, e.logn);
         return hipGetLastError();
     }

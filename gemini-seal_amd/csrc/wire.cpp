@@ -114,9 +114,12 @@ namespace sealhip
         int level_of(const Engine &e, const sealhip_ciphertext_info &ci)
         {
             int k = -1;
-            for (const auto &kv : e.parms_ids)
-                if (std::memcmp(kv.second.data(), ci.parms_id, 32) == 0)
-                    k = kv.first;
+            {
+                std::lock_guard<std::mutex> lock(e.mu); // wire_set_parms_id may run on another thread
+                for (const auto &kv : e.parms_ids)
+                    if (std::memcmp(kv.second.data(), ci.parms_id, 32) == 0)
+                        k = kv.first;
+            }
             if (k < 0)
                 throw std::logic_error("ciphertext data is invalid"); // no ContextData for the parms_id (:76-80)
             if (static_cast<int>(ci.coeff_modulus_size) != k || ci.poly_modulus_degree != e.n)
@@ -160,8 +163,8 @@ namespace sealhip
         if (total > capacity_words)
             throw std::invalid_argument("destination buffer is too small");
         if (total)
-            SEALHIP_CHECK(hipMemcpyAsync(dst, ps.words, total * 8, hipMemcpyHostToDevice, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream)); // the caller's buffer may go away after the call
+            SEALHIP_CHECK(hipMemcpyAsync(dst, ps.words, total * 8, hipMemcpyHostToDevice, e.lane().stream));
+        SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream)); // the caller's buffer may go away after the call
     }
 
     std::size_t wire_save_size(std::uint32_t size, std::uint32_t k, std::size_t n)
@@ -198,9 +201,12 @@ namespace sealhip
         std::memcpy(p, &count, 8);
         p += 8;
         if (words)
-            SEALHIP_CHECK(hipMemcpyAsync(p, src, words * 8, hipMemcpyDeviceToHost, e.stream));
-        SEALHIP_CHECK(hipStreamSynchronize(e.stream));
-        if (ci.size == 2 && words && reinterpret_cast<const std::uint64_t *>(p)[static_cast<std::size_t>(k) * e.n] == kSeedMarker)
+            SEALHIP_CHECK(hipMemcpyAsync(p, src, words * 8, hipMemcpyDeviceToHost, e.lane().stream));
+        e.sync_and_check(); // the words become host-visible here: a failed launch must not be saved with S_OK
+        std::uint64_t first_c1 = 0;
+        if (ci.size == 2 && words)
+            std::memcpy(&first_c1, p + static_cast<std::size_t>(k) * e.n * 8, 8); // (the stream is not 8-byte aligned)
+        if (ci.size == 2 && words && first_c1 == kSeedMarker)
         {
             // a ciphertext whose c_1 starts with the seed marker would be written in the seeded form by the reference
             // (ciphertext.cpp:189-208); evaluated ciphertexts never carry it
@@ -226,9 +232,12 @@ namespace sealhip
         std::memcpy(&dim1, p + 32, 8);
         p += 40;
         *dim1_out = dim1;
-        const auto key_id = e.parms_ids.find(e.n_key);
-        if (key_id == e.parms_ids.end() || std::memcmp(key_id->second.data(), pid, 32) != 0)
-            throw std::logic_error("kswitch_keys is not valid for encryption parameters"); // is_metadata_valid_for, valcheck.cpp
+        {
+            std::lock_guard<std::mutex> lock(e.mu);
+            const auto key_id = e.parms_ids.find(e.n_key);
+            if (key_id == e.parms_ids.end() || std::memcmp(key_id->second.data(), pid, 32) != 0)
+                throw std::logic_error("kswitch_keys is not valid for encryption parameters"); // is_metadata_valid_for, valcheck.cpp
+        }
         if (index >= dim1)
             throw std::invalid_argument("key index out of range");
         const std::size_t digit_words = static_cast<std::size_t>(2) * e.n_key * e.n;
@@ -242,18 +251,32 @@ namespace sealhip
             p += 8;
             if (dim2 > 64)
                 throw std::logic_error("kswitch_keys is not valid for encryption parameters");
-            u64 *dev = nullptr;
+            // owns the device buffer until the key is handed over: any failure (also of the final synchronisation)
+            // drains the stream and frees it
+            struct DevGuard
+            {
+                u64 *dev = nullptr;
+                hipStream_t stream;
+                ~DevGuard()
+                {
+                    if (dev)
+                    {
+                        (void)hipStreamSynchronize(stream);
+                        (void)hipFree(dev);
+                    }
+                }
+            } guard{ nullptr, e.lane().stream };
             if (i == index)
             {
                 if (dim2 == 0)
                     return 0;
                 if (dim2 > max_digits)
                     throw std::logic_error("kswitch_keys is not valid for encryption parameters");
-                SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), dim2 * digit_words * sizeof(u64)));
+                SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&guard.dev), dim2 * digit_words * sizeof(u64)));
             }
+            u64 *const dev = guard.dev;
             for (std::uint64_t j = 0; j < dim2; j++)
             {
-                try
                 {
                     const Parsed ps = parse(p, static_cast<std::size_t>(end - p));
                     if (i == index)
@@ -267,23 +290,15 @@ namespace sealhip
                         if (ps.info.data_words != digit_words)
                             throw std::logic_error("kswitch_keys is not valid for encryption parameters");
                         SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words, ps.words, digit_words * sizeof(u64),
-                                                     hipMemcpyHostToDevice, e.stream));
+                                                     hipMemcpyHostToDevice, e.lane().stream));
                     }
                     p += ps.info.total_bytes;
-                }
-                catch (...)
-                {
-                    if (dev)
-                    {
-                        (void)hipStreamSynchronize(e.stream);
-                        (void)hipFree(dev);
-                    }
-                    throw;
                 }
             }
             if (i == index)
             {
-                SEALHIP_CHECK(hipStreamSynchronize(e.stream));
+                SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream));
+                guard.dev = nullptr; // handed over
                 *d_out = dev;
                 *words_out = dim2 * digit_words;
                 return static_cast<std::uint32_t>(dim2);

@@ -60,7 +60,9 @@ SYMBOLS = {
     "sealhip_context_first_level": [_vp, C.POINTER(_u32)],
     "sealhip_context_bsk_size": [_vp, _u32, C.POINTER(_u32)],
     "sealhip_set_stream": [_vp, _vp],
+    "sealhip_use_default_stream": [_vp],
     "sealhip_synchronize": [_vp],
+    "sealhip_debug_ntt_handoff": [_vp, _u32, _i32],
     "sealhip_malloc": [_vp, _sz, C.POINTER(_vp)],
     "sealhip_free": [_vp, _vp],
     "sealhip_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -322,7 +324,14 @@ class Context:
         _check(lib().sealhip_synchronize(self.handle))
 
     def set_stream(self, stream_ptr):
+        """hipStream_t of the calling thread's lane (None/0: back to a private stream)"""
         _check(lib().sealhip_set_stream(self.handle, stream_ptr))
+
+    def use_default_stream(self):
+        _check(lib().sealhip_use_default_stream(self.handle))
+
+    def debug_ntt_handoff(self, spin_limit=0, suppress_signal=False):
+        _check(lib().sealhip_debug_ntt_handoff(self.handle, spin_limit, 1 if suppress_signal else 0))
 
     def bsk_size(self, k):
         v = C.c_uint32()

@@ -11,8 +11,17 @@
  *     data + (j*k + i)*N   (native/src/seal/ciphertext.h:359-368, util/iterator.h:746-766);
  *   - a *batch* is `count` such objects stored back to back (the data-parallel axis);
  *   - unless a function name ends in `_host`, every data pointer is a DEVICE pointer (hipMalloc'd,
- *     or a torch CUDA tensor's data_ptr()); work is enqueued on the context's stream and is
- *     asynchronous until sealhip_synchronize();
+ *     or a torch CUDA tensor's data_ptr()); work is enqueued on a HIP stream and is asynchronous
+ *     until sealhip_synchronize();
+ *   - threading: like seal::Evaluator (native/src/seal/evaluator.h:1375-1377) a context is re-entrant.
+ *     Every host thread that calls into a context works on its own LANE (HIP stream + temporaries
+ *     arena), so operations issued by different threads overlap on the device; operations issued by
+ *     one thread run in order. Work of different threads is NOT ordered against each other: hand a
+ *     buffer from one thread to another only after sealhip_synchronize() (which waits for every lane);
+ *   - a device-side failure (the forward NTT's bounded hand-off wait timing out) is sticky: the next
+ *     entry point that makes results host-visible (sealhip_synchronize, sealhip_memcpy_d2h,
+ *     sealhip_ciphertext_save, sealhip_is_transparent, sealhip_is_data_valid_for,
+ *     sealhip_profile_fetch, the *_host batch entries) returns SEALHIP_E_UNEXPECTED;
  *   - a ciphertext level is addressed by `k` = number of leading coefficient-modulus primes
  *     (the chain drops the last prime per level: native/src/seal/context.cpp:423-431).
  *
@@ -75,7 +84,12 @@ long sealhip_context_create(const sealhip_params *params, sealhip_context **out)
 long sealhip_context_destroy(sealhip_context *ctx);
 long sealhip_context_first_level(const sealhip_context *ctx, uint32_t *k_first); /* = n_key - nsp */
 long sealhip_context_bsk_size(sealhip_context *ctx, uint32_t k, uint32_t *bsk_size); /* |Bsk| of level k */
-long sealhip_set_stream(sealhip_context *ctx, void *hip_stream); /* NULL = the context's own stream */
+/* Stream of the CALLING THREAD's lane: a caller-owned hipStream_t (e.g. torch.cuda.Stream().cuda_stream), or NULL to go
+   back to a private non-blocking stream. The legacy default stream cannot be named by its handle (it is NULL too): use
+   sealhip_use_default_stream for it. */
+long sealhip_set_stream(sealhip_context *ctx, void *hip_stream);
+long sealhip_use_default_stream(sealhip_context *ctx);
+/* waits for the work of every lane of the context (all host threads) and reports a pending device-side failure */
 long sealhip_synchronize(sealhip_context *ctx);
 
 /* device memory helpers for hosts that do not bring their own allocator */
@@ -90,6 +104,11 @@ long sealhip_memcpy_d2h(sealhip_context *ctx, void *dst_host, const void *src_de
    and clears the records. `units` counts RNS rows for the NTT passes (0 for other kernels). */
 long sealhip_profile_enable(sealhip_context *ctx, int32_t enable);
 long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity);
+
+/* Test hook of the forward NTT's sibling hand-off (csrc/ntt.hip): spin_limit = polls before a waiting wave gives up
+   (0 restores the default 2^24), suppress_signal != 0 withholds the "finished reading" signal so that every wait times
+   out. Used by the tests to prove that the failure surfaces at every host-visible synchronisation point. */
+long sealhip_debug_ntt_handoff(sealhip_context *ctx, uint32_t spin_limit, int32_t suppress_signal);
 
 /* Introspection of the precomputed tables (works on host-only contexts; used by the CPU tests).
    kind: 0 root_powers, 1 scaled_root_powers, 2 inv_root_powers (reference order, n^-1 merged),
@@ -243,7 +262,10 @@ long sealhip_decrypt_scale_and_round(sealhip_context *ctx, uint32_t k, const uin
    a fixed sequence of operations on fixed device buffers can be captured once from the context's stream and replayed as
    one hipGraph launch. Run the sequence once before capturing (tables, the arena and the NTT tickets are allocated on
    first use; allocation and synchronisation are not capturable); entry points that synchronise (is_transparent,
-   ckks_encode, the wire format) cannot be captured. */
+   ckks_encode, the wire format) cannot be captured. An operation that fails during a capture aborts and discards the
+   capture (the error message says so). A graph replays on the lane (thread) it was captured on, whichever thread
+   launches it; it goes stale -- launch fails with COR_E_INVALIDOPERATION -- when that lane's workspace is re-allocated
+   or any key-switch key of the context is destroyed. Operand buffers are the caller's: they must outlive the graph. */
 typedef struct sealhip_graph sealhip_graph;
 long sealhip_graph_capture_begin(sealhip_context *ctx);
 long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph);

@@ -26,7 +26,13 @@ def main():
     tmax = bench.max_over_ranks(t.item())
     assert tmax == float(world)
     digests = bench.gather_digests(0x1000 + rank)
+    assert bench.all_ranks_true(True) and not bench.all_ranks_true(rank == 0)
+    # the final gather: every rank's slice lands on rank 0 and is checked there against the rank's own digest
+    payload = torch.arange(rank * 1000, rank * 1000 + 96, dtype=torch.int64).reshape(3, 2, 4, 4)
+    g = bench.gather_payload(payload, bench.cheap_digest)
+    assert g["bytes_per_rank"] == 96 * 8 and g["backend"] == "gloo"
     if rank == 0:
+        assert g["ranks_seen"] == world
         assert digests == [0x1000 + r for r in range(world)]
         print("SHARD_OK")
     dist.barrier()

@@ -108,7 +108,9 @@ def lib():
         return _LIB
     path = os.path.join(ORACLE_DIR, "libsealref.so")
     src = os.path.join(ORACLE_DIR, "sealref.c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    if os.environ.get("SEALREF_LIBRARY"):  # another build of the same source (bench.py: -march=native for its host)
+        path = os.environ["SEALREF_LIBRARY"]
+    elif not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         build()
     L = C.CDLL(path)
     L.ref_splitmix64.restype = u64

@@ -1519,6 +1519,162 @@ def test_full_size_batched_pipeline_semantics_cfg3(sealhip):
     assert np.array_equal(decrypt_decode(cb, 2, k), (va * vb) % t)
 
 
+# ---------------------------------------------------------------- the launch shapes bench.py is timed on
+def _bench_shape_batch(row, count, n_random, seed):
+    """`count` ciphertext pairs of a BASELINE config: the survey's golden input interleaved with `n_random` distinct
+    random pairs (positions spread over the batch, first and last included), so that wrong item / chunk offsets cannot
+    cancel out."""
+    inp = synth.end_to_end_inputs(row)
+    k, n = inp["k"], inp["n"]
+    rng = np.random.default_rng(seed)
+    a = np.stack([inp["a"]] * count)
+    b = np.stack([inp["b"]] * count)
+    where = sorted({int(x) for x in np.linspace(0, count - 1, n_random)})
+    for i in where:
+        a[i] = rand_rows(rng, inp["kmods"][:k] * 2, n).reshape(2, k, n)
+        b[i] = rand_rows(rng, inp["kmods"][:k] * 2, n).reshape(2, k, n)
+    return inp, a, b, where
+
+
+@pytest.mark.parametrize("count", [33])
+def test_cfg3_bench_launch_shapes_vs_golden_and_oracle(sealhip, count):
+    """BASELINE config 3 (what bench.py times) at a batch that takes the same kernels as the bench: count >= 16 selects
+    ks_mac_items_kernel<7> at N = 2^15 (key words kept in registers across eight ciphertexts; 33 leaves a ragged last
+    group), the single-pass NTT kernels see multi-polynomial launches, and -- when SEALHIP_WORKSPACE_MB shrinks the arena
+    (test_bench_shapes_with_a_small_arena re-runs this test so) -- the batch spans many arena chunks. Golden items must
+    reproduce the compiled reference's digests, random items the oracle's words."""
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == 3][0]
+    inp, a, b, where = _bench_shape_batch(row, count, 5, 33)
+    n, k = inp["n"], inp["k"]
+    ctx = sealhip.Context(row["scheme"], inp["logn"], inp["kmods"], row["nsp"], row["t"])
+    ev = sealhip.Evaluator(ctx)
+    rk = sealhip.KSwitchKeys(ctx, inp["rk"])
+    out = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, out)
+    mul = out.download((count, 3, k, n)).copy()
+    ev.relinearize_inplace(out, 3, k, count, [rk])
+    relin = out.download((count, 3, k, n))
+    ref = O.RefContext(1, inp["logn"], inp["kmods"], nsp=row["nsp"], t=row["t"])
+    keys = (C.c_void_p * 1)(inp["rk"].ctypes.data)
+    for i in range(count):
+        if i in where:
+            exp = np.zeros((3, k, n), dtype=np.uint64)
+            assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(exp)) == 0
+            assert np.array_equal(mul[i], exp), i
+            assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp), 3, keys) == 0
+            assert np.array_equal(relin[i], exp), i
+        else:
+            assert h(mul[i]) == row["digests"]["mul"], i
+            assert h(np.ascontiguousarray(relin[i, :2])) == row["digests"]["relin"], i
+
+
+def test_cfg4_rotate_large_batch_vs_golden_and_oracle(sealhip):
+    """BASELINE config 4 (CKKS N = 2^15, 12 primes, 11 digits): rotate_vector over 32 ciphertexts -- the batched Galois
+    gather, ks_mac_items_kernel<11>, the special-row inverse and the CKKS mod-down at the shape the scaling runs use."""
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == 4][0]
+    count = 32
+    inp, a, _, where = _bench_shape_batch(row, count, 4, 44)
+    n, k = inp["n"], inp["k"]
+    ctx = sealhip.Context(row["scheme"], inp["logn"], inp["kmods"], row["nsp"], row["t"])
+    ev = sealhip.Evaluator(ctx)
+    gk = sealhip.KSwitchKeys(ctx, inp["gk"])
+    elt = ctx.galois_elt_from_step(1)
+    c = ctx.upload(a)
+    ev.rotate_vector_inplace(c, k, count, 1, {elt: gk})
+    got = c.download((count, 2, k, n))
+    ref = O.RefContext(2, inp["logn"], inp["kmods"], nsp=row["nsp"], t=0)
+    for i in range(count):
+        if i in where:
+            exp = a[i].copy()
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(exp), elt, O.ptr(inp["gk"])) == 0
+            assert np.array_equal(got[i], exp), i
+        else:
+            assert h(got[i]) == row["digests"]["rotate"], i
+
+
+def test_bench_shapes_with_a_small_arena():
+    """SEALHIP_WORKSPACE_MB is read once per process: a child process with a 64 MB arena runs the two tests above with
+    a smaller batch, so that every operation walks its batch in chunks of two or three ciphertexts (config 3 needs 27 MB
+    of temporaries per pair in multiply and 22.5 MB per ciphertext in the key switch): the chunk-offset arithmetic of
+    csrc/pipeline.cpp against the golden digests and the oracle."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SEALHIP_WORKSPACE_MB="64", SEALHIP_TEST_SMALL_ARENA_COUNT="7")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "small_arena_child"],
+                       env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode("utf-8", "replace")[-600:]
+    assert r.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.skipif("SEALHIP_TEST_SMALL_ARENA_COUNT" not in os.environ, reason="child of test_bench_shapes_with_a_small_arena")
+def test_small_arena_child(sealhip):
+    assert os.environ.get("SEALHIP_WORKSPACE_MB") == "64"
+    count = int(os.environ["SEALHIP_TEST_SMALL_ARENA_COUNT"])
+    test_cfg3_bench_launch_shapes_vs_golden_and_oracle(sealhip, count)
+    # cfg4 rotate at 7 ciphertexts: Galois scratch at the arena front + chunked key switch behind it
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == 4][0]
+    inp = synth.end_to_end_inputs(row)
+    n, k = inp["n"], inp["k"]
+    ctx = sealhip.Context(row["scheme"], inp["logn"], inp["kmods"], row["nsp"], row["t"])
+    ev = sealhip.Evaluator(ctx)
+    gk = sealhip.KSwitchKeys(ctx, inp["gk"])
+    c = ctx.upload(np.stack([inp["a"]] * count))
+    ev.rotate_vector_inplace(c, k, count, 1, {ctx.galois_elt_from_step(1): gk})
+    got = c.download((count, 2, k, n))
+    for i in range(count):
+        assert h(got[i]) == row["digests"]["rotate"], i
+
+
+def test_ntt_handoff_failure_surfaces_at_every_host_visible_point(sealhip):
+    """The forward NTT's sibling hand-off has a bounded wait; when it times out the launch's rows are invalid and a
+    sticky flag is raised. sealhip_debug_ntt_handoff withholds the hand-off signal and cuts the wait to one poll, which
+    drives exactly that path: every entry point that makes results host-visible must then fail (E_UNEXPECTED ->
+    RuntimeError) instead of returning the rows with S_OK, once per failure, and the engine must work again afterwards."""
+    logn, n = 15, 1 << 15
+    kmods = O.coeff_modulus_create(n, [55] * 3)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433)
+    k = 2
+    rng = np.random.default_rng(7)
+    x = rand_rows(rng, kmods[:k] * 2, n).reshape(2, k, n)
+    ctx.set_parms_id(k, (1, 2, 3, 4))
+    info = sealhip.CiphertextInfo()
+    info.parms_id[:] = (1, 2, 3, 4)
+    info.size, info.coeff_modulus_size, info.poly_modulus_degree, info.scale = 2, k, n, 1.0
+
+    def fail_once(fn):
+        d = ctx.upload(x)
+        ctx.debug_ntt_handoff(spin_limit=1, suppress_signal=True)
+        try:
+            ctx.ntt_negacyclic_harvey_lazy(d, 2, k)  # every wave's wait gives up after one poll
+            with pytest.raises(RuntimeError, match="sibling workgroup wait timed out"):
+                fn(d)
+        finally:
+            ctx.debug_ntt_handoff(0, False)
+        return d
+
+    out = np.empty(x.size, dtype=np.uint64)
+    L_ = sealhip.lib()
+    fail_once(lambda d: ctx.synchronize())
+    fail_once(lambda d: sealhip._check(L_.sealhip_memcpy_d2h(ctx.handle, out.ctypes.data, d.ptr, out.size * 8)))
+    fail_once(lambda d: ctx.save_ciphertext(info, d))
+    fail_once(lambda d: ctx.is_data_valid_for(d, 2, k, 1))
+    fail_once(lambda d: ctx.is_transparent(d, 2, k, 1))
+    fail_once(lambda d: ctx.profile_fetch())
+    ctx.synchronize()  # the flag was consumed by the failing call: nothing is pending
+    # and the engine is intact: the same transform, hand-off restored, is bit-exact again
+    d = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey_lazy(d, 2, k)
+    got = d.download(x.shape)
+    tabs = [O.Tables(logn, p) for p in kmods[:k]]
+    for j in range(2):
+        for i in range(k):
+            e = x[j, i].copy()
+            L.ref_ntt_forward_lazy(O.ptr(e), C.byref(tabs[i].t), 0)
+            assert np.array_equal(got[j, i], e)
+
+
 def test_exact_ntt_variants_still_match_the_golden_digests():
     """The lazy-sum inverse and the last-layer shortcut of the forward transform are switched off with
     SEALHIP_NTT_EXACT_INV / SEALHIP_NTT_EXACT_FWD (read once per process, hence the child process): the exact kernels

@@ -133,6 +133,35 @@ def test_multi_rank_sharding_plan_gloo():
     assert "SHARD_OK" in out.stdout
 
 
+def test_bench_spawns_its_own_ranks_and_gathers_gloo():
+    """`python bench.py --gpus 2` with no launcher around it must start its two ranks itself (a child
+    torch.distributed.run, never an exec), run the per-rank setup (rank-dependent ciphertext seed, replicated key,
+    contiguous shard of the global batch), the barrier / max-over-ranks timing and the final payload gather to rank 0,
+    and relay ONE JSON line. The stub workload stands in for the engine (no GPU here); backend gloo."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "2",
+                          "--warmup", "1", "--batch", "6", "--gather-cts", "4"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["stub"] is True and line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 12 and line["config"]["ciphertexts_per_gpu"] == 6
+    assert line["rccl_ranks_seen"] == 2 and line["gather"]["ranks_seen"] == 2  # both slices arrived intact at rank 0
+    assert line["gather"]["bytes_per_rank"] == 4 * 2 * 2 * 64 * 8
+    assert line["key_replicated"] is True
+    assert len(set(line["rank_digests"])) == 2  # every rank worked on its own ciphertexts
+    # a launcher that started a different number of ranks is an error message, not an assert
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--stub"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode != 0 and "does not match" in bad.stderr
+
+
 def _build_adapter(tmp_path):
     import subprocess
 

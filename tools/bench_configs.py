@@ -55,7 +55,7 @@ def main():
     if want("cfg2"):
         logn, n = 14, 1 << 14
         ctx = S.Context(S.SCHEME_CKKS, logn, P14, 1, 0)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         P = 1024
         x = mk(ctx, (P, 6, n), P14, dev)  # key-level polynomials: 6 rows each (1024 x 6 = 6144 rows)
         # BASE_KEY at level k=5 = 5 ciphertext primes + 1 special prime = all 6 key primes
@@ -69,7 +69,7 @@ def main():
     if want("cfg1"):
         logn, n = 12, 1 << 12
         ctx = S.Context(S.SCHEME_BFV, logn, P12, 1, 786433)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 4096, 2
         x, y = mk(ctx, (B, 2, k, n), P12[:k], dev), mk(ctx, (B, 2, k, n), P12[:k], dev)
@@ -85,7 +85,7 @@ def main():
     if want("cfg4"):
         logn, n = 15, 1 << 15
         ctx = S.Context(S.SCHEME_CKKS, logn, P15_12, 1, 0)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 1024, 11  # 8192 ciphertexts / 8 GPUs
         c = mk(ctx, (B, 2, k, n), P15_12[:k], dev)
@@ -107,7 +107,7 @@ def main():
     if want("cfg5"):
         logn, n = 16, 1 << 16
         ctx = S.Context(S.SCHEME_BFV, logn, P16, 1, 786433)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 256, 15
         x, y = mk(ctx, (B, 2, k, n), P16[:k], dev), mk(ctx, (B, 2, k, n), P16[:k], dev)
@@ -129,7 +129,7 @@ def main():
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
         ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 1024, 7
         x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
@@ -155,7 +155,7 @@ def main():
         logn, n, t = 15, 1 << 15, 786433
         pr = bench.CFG3_PRIMES
         ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, t)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 1024, 7
         a_ntt = mk(ctx, (B, k, n), pr[:k], dev)
@@ -190,7 +190,7 @@ def main():
         dt_save = (time.perf_counter() - t0) / 20
         # CKKSEncoder at cfg4 size (N=2^15, k=11): 256 plaintexts of N/2 complex slots
         cctx = S.Context(S.SCHEME_CKKS, 15, P15_12, 1, 0)
-        cctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        cctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         CB, ck = 256, 11
         cv = torch.randn((CB, n // 2, 2), dtype=torch.float64, device=dev) * 1000.0
         cpl = torch.empty((CB, ck, n), dtype=torch.int64, device=dev)
@@ -219,7 +219,7 @@ def main():
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
         ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         B, k = 256, 7
         ha = torch.empty((B, 2, k, n), dtype=torch.int64).pin_memory()
@@ -248,7 +248,7 @@ def main():
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
         ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
         ev = S.Evaluator(ctx)
         k = 7
         key = mk(ctx, (k, 2, 8, n), pr, dev)

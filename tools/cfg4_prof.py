@@ -5,7 +5,7 @@ from tools.bench_configs import P15_12, mk, timed
 dev = torch.device("cuda", 0)
 logn, n = 15, 1 << 15
 ctx = S.Context(S.SCHEME_CKKS, logn, P15_12, 1, 0)
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
 ev = S.Evaluator(ctx)
 B, k = 512, 11
 c = mk(ctx, (B, 2, k, n), P15_12[:k], dev)

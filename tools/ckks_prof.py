@@ -7,7 +7,7 @@ from tools.bench_configs import P15_12
 dev = torch.device("cuda", 0)
 n, k, B = 1 << 15, 11, 256
 ctx = S.Context(S.SCHEME_CKKS, 15, P15_12, 1, 0)
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
 v = torch.randn((B, n // 2, 2), dtype=torch.float64, device=dev) * 1000
 pl = torch.empty((B, k, n), dtype=torch.int64, device=dev)
 out = torch.empty((B, n // 2, 2), dtype=torch.float64, device=dev)

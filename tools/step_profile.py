@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n, k, pr = 1 << 15, 7, bench.CFG3_PRIMES
 ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433)
-ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
 ev = S.Evaluator(ctx)
 x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
 o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
