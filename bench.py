@@ -234,13 +234,19 @@ def verify_against_oracle(O, key, a, b, out, items):
 
 def cpu_baseline(O, how, total_ops):
     """Times the CPU oracle (oracle/sealref.c, digest-identical to the reference) on a bounded sample of the SAME
-    workload: one worker thread per logical CPU, each doing multiply+relinearize on its own ciphertexts (the
-    reference is single-threaded per call and thread-safe across calls)."""
+    workload: one worker thread per CPU this process may use -- min(logical CPUs, scheduler affinity, cgroup CPU quota);
+    threads beyond the quota only get throttled -- each doing multiply+relinearize on its own ciphertexts (the
+    reference is single-threaded per call and thread-safe across calls). The host's CPU model and core counts are
+    reported next to it, with the linear projection of the 1-thread rate to every physical core of the host (an upper
+    bound: it assumes perfect scaling), because a GPU box hands its container only a share of the host's cores."""
+    import math
     from concurrent.futures import ThreadPoolExecutor
 
     L = O.lib()
     info = cpu_info()
-    threads = max(1, info["logical_cpus"] or 1)
+    usable = [c for c in (info["logical_cpus"], info["affinity_cpus"],
+                          math.ceil(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else None) if c]
+    threads = max(1, min(usable) if usable else 1)
     per_thread = max(1, int(round(total_ops / threads)))
     n = 1 << LOGN
     kmods = O.coeff_modulus_create(n, BITS)
@@ -284,14 +290,16 @@ def cpu_baseline(O, how, total_ops):
         "unit": "ct_mul_relin/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d threads (one per logical CPU) x %d BFV multiply+relinearize at N=2^15, 8 primes (same workload, "
-                  "%d ciphertext pairs)" % (threads, per_thread, threads * per_thread),
+        "sample": "%d threads (one per CPU usable by this container) x %d BFV multiply+relinearize at N=2^15, 8 primes "
+                  "(same workload, %d ciphertext pairs)" % (threads, per_thread, threads * per_thread),
         "seconds": dt,
         "value_1thread": one_thread,
         "forward_ntt_per_s_1core": ntt_s,
         "build": how,
     }
     out.update(info)
+    cores = info["physical_cores"] or info["logical_cpus"] or threads
+    out["projected_all_physical_cores_linear"] = one_thread * cores
     return out
 
 
@@ -525,8 +533,9 @@ def main(argv=None):
             verified = all_ranks_true(all(oks))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(O, how, args.cpu_ops)
-            cpu["gpu_over_cpu_%dthreads" % cpu["cores"]] = value / cpu["value"]
+            cpu["gpu_over_cpu_%dthreads_measured" % cpu["cores"]] = value / cpu["value"]
             cpu["gpu_over_cpu_1thread"] = value / cpu["value_1thread"]
+            cpu["gpu_over_cpu_all_physical_cores_projected"] = value / cpu["projected_all_physical_cores_linear"]
 
     if rank == 0:
         line = {
