@@ -488,6 +488,8 @@ namespace sealhip
                     throw std::logic_error("internal: Bsk prime order");
                 rd.floor_G1m_top[0][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n, b), b);
                 rd.floor_G1m_top[1][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n_w, b), b);
+                rd.floor_G1m_topM[0][j] = mont(rd.floor_G1m_top[0][j], b);
+                rd.floor_G1m_topM[1][j] = mont(rd.floor_G1m_top[1][j], b);
             }
             for (int i = 0; i < k; i++)
             {
@@ -496,6 +498,11 @@ namespace sealhip
                 rd.floor_F0_top[1][i] = mulmod(rd.floor_F0[i], tables[i].inv_n_w, qi);
                 rd.floor_F0_top_s[0][i] = shoup(rd.floor_F0_top[0][i], qi);
                 rd.floor_F0_top_s[1][i] = shoup(rd.floor_F0_top[1][i], qi);
+                for (int hh = 0; hh < 2; hh++)
+                {
+                    rd.floor_F0_topM[hh][i] = mont(rd.floor_F0_top[hh][i], qi);
+                    rd.floor_F0_topM_s[hh][i] = shoup(rd.floor_F0_topM[hh][i], qi);
+                }
                 rd.q_mt_inv_s[i] = shoup(rd.q_mt_inv[i], qi);
                 rd.floor_F0_s[i] = shoup(rd.floor_F0[i], qi);
                 rd.pBm[i] = mont(hr.prod_B_mod_q[i], qi);

@@ -49,6 +49,7 @@ namespace sealhip
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
     constexpr int kNttAnyRep = 8;    // inverse: the consumer canonicalises, any representative below 2p may be stored
+    constexpr int kNttReduceOut = 0x10; // forward, single-pass kernel: one more conditional subtraction, outputs in [0, 2p)
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
 
@@ -101,6 +102,10 @@ namespace sealhip
         // n^{-1}; index 1: upper half, w * n^{-1}; ntt.cpp:393-402), so the fused floor kernel multiplies once, not twice
         u64 floor_F0_top[2][kMaxModuli], floor_F0_top_s[2][kMaxModuli];
         u64 floor_G1m_top[2][kMaxModuli + 2];
+        // ... and with 2^64 mod the row's prime on top: the inverse NTT that forms the tensor product on load leaves the
+        // Montgomery factor 2^-64 on every word (ntt.hip: DyadicSrc)
+        u64 floor_F0_topM[2][kMaxModuli], floor_F0_topM_s[2][kMaxModuli];
+        u64 floor_G1m_topM[2][kMaxModuli + 2];
         // Montgomery/Shoup companions of the folded constants (suffix m: times 2^64 mod the row's prime; s: Shoup)
         const u64 *lift_L1m, *floor_G2m, *B_to_qm; // [nB][k], [nB][k], [k][B]
         u64 lift_L2m[kMaxModuli + 2], floor_G1m[kMaxModuli + 2];
@@ -342,6 +347,7 @@ namespace sealhip
     // fused (x t) + fast_floor + fastbconv_sk: in (k+|Bsk|) rows -> out k rows
     // deferred_top != 0: `in` holds the output of the single-pass inverse kernel WITHOUT its top layer; the kernel
     // applies that layer and the canonicalising subtraction while loading (needs ntt_can_defer_top(e))
+    // deferred_top == 2: as 1, and every input word carries the Montgomery factor 2^-64 (launch_intt_tensor)
     hipError_t launch_bfv_floor_sk(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int deferred_top = 0);
@@ -349,6 +355,9 @@ namespace sealhip
     // inverse NTT whose input rows come from another buffer (single-pass kernels only: ntt_can_gather(e))
     hipError_t launch_intt_from(const Engine &e, u64 *data, const u64 *src, std::size_t src_poly_stride, std::size_t nrows,
                                 const RowMap &map, int flags);
+    // inverse NTT that forms the (2,2) ciphertext tensor product on load (needs ntt_can_gather(e)); see ntt.hip
+    hipError_t launch_intt_tensor(const Engine &e, u64 *data, const u64 *x, std::size_t item_stride, std::size_t poly_stride,
+                                  int kb, std::size_t nrows, const RowMap &map, int flags);
     hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int out_rows);

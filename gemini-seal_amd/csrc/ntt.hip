@@ -386,7 +386,7 @@ namespace sealhip
 #define NTT_EXP(flags, bit) false
 #endif
 
-        template <int T, bool STRICT, int G>
+        template <int T, bool STRICT, int G, bool ROUT>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -427,6 +427,14 @@ namespace sealhip
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
+                else if constexpr (ROUT)
+                {
+                    // kNttReduceOut: [0, 4p) -> [0, 2p), same residue. (The last layer reduces its first operand and its
+                    // product below 2p before it adds them -- ForwardLazyLast, ntt.cpp:254-261 -- so even on the 60-bit rows,
+                    // where earlier layers wrap, what it outputs is below 4p.)
+                    v.x = v.x >= two_p ? v.x - two_p : v.x;
+                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
                 // (plain store: this path serves f = 3, where a lane's 64-byte run is written by four instructions and
@@ -435,20 +443,20 @@ namespace sealhip
             }
         }
 
-        template <int T, bool STRICT, int G, int NG>
+        template <int T, bool STRICT, int G, int NG, bool ROUT>
         struct FinalGroups
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                        int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
-                h_final_group<T, STRICT, G>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                h_final_group<T, STRICT, G, ROUT>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 if ((G & 1) == 1)
                     __builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting every group's twiddle loads
-                FinalGroups<T, STRICT, G + 1, NG>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                FinalGroups<T, STRICT, G + 1, NG, ROUT>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, bool STRICT, int NG>
-        struct FinalGroups<T, STRICT, NG, NG>
+        template <int T, bool STRICT, int NG, bool ROUT>
+        struct FinalGroups<T, STRICT, NG, NG, ROUT>
         {
             __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
             {}
@@ -485,7 +493,7 @@ namespace sealhip
             }
         }
 
-        template <int T, bool STRICT, int G>
+        template <int T, bool STRICT, int G, bool ROUT>
         __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
                                                            int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -525,6 +533,14 @@ namespace sealhip
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
+                else if constexpr (ROUT)
+                {
+                    // kNttReduceOut: [0, 4p) -> [0, 2p), same residue. (The last layer reduces its first operand and its
+                    // product below 2p before it adds them -- ForwardLazyLast, ntt.cpp:254-261 -- so even on the 60-bit rows,
+                    // where earlier layers wrap, what it outputs is below 4p.)
+                    v.x = v.x >= two_p ? v.x - two_p : v.x;
+                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
                 store_nt(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s), v.x, v.y);
@@ -541,19 +557,19 @@ namespace sealhip
                     StageTw<T, ST, I + 1>::load(tg, tw, jb, N);
             }
         };
-        template <int T, bool STRICT, int ST, int I = 0>
+        template <int T, bool STRICT, bool ROUT, int ST, int I = 0>
         struct StageRun
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
                                                        u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
-                h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
-                                                                         two_p, neg_p, rdp, fin);
+                h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I, ROUT>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
+                                                                               two_p, neg_p, rdp, fin);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    StageRun<T, STRICT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    StageRun<T, STRICT, ROUT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, bool STRICT, int ST>
+        template <int T, bool STRICT, bool ROUT, int ST>
         struct FinalPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
@@ -564,10 +580,10 @@ namespace sealhip
                 if constexpr (ST + 1 < FinalStage<T>::NS)
                     StageTw<T, ST + 1>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                StageRun<T, STRICT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                StageRun<T, STRICT, ROUT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FinalPipe<T, STRICT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    FinalPipe<T, STRICT, ROUT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
 
@@ -661,7 +677,7 @@ namespace sealhip
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
                 }
-                if constexpr (REDUCE != 0) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
+                if constexpr (REDUCE == 1 || REDUCE == 2) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
                 {
                     const u64 p = 0 - neg_p;
                     const auto red = [&](u64 v) {
@@ -885,10 +901,11 @@ namespace sealhip
             const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
             // bit 0: canonicalising wrapper; bit 1: leave the last layer's first operand unreduced (kNttAnyRep)
             const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0);
+            constexpr bool ROUT = REDUCE == 3; // kNttReduceOut launches (never gathered: no load treatment to combine with)
             if constexpr (FinalStage<T>::PIPE)
-                FinalPipe<T, STRICT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+                FinalPipe<T, STRICT, ROUT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             else
-                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12))>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
             if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
@@ -1083,14 +1100,149 @@ namespace sealhip
             }
         };
 
-        template <int LOGN, bool LZ>
+        // ---- ciphertext tensor product formed on load (evaluator.cpp:376-420 for two size-2 operands): output polynomial I
+        // of an item is c_0 = a_0 b_0, c_1 = a_0 b_1 + a_1 b_0, c_2 = a_1 b_1 over the forward-transformed rows X[s] (s = 0, 1:
+        // a; s = 2, 3: b) of the same prime. The reference reduces every product with Barrett and adds with one conditional
+        // subtraction; its results are canonical residues that only feed this inverse transform, so any representative of
+        // the same residue class below 2p gives the same final output. Here: carry-free 128-bit sum of products (operands
+        // below 2^61) and ONE Montgomery reduction, which leaves the factor 2^-64; the consumer's constants carry 2^64
+        // (RnsDev::floor_*_topM). The operands must make that reduction land below 2p: below 4p for primes under 2^59
+        // (what the lazy forward transform stores), below 2p for primes up to 2^61 -- the wrapped 60-bit Bsk rows hold
+        // arbitrary 64-bit words (which dyadic_product_coeffmod accepts, polyarithsmallmod.cpp:63-117), so the forward
+        // launch that produces them reduces every word with barrett_lazy before it stores it (kNttReduceOut).
+        struct DyadicSrc
+        {
+            const u64 *x;                        // forward-transformed operands: item-major, 4 polynomials of kb rows
+            std::size_t item_stride, poly_stride; // words
+            int kb;
+        };
+        // IL words in lock step: t_j = (sum of NP products of operands below 2^61) * 2^-64 mod p as a Montgomery reduction,
+        // t_j < sum / 2^64 + p. 4 multiplier instructions per product (the operands' upper halves are below 2^29, so the
+        // middle sums cannot overflow), 3 for m = lo * (-p^-1) mod 2^64, 4 + one carry for floor(m p / 2^64).
+        // Program-ordered (volatile) like the butterflies: consecutive instructions belong to different words, and the
+        // carry of the high product is read IL >= 3 instructions after it is written.
+        template <int IL, int NP>
+        __device__ __forceinline__ void dyadic_redc(u64 (&t)[IL], const u64 (&a)[NP][IL], const u64 (&b)[NP][IL], u64 p, u64 ninv)
+        {
+            static_assert(IL >= 3, "the carry of the high product is read IL instructions after its producer");
+            typedef unsigned __int128 u128;
+            u64 P0[NP][IL], M[IL], H[IL], cy[IL] = {};
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+            {
+#pragma unroll
+                for (int j = 0; j < IL; j++)
+                    P0[q][j] = mul64v<false>(static_cast<u32>(a[q][j]), static_cast<u32>(b[q][j]), cy[j]);
+#pragma unroll
+                for (int j = 0; j < IL; j++)
+                    M[j] = q == 0 ? mul64v<false>(static_cast<u32>(a[q][j]), static_cast<u32>(b[q][j] >> 32), cy[j])
+                                  : mad64v<false>(static_cast<u32>(a[q][j]), static_cast<u32>(b[q][j] >> 32), M[j], cy[j]);
+#pragma unroll
+                for (int j = 0; j < IL; j++)
+                    M[j] = mad64v<false>(static_cast<u32>(a[q][j] >> 32), static_cast<u32>(b[q][j]), M[j], cy[j]);
+#pragma unroll
+                for (int j = 0; j < IL; j++)
+                    H[j] = q == 0 ? mul64v<false>(static_cast<u32>(a[q][j] >> 32), static_cast<u32>(b[q][j] >> 32), cy[j])
+                                  : mad64v<false>(static_cast<u32>(a[q][j] >> 32), static_cast<u32>(b[q][j] >> 32), H[j], cy[j]);
+            }
+            u64 lo[IL], hi[IL], m[IL], A[IL], B[IL], carry[IL], mh[IL];
+            u32 cb[IL];
+            const u32 p0 = static_cast<u32>(p), p1 = static_cast<u32>(p >> 32);
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+            {
+                u128 X = (static_cast<u128>(H[j]) << 64) + (static_cast<u128>(M[j]) << 32);
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    X += P0[q][j];
+                lo[j] = static_cast<u64>(X);
+                hi[j] = static_cast<u64>(X >> 64);
+                m[j] = lo[j] * ninv;
+            }
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+                A[j] = mad64v<true>(static_cast<u32>(m[j] >> 32), p0, static_cast<u64>(__umulhi(static_cast<u32>(m[j]), p0)), cy[j]);
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+                asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(B[j]), "=s"(carry[j]) : "v"(static_cast<u32>(m[j])), "s"(p1), "v"(A[j]));
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+                asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(cb[j]) : "s"(carry[j]));
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+                mh[j] = mad64v<true>(static_cast<u32>(m[j] >> 32), p1,
+                                     static_cast<u64>(static_cast<u32>(B[j] >> 32)) | (static_cast<u64>(cb[j]) << 32), cy[j]);
+#pragma unroll
+            for (int j = 0; j < IL; j++)
+                t[j] = hi[j] + mh[j] + (lo[j] != 0); // lo + m p is a multiple of 2^64: its low word carries iff lo != 0
+        }
+        // the half row's 32 words per lane, arrangement 4, as products of two (c_0, c_2) or four (c_1) input rows
+        template <int T>
+        __device__ __forceinline__ void h_load_dyadic2(u64 (&x)[32], const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                       int jloc, u64 p, u64 ninv)
+        {
+#pragma unroll
+            for (int batch = 0; batch < 4; batch++)
+            {
+                ulonglong2 va[4], vb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int idx = jloc + Arr<T, 4>::slot_index((batch * 4 + i) * 2);
+                    va[i] = *reinterpret_cast<const ulonglong2 *>(a + idx);
+                    vb[i] = *reinterpret_cast<const ulonglong2 *>(b + idx);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+                {
+                    const u64 aa[1][4] = { { va[2 * g].x, va[2 * g].y, va[2 * g + 1].x, va[2 * g + 1].y } };
+                    const u64 bb[1][4] = { { vb[2 * g].x, vb[2 * g].y, vb[2 * g + 1].x, vb[2 * g + 1].y } };
+                    u64 t[4];
+                    dyadic_redc<4, 1>(t, aa, bb, p, ninv);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        x[(batch * 4 + 2 * g) * 2 + j] = t[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        template <int T>
+        __device__ __forceinline__ void h_load_dyadic4(u64 (&x)[32], const u64 *__restrict__ a0, const u64 *__restrict__ b1,
+                                                       const u64 *__restrict__ a1, const u64 *__restrict__ b0, int jloc, u64 p,
+                                                       u64 ninv)
+        {
+#pragma unroll
+            for (int batch = 0; batch < 8; batch++)
+            {
+                ulonglong2 v0[2], v1[2], v2[2], v3[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+                {
+                    const int idx = jloc + Arr<T, 4>::slot_index((batch * 2 + i) * 2);
+                    v0[i] = *reinterpret_cast<const ulonglong2 *>(a0 + idx);
+                    v1[i] = *reinterpret_cast<const ulonglong2 *>(b1 + idx);
+                    v2[i] = *reinterpret_cast<const ulonglong2 *>(a1 + idx);
+                    v3[i] = *reinterpret_cast<const ulonglong2 *>(b0 + idx);
+                }
+                const u64 aa[2][4] = { { v0[0].x, v0[0].y, v0[1].x, v0[1].y }, { v2[0].x, v2[0].y, v2[1].x, v2[1].y } };
+                const u64 bb[2][4] = { { v1[0].x, v1[0].y, v1[1].x, v1[1].y }, { v3[0].x, v3[0].y, v3[1].x, v3[1].y } };
+                u64 t[4];
+                dyadic_redc<4, 2>(t, aa, bb, p, ninv);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    x[batch * 4 + j] = t[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        template <int LOGN, bool LZ, bool DY>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
                                                                                   std::size_t chunk,
                                                                                   const u64 *__restrict__ src,
                                                                                   std::size_t src_poly_stride,
-                                                                                  LiveSlots live)
+                                                                                  LiveSlots live, DyadicSrc dy)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
@@ -1116,13 +1268,32 @@ namespace sealhip
                 // the first stage with them
                 const int jloc = Arr<T, 4>::tid_index(fresh(tid));
                 u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
-                FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
-#pragma unroll
-                for (int s = 0; s < 32; s += 2)
+                if constexpr (!DY)
+                    FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
+                if constexpr (DY)
                 {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(inp + jloc + Arr<T, 4>::slot_index(s));
-                    x[s] = v.x;
-                    x[s + 1] = v.y;
+                    // map.rows = 3 * kb: slot = I * kb + r selects the output polynomial I and the prime row r
+                    const int slot = live.slot[position], I = slot / dy.kb, r = slot - I * dy.kb;
+                    const u64 *xr = dy.x + poly * dy.item_stride + (static_cast<std::size_t>(r) << LOGN) + gbase;
+                    const std::size_t ps = dy.poly_stride;
+                    if (I == 1) // block-uniform
+                        h_load_dyadic4<T>(x, xr, xr + 3 * ps, xr + ps, xr + 2 * ps, jloc, p, P.ninv);
+                    else if (I == 0)
+                        h_load_dyadic2<T>(x, xr, xr + 2 * ps, jloc, p, P.ninv);
+                    else
+                        h_load_dyadic2<T>(x, xr + ps, xr + 3 * ps, jloc, p, P.ninv);
+                    // (the first stage's twiddles only now: held across the products they cost 24 registers of scratch)
+                    FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
+                }
+                else
+                {
+#pragma unroll
+                    for (int s = 0; s < 32; s += 2)
+                    {
+                        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(inp + jloc + Arr<T, 4>::slot_index(s));
+                        x[s] = v.x;
+                        x[s + 1] = v.y;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 FirstPipe<T, 0, LZ>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
@@ -1204,7 +1375,8 @@ namespace sealhip
 
         template <int LOGN>
         hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags,
-                                   const u64 *src = nullptr, std::size_t src_poly_stride = 0)
+                                   const u64 *src = nullptr, std::size_t src_poly_stride = 0,
+                                   const DyadicSrc *dyadic = nullptr)
         {
             constexpr int T = LOGN - 1;
             const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
@@ -1226,12 +1398,22 @@ namespace sealhip
                 bool lazy = (flags & kNttAnyRep) != 0 && !exact_only;
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
-                if (lazy)
-                    ntt_inv_half_kernel<LOGN, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
+                const DyadicSrc dy = dyadic ? *dyadic : DyadicSrc{};
+#define SEALHIP_INV_HALF(LZ_, DY_)                                                                                    \
+    ntt_inv_half_kernel<LOGN, LZ_, DY_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
+        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy)
+                if (dyadic)
+                {
+                    if (lazy)
+                        SEALHIP_INV_HALF(true, true);
+                    else
+                        SEALHIP_INV_HALF(false, true);
+                }
+                else if (lazy)
+                    SEALHIP_INV_HALF(true, false);
                 else
-                    ntt_inv_half_kernel<LOGN, false><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live);
+                    SEALHIP_INV_HALF(false, false);
+#undef SEALHIP_INV_HALF
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -1327,10 +1509,18 @@ namespace sealhip
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
     ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
         data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, src, chunk, live)
-            const int red = src.base[0] ? src.reduce_mode : 0;
+            int red = src.base[0] ? src.reduce_mode : 0;
+            if (flags & kNttReduceOut)
+            {
+                if (red != 0 || (flags & kNttCanonical))
+                    return hipErrorInvalidValue; // an in-place, non-canonical launch option
+                red = 3;
+            }
             if (flags & kNttStrict)
             {
-                if (red == 2)
+                if (red == 3)
+                    SEALHIP_FWD_HALF(true, 3);
+                else if (red == 2)
                     SEALHIP_FWD_HALF(true, 2);
                 else if (red == 1)
                     SEALHIP_FWD_HALF(true, 1);
@@ -1339,7 +1529,9 @@ namespace sealhip
             }
             else
             {
-                if (red == 2)
+                if (red == 3)
+                    SEALHIP_FWD_HALF(false, 3);
+                else if (red == 2)
                     SEALHIP_FWD_HALF(false, 2);
                 else if (red == 1)
                     SEALHIP_FWD_HALF(false, 1);
@@ -1355,7 +1547,9 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[6] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
+            const void *fwd[8] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 3>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 3>),
+                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 1>),
                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 2>),
                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 0>),
@@ -1367,12 +1561,17 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (err != hipSuccess)
-                return err;
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            const void *inv[4] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, true>) };
+            for (const void *f : inv)
+            {
+                err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (err != hipSuccess)
+                    return err;
+            }
+            return hipSuccess;
         }
 
         void make_rounds(NttPass &ps, int lo, int hi, bool inverse)
@@ -1534,6 +1733,24 @@ namespace sealhip
         if (e.logn == 15)
             return launch_half_inv<15>(e, data, nrows, map, flags, src, src_poly_stride);
         return launch_half_inv<16>(e, data, nrows, map, flags, src, src_poly_stride);
+    }
+
+    // inverse NTT of the ciphertext tensor product of two size-2 operands, formed on load from the forward-transformed
+    // rows x (item-major: 4 polynomials of kb rows each, item_stride words apart); map has 3 * kb rows (output polynomial
+    // I, row r at slot I * kb + r); the stored values carry the Montgomery factor 2^-64 (see DyadicSrc)
+    hipError_t launch_intt_tensor(const Engine &e, u64 *data, const u64 *x, std::size_t item_stride, std::size_t poly_stride,
+                                  int kb, size_t nrows, const RowMap &map, int flags)
+    {
+        if (!(e.use_half_kernel && e.logn >= 14 && e.logn <= 16) || map.rows != 3 * kb)
+            return hipErrorInvalidValue;
+        if (nrows == 0)
+            return hipSuccess;
+        const DyadicSrc dy{ x, item_stride, poly_stride, kb };
+        if (e.logn == 14)
+            return launch_half_inv<14>(e, data, nrows, map, flags, nullptr, 0, &dy);
+        if (e.logn == 15)
+            return launch_half_inv<15>(e, data, nrows, map, flags, nullptr, 0, &dy);
+        return launch_half_inv<16>(e, data, nrows, map, flags, nullptr, 0, &dy);
     }
 
     hipError_t launch_ntt(const Engine &e, u64 *data, size_t nrows, const RowMap &map, bool inverse, int flags)

@@ -309,6 +309,13 @@ namespace sealhip
                     check(launch_copy_rows(e, src, src_stride, dst, w_x, m, k), "copy");
                 check(launch_bfv_lift(e, lt.d_rns, h, src, src_stride, dst + poly_q, w_x, m), "bfv_lift");
             }
+            // With the single-pass kernels and two size-2 operands the tensor product (step 4) is formed by the inverse
+            // NTT while it loads its rows (no separate pass over 7 rows per prime; launch_intt_tensor)
+            const bool defer = ntt_can_defer_top(e, k);
+            bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
+                                std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
+            for (int r = 0; r < k; r++) // its Montgomery reduction lands below 2p for ciphertext primes under 2^59
+                fused_tensor = fused_tensor && e.key_moduli[r] < (u64(1) << 59);
             if (gather)
             {
                 // one "polynomial" of the launch = all sin*(k+|Bsk|) rows of an item
@@ -330,21 +337,45 @@ namespace sealhip
                     }
                 // two launches over disjoint rows: the q rows only feed the tensor product, which reduces canonically, so
                 // their last layer may skip its Barrett step (kNttAnyRep); the 60-bit Bsk rows wrap in the reference (F2)
-                // and keep its exact sequence
+                // and keep its exact sequence. (The fused tensor product multiplies the q rows without reducing them first
+                // and needs them below 4p: there the last layer keeps its Barrett step.)
                 RowMap mq = big, mb = big;
                 for (int s = 0; s < sin; s++)
                     for (int r = 0; r < kb; r++)
                         (r < k ? mb : mq).prime[s * kb + r] = kSkipRow;
-                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, kNttAnyRep), "ntt(X, gathered q rows)");
-                check(launch_ntt(e, X, m * sin * kb, mb, false, 0), "ntt(X, Bsk rows)");
+                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, fused_tensor ? 0 : kNttAnyRep), "ntt(X, gathered q rows)");
+                // (fused tensor product: the wrapped Bsk words are brought below 2p as they are stored -- the residue class
+                //  is all the dyadic product depends on)
+                check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? kNttReduceOut : 0), "ntt(X, Bsk rows)");
             }
             else
                 check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
+            if (fused_tensor)
+            {
+                // steps (4) + (5) (:376-424): D[I] = inverse NTT of sum_{i1+i2=I} X[i1] (.) X[2+i2], top layer deferred, every
+                // word with the Montgomery factor 2^-64 that bfv_floor_sk's constants undo. q rows: lazy sums (any
+                // representative); Bsk rows: operands reduced on load, the reference's butterfly sequence
+                RowMap mq{}, mb{};
+                mq.rows = mb.rows = dest * kb;
+                for (int I = 0; I < dest; I++)
+                    for (int r = 0; r < kb; r++)
+                    {
+                        mq.prime[I * kb + r] = r < k ? lt.map_qbsk.prime[r] : kSkipRow;
+                        mb.prime[I * kb + r] = r < k ? kSkipRow : lt.map_qbsk.prime[r];
+                    }
+                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mq, kNttDeferTop | kNttAnyRep),
+                      "intt(tensor, q rows)");
+                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop), "intt(tensor, Bsk rows)");
+                for (int I = 0; I < dest; I++)
+                    check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
+                                              dest * poly_q, m, 2),
+                          "floor_sk");
+                continue;
+            }
             // step (4) (:376-420)
             check(launch_tensor_product(e, X, sa, w_x, X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
             // step (5) (:423-424); with the single-pass kernels the top inverse layer and the canonicalisation are
             // applied by the consumer while it loads (saves one read+write pass over D)
-            const bool defer = ntt_can_defer_top(e, k);
             if (defer)
             {
                 // two launches over disjoint rows: the q rows may store any representative (bfv_floor_sk canonicalises

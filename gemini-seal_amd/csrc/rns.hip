@@ -267,7 +267,7 @@ namespace sealhip
                                                                          const u64 *__restrict__ in,
                                                                          std::size_t in_stride, u64 *__restrict__ out,
                                                                          std::size_t out_stride, std::size_t count,
-                                                                         int logn)
+                                                                         int logn, int mont)
         {
             Cols cc;
             if (!column(count, logn, cc))
@@ -301,14 +301,17 @@ namespace sealhip
                 }
             __builtin_amdgcn_sched_barrier(0);
             u64 t[KA];
+            // mont (kernel-uniform): the input words carry the Montgomery factor 2^-64 of the tensor product formed inside
+            // the inverse NTT; the constants of the first product of every input then carry 2^64 on top
+            const auto *F0t = mont ? kc(d->floor_F0_topM[is_hi ? 1 : 0]) : kc(d->floor_F0_top[is_hi ? 1 : 0]);
+            const auto *F0ts = mont ? kc(d->floor_F0_topM_s[is_hi ? 1 : 0]) : kc(d->floor_F0_top_s[is_hi ? 1 : 0]);
 #pragma unroll
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
                     const auto *Q = primes + d->q_prime[i];
                     if (DEFER) // (u +- v) * (n^{-1} or w n^{-1}) * F0 with ONE canonical Shoup product
-                        t[i] = mulmod_shoup_hs(before_top<false>(ru[i], rv[i], is_hi, Q), kc(d->floor_F0_top[is_hi ? 1 : 0])[i],
-                                               kc(d->floor_F0_top_s[is_hi ? 1 : 0])[i], Q->p);
+                        t[i] = mulmod_shoup_hs(before_top<false>(ru[i], rv[i], is_hi, Q), F0t[i], F0ts[i], Q->p);
                     else
                         t[i] = mulmod_shoup_hs(ru[i], kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
                 }
@@ -318,7 +321,8 @@ namespace sealhip
             SplitT ts[KA], tbs[KA + 1];
             if constexpr (KMAX < 0)
                 static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
-            const auto *G1m = DEFER ? kc(d->floor_G1m_top[is_hi ? 1 : 0]) : kc(d->floor_G1m);
+            const auto *G1m = DEFER ? (mont ? kc(d->floor_G1m_topM[is_hi ? 1 : 0]) : kc(d->floor_G1m_top[is_hi ? 1 : 0]))
+                                    : kc(d->floor_G1m);
             const auto *G2m = kc(d->floor_G2m);
 #pragma unroll
             for (int j = 0; j < KA + 2; j++)
@@ -802,10 +806,11 @@ namespace sealhip
     {                                                                                                                \
         if (deferred_top)                                                                                            \
             bfv_floor_sk2_kernel<KM, true><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,       \
-                                                                           out_stride, count, e.logn);              \
+                                                                           out_stride, count, e.logn,               \
+                                                                           deferred_top == 2 ? 1 : 0);              \
         else                                                                                                         \
             bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,      \
-                                                                            out_stride, count, e.logn);             \
+                                                                            out_stride, count, e.logn, 0);          \
     } while (0)
             switch (h.k)
             {
