@@ -407,7 +407,7 @@ namespace sealhip
         rd.k = k;
         rd.t = t;
         for (int i = 0; i < k; i++)
-            rd.q_prime[i] = static_cast<unsigned short>(i);
+            rd.q_prime[i] = static_cast<unsigned>(i);
         for (int i = 0; i + 1 < k; i++)
             rd.inv_q_last_mod_q[i] = hr.inv_q_last_mod_q[i];
         if (scheme == 1)
@@ -488,8 +488,16 @@ namespace sealhip
                     throw std::logic_error("internal: Bsk prime order");
                 rd.floor_G1m_top[0][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n, b), b);
                 rd.floor_G1m_top[1][j] = mont(mulmod(rd.floor_G1[j], tb.inv_n_w, b), b);
-                rd.floor_G1m_topM[0][j] = mont(rd.floor_G1m_top[0][j], b);
-                rd.floor_G1m_topM[1][j] = mont(rd.floor_G1m_top[1][j], b);
+                rd.floor_G1m_top[2][j] = mont(rd.floor_G1m_top[0][j], b);
+                rd.floor_G1m_top[3][j] = mont(rd.floor_G1m_top[1][j], b);
+                rd.b_p[j] = b;
+                rd.b_rdp[j] = tb.rdp ? tb.rdp : shoup(1, b);
+                {
+                    u64 inv = b;
+                    for (int it = 0; it < 6; it++)
+                        inv *= 2 - b * inv;
+                    rd.b_ninv[j] = 0 - inv;
+                }
             }
             for (int i = 0; i < k; i++)
             {
@@ -500,8 +508,16 @@ namespace sealhip
                 rd.floor_F0_top_s[1][i] = shoup(rd.floor_F0_top[1][i], qi);
                 for (int hh = 0; hh < 2; hh++)
                 {
-                    rd.floor_F0_topM[hh][i] = mont(rd.floor_F0_top[hh][i], qi);
-                    rd.floor_F0_topM_s[hh][i] = shoup(rd.floor_F0_topM[hh][i], qi);
+                    rd.floor_F0_top[2 + hh][i] = mont(rd.floor_F0_top[hh][i], qi);
+                    rd.floor_F0_top_s[2 + hh][i] = shoup(rd.floor_F0_top[2 + hh][i], qi);
+                }
+                rd.q_p[i] = qi;
+                rd.q_rdp[i] = tables[i].rdp ? tables[i].rdp : shoup(1, qi);
+                {
+                    u64 inv = qi;
+                    for (int it = 0; it < 6; it++)
+                        inv *= 2 - qi * inv;
+                    rd.q_ninv[i] = 0 - inv;
                 }
                 rd.q_mt_inv_s[i] = shoup(rd.q_mt_inv[i], qi);
                 rd.floor_F0_s[i] = shoup(rd.floor_F0[i], qi);
@@ -541,7 +557,7 @@ namespace sealhip
                 rd.dsr_neg_inv_q_g = ig ? hr.gamma - ig : 0;
                 rd.dsr_inv_gamma_t = igt;
                 rd.dsr_gamma = hr.gamma;
-                rd.gamma_prime = static_cast<unsigned short>(n_key + 1); // aux primes: m_sk, gamma, B...
+                rd.gamma_prime = static_cast<unsigned>(n_key + 1); // aux primes: m_sk, gamma, B...
             }
             // REDC lands below 2p iff (sum of the bounds of the variable factors) <= 2^64:
             //   lift rows:   k terms t_i < q_i plus temp < b_j;  floor Bsk rows: in < b_j plus k terms < q_i;
@@ -568,7 +584,7 @@ namespace sealhip
             kd.strict = mode_strict;
             const int rows = k + nsp;
             for (int r = 0; r < rows; r++)
-                kd.row_prime[r] = static_cast<unsigned short>(r < k ? r : k_first + (r - k));
+                kd.row_prime[r] = static_cast<unsigned>(r < k ? r : k_first + (r - k));
             auto prime_of = [&](int r) { return key_moduli[kd.row_prime[r]]; };
             // mod-up (multi_special_primes.cpp:110-126)
             const std::size_t blk = static_cast<std::size_t>(2 * nsp + rows * nsp);

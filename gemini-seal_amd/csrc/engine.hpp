@@ -100,12 +100,16 @@ namespace sealhip
         u64 floor_F0[kMaxModuli];     // t * (q^_i)^{-1} mod q_i
         // the same constants with the deferred top inverse-NTT layer's factor folded in (index 0: lower half of a row,
         // n^{-1}; index 1: upper half, w * n^{-1}; ntt.cpp:393-402), so the fused floor kernel multiplies once, not twice
-        u64 floor_F0_top[2][kMaxModuli], floor_F0_top_s[2][kMaxModuli];
-        u64 floor_G1m_top[2][kMaxModuli + 2];
-        // ... and with 2^64 mod the row's prime on top: the inverse NTT that forms the tensor product on load leaves the
-        // Montgomery factor 2^-64 on every word (ntt.hip: DyadicSrc)
-        u64 floor_F0_topM[2][kMaxModuli], floor_F0_topM_s[2][kMaxModuli];
-        u64 floor_G1m_topM[2][kMaxModuli + 2];
+        // Index 2, 3: the same with 2^64 mod the row's prime on top -- the inverse NTT that forms the tensor product on load
+        // leaves the Montgomery factor 2^-64 on every word (ntt.hip: DyadicSrc). One array indexed by 2 * mont + half: the
+        // kernel selects its table with scalar arithmetic, not with a branch.
+        u64 floor_F0_top[4][kMaxModuli], floor_F0_top_s[4][kMaxModuli];
+        u64 floor_G1m_top[4][kMaxModuli + 2];
+        // per-row prime constants next to the level constants (p, -p^-1 mod 2^64, floor(2^64 / p)): read at compile-time
+        // offsets with scalar loads the compiler can batch -- going through PrimeDev[prime id] made every row loop wait for
+        // two dependent scalar loads
+        u64 q_p[kMaxModuli], q_ninv[kMaxModuli], q_rdp[kMaxModuli];
+        u64 b_p[kMaxModuli + 2], b_ninv[kMaxModuli + 2], b_rdp[kMaxModuli + 2];
         // Montgomery/Shoup companions of the folded constants (suffix m: times 2^64 mod the row's prime; s: Shoup)
         const u64 *lift_L1m, *floor_G2m, *B_to_qm; // [nB][k], [nB][k], [k][B]
         u64 lift_L2m[kMaxModuli + 2], floor_G1m[kMaxModuli + 2];
@@ -117,10 +121,12 @@ namespace sealhip
         //   y_i = in_i * dsr_scale[i] mod q_i  (|gamma t|_qi times (q^_i)^{-1});  {t, gamma} part = sum_i y_i * dsr_to_t/g[i]
         u64 dsr_scale[kMaxModuli], dsr_scale_s[kMaxModuli], dsr_to_t[kMaxModuli], dsr_to_g[kMaxModuli];
         u64 dsr_neg_inv_q_t, dsr_neg_inv_q_g, dsr_inv_gamma_t, dsr_gamma;
-        unsigned short gamma_prime; // PrimeDev id of gamma
+        unsigned gamma_prime; // PrimeDev id of gamma
         int redc_small;                        // every REDC of the fused kernels provably lands below 2p
-        unsigned short q_prime[kMaxModuli];       // prime ids of q rows
-        unsigned short bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
+        // (32-bit: there are no sub-dword scalar loads; a 16-bit id became a VECTOR load with a vmcnt(0) wait in the middle
+        //  of every row loop)
+        unsigned q_prime[kMaxModuli];       // prime ids of q rows
+        unsigned bsk_prime[kMaxModuli + 2]; // prime ids of Bsk rows (m_sk last)
     };
 
     // ---- device-resident constants of the hybrid key switch at level k (multi_special_primes.cpp) ----
@@ -128,7 +134,7 @@ namespace sealhip
     {
         int k, nsp, nd, n_all, n_total; // ct primes, special primes, digits at this level, first-level k, key primes
         int is_ckks, strict;
-        unsigned short row_prime[kMaxModuli]; // prime id of ext row r (r < k: r; r >= k: n_all + r - k)
+        unsigned row_prime[kMaxModuli]; // prime id of ext row r (r < k: r; r >= k: n_all + r - k); 32-bit: scalar loads
         // mod-up: for bundle j, element a (source row j*nsp+a): inv_punch and its shoup; punch[dst row][a]
         const u64 *modup; // layout: [nd][ (2*nsp) + rows*nsp ] see engine.cpp
         // mod-down

@@ -184,25 +184,26 @@ namespace sealhip
             u64 *pout = out + cc.item * out_stride + cc.c;
             u64 t[KA];
             u64 acc = 0;
+            (void)primes;
 #pragma unroll
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
-                    const u64 qp = primes[d->q_prime[i]].p;
+                    const u64 qp = d->q_p[i];
                     t[i] = mulmod_shoup_hs(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
                     acc += t[i] * d->q_to_mt[i];
                 }
             const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
-            const bool small = d->redc_small != 0;
+            // exact-K instances are only launched when the host proved every REDC lands below 2p (RnsDev::redc_small):
+            // a compile-time fact there, so the row loops carry no branch
+            const bool small = KMAX < 0 ? true : d->redc_small != 0;
             SplitT ts[KA];
             if constexpr (KMAX < 0)
                 static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
             const auto *L1m = kc(d->lift_L1m);
             const auto *L2m = kc(d->lift_L2m);
-            for (int j = 0; j < nB; j++)
-            {
-                const auto *Bp = primes + d->bsk_prime[j];
-                const u64 bp = Bp->p;
+            const auto row_out = [&](int j) {
+                const u64 bp = d->b_p[j];
                 u64 temp = r_mt;
                 if (temp >= (1ull << 31))
                     temp += bp - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
@@ -224,8 +225,19 @@ namespace sealhip
                         if (i < k)
                             mac128(lo, hi, t[i], row[i]);
                 }
-                pout[j * N] = redc_finish(redc128(lo, hi, bp, Bp->ninv), bp, Bp->rdp, small);
+                pout[j * N] = redc_finish(redc128(lo, hi, bp, d->b_ninv[j]), bp, d->b_rdp[j], small);
+            };
+            if constexpr (KMAX < 0)
+            {
+                // |Bsk| is k + 1 or k + 2 (rns.cpp:568-573): with an exact K only the last row is a run-time question, the
+                // others are straight-line code whose scalar loads overlap the neighbouring rows' arithmetic
+                static_for<KA + 1>([&](auto J) { row_out(J.value); });
+                if (nB == KA + 2)
+                    row_out(KA + 1);
             }
+            else
+                for (int j = 0; j < nB; j++)
+                    row_out(j);
         }
 
         // Constant-folded variant of bfv_floor_sk_kernel (k <= 32); see RnsDev for the folded constants.
@@ -252,11 +264,11 @@ namespace sealhip
         // The same pair without the multiplication: its constant (n^{-1} or w * n^{-1}) is folded into the constant the
         // value is multiplied with next (RnsDev::floor_F0_top / floor_G1m_top). REDUCE brings the value below 2p (operands
         // of the carry-free dot products must stay below 2^61); a Shoup product takes it as it is.
-        template <bool REDUCE, class PP>
-        __device__ __forceinline__ u64 before_top(u64 u, u64 v, bool is_hi, PP P)
+        template <bool REDUCE>
+        __device__ __forceinline__ u64 before_top(u64 u, u64 v, bool is_hi, u64 two_p)
         {
-            const u64 two_p = P->two_p;
-            u64 r = is_hi ? u - v + two_p : u + v; // < 4p
+            const u64 vv = is_hi ? two_p - v : v; // (a select, not a branch: a uniform branch here splits the row loop into
+            u64 r = u + vv;                       //  blocks the scalar loads cannot be scheduled across); r < 4p
             if (REDUCE)
                 r = r >= two_p ? r - two_p : r;
             return r;
@@ -269,18 +281,40 @@ namespace sealhip
                                                                          std::size_t out_stride, std::size_t count,
                                                                          int logn, int mont)
         {
-            Cols cc;
-            if (!column(count, logn, cc))
-                return;
             constexpr int KA = KMAX < 0 ? -KMAX : KMAX;
+            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            const std::size_t half = N >> 1;
+            Cols cc;
+            bool is_hi = false;
+            if constexpr (DEFER)
+            {
+                // With the deferred top layer the lanes of columns c and c + N/2 read the same 2(k + |Bsk| + 1) words. Blocks
+                // are dealt round-robin over the 8 XCDs (one L2 each): physical blocks b and b + 8 run on the same XCD at
+                // about the same time, so they are given the lower and the upper half of the same 256 columns and the second
+                // read comes from L2 instead of HBM (the halves used to be half a grid apart: 37 row passes instead of 22).
+                // logn >= 14 here: the blocks of an item are a multiple of 16. Everything is derived from the block index, so
+                // the compiler knows is_hi is uniform and reads the tables selected by it with scalar loads.
+                const std::size_t per_item = N / kThreads, bid = blockIdx.x;
+                cc.item = bid / per_item;
+                if (cc.item >= count)
+                    return;
+                const unsigned pl = static_cast<unsigned>(bid - cc.item * per_item), r = pl & 15u;
+                is_hi = (r >> 3) != 0;
+                cc.c = (is_hi ? half : 0) + static_cast<std::size_t>(((pl >> 4) << 3) | (r & 7u)) * kThreads + threadIdx.x;
+            }
+            else if (!column(count, logn, cc))
+                return;
             const auto *d = kc(d_);           // read-only for the lifetime of the context: constant address space
             const auto *primes = kc(primes_); // (scalar loads the compiler may merge and hoist)
             const int k = KMAX < 0 ? KA : d->k, B = d->B; // B is k or k + 1
-            const std::size_t N = static_cast<std::size_t>(1) << logn;
+            // with an exact K every test against B is a compile-time fact except for the one optional extra prime of B
+            // (index K): no branches inside the row loops, so scalar loads and arithmetic of neighbouring rows overlap
+            const bool extraB = B > KA;
+            auto lt_B = [&](int j) { return KMAX < 0 ? (j < KA || (j == KA && extraB)) : j < B; };
+            auto le_B = [&](int j) { return KMAX < 0 ? (j <= KA || (j == KA + 1 && extraB)) : j <= B; };
             const u64 *pin = in + cc.item * in_stride + cc.c;
             const u64 *pitem = in + cc.item * in_stride;
-            const std::size_t half = N >> 1, c_lo = cc.c & (half - 1);
-            const bool is_hi = cc.c >= half; // block-uniform (N/2 is a multiple of the block size)
+            const std::size_t c_lo = cc.c & (half - 1);
             u64 *pout = out + cc.item * out_stride + cc.c;
             // every input word of this column is requested before any arithmetic: one exposed memory latency per
             // thread instead of one per output row (the loads used to sit in the row loops)
@@ -294,7 +328,7 @@ namespace sealhip
                 }
 #pragma unroll
             for (int j = 0; j < KA + 2; j++)
-                if (j <= B)
+                if (le_B(j))
                 {
                     ru[KA + j] = DEFER ? pitem[(k + j) * N + c_lo] : pin[(k + j) * N];
                     rv[KA + j] = DEFER ? pitem[(k + j) * N + c_lo + half] : 0;
@@ -303,34 +337,49 @@ namespace sealhip
             u64 t[KA];
             // mont (kernel-uniform): the input words carry the Montgomery factor 2^-64 of the tensor product formed inside
             // the inverse NTT; the constants of the first product of every input then carry 2^64 on top
-            const auto *F0t = mont ? kc(d->floor_F0_topM[is_hi ? 1 : 0]) : kc(d->floor_F0_top[is_hi ? 1 : 0]);
-            const auto *F0ts = mont ? kc(d->floor_F0_topM_s[is_hi ? 1 : 0]) : kc(d->floor_F0_top_s[is_hi ? 1 : 0]);
+            const int top_sel = (mont ? 2 : 0) + (is_hi ? 1 : 0); // scalar: selects a table by address arithmetic
+            const auto *F0t = DEFER ? kc(d->floor_F0_top[top_sel]) : kc(d->floor_F0);
+            const auto *F0ts = DEFER ? kc(d->floor_F0_top_s[top_sel]) : kc(d->floor_F0_s);
+            (void)primes;
+            // the constants of the first loop, requested as one batch of scalar loads while the vector loads are in flight
+            // (inside the loop every iteration waited for its own three)
+            u64 cF0[KA], cF0s[KA], cQ[KA];
 #pragma unroll
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
-                    const auto *Q = primes + d->q_prime[i];
+                    cF0[i] = F0t[i];
+                    cF0s[i] = F0ts[i];
+                    cQ[i] = d->q_p[i];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KA; i++)
+                if (KMAX < 0 || i < k)
+                {
+                    const u64 qp = cQ[i];
                     if (DEFER) // (u +- v) * (n^{-1} or w n^{-1}) * F0 with ONE canonical Shoup product
-                        t[i] = mulmod_shoup_hs(before_top<false>(ru[i], rv[i], is_hi, Q), F0t[i], F0ts[i], Q->p);
+                        t[i] = mulmod_shoup_hs(before_top<false>(ru[i], rv[i], is_hi, qp << 1), cF0[i], cF0s[i], qp);
                     else
-                        t[i] = mulmod_shoup_hs(ru[i], kc(d->floor_F0)[i], kc(d->floor_F0_s)[i], Q->p);
+                        t[i] = mulmod_shoup_hs(ru[i], cF0[i], cF0s[i], qp);
                 }
             u64 tb[KA + 1];
             u64 fl_sk = 0;
-            const bool small = d->redc_small != 0;
+            // exact-K instances are only launched when the host proved every REDC lands below 2p (RnsDev::redc_small):
+            // a compile-time fact there, so the row loops carry no branch
+            const bool small = KMAX < 0 ? true : d->redc_small != 0;
             SplitT ts[KA], tbs[KA + 1];
             if constexpr (KMAX < 0)
                 static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
-            const auto *G1m = DEFER ? (mont ? kc(d->floor_G1m_topM[is_hi ? 1 : 0]) : kc(d->floor_G1m_top[is_hi ? 1 : 0]))
-                                    : kc(d->floor_G1m);
+            const auto *G1m = DEFER ? kc(d->floor_G1m_top[top_sel]) : kc(d->floor_G1m);
             const auto *G2m = kc(d->floor_G2m);
 #pragma unroll
             for (int j = 0; j < KA + 2; j++)
-                if (j <= B)
+                if (le_B(j))
                 {
-                    const auto *Bp = primes + d->bsk_prime[j];
+                    const u64 bp = d->b_p[j];
                     const auto *row = G2m + j * k;
-                    const u64 x = DEFER ? before_top<true>(ru[KA + j], rv[KA + j], is_hi, Bp) : ru[KA + j];
+                    const u64 x = DEFER ? before_top<true>(ru[KA + j], rv[KA + j], is_hi, bp << 1) : ru[KA + j];
                     u64 lo, hi;
                     if constexpr (KMAX < 0)
                     {
@@ -348,26 +397,29 @@ namespace sealhip
                             if (i < k)
                                 mac128(lo, hi, t[i], row[i]);
                     }
-                    const u64 bp = Bp->p;
-                    const u64 v = redc_finish(redc128(lo, hi, bp, Bp->ninv), bp, Bp->rdp, small);
-                    if (j < B)
+                    const u64 v = redc_finish(redc128(lo, hi, bp, d->b_ninv[j]), bp, d->b_rdp[j], small);
+                    if (lt_B(j))
                         tb[j < KA + 1 ? j : 0] = v;
                     else
                         fl_sk = v;
+                    // one row's constants at a time: left alone the scheduler requests the constants of every row up front
+                    // and spills scalar registers to scratch
+#if !defined(SEALHIP_FLOOR_VARIANT) || SEALHIP_FLOOR_VARIANT != 1
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
-            const auto *Msk = primes + d->bsk_prime[B];
-            const u64 mp = Msk->p;
+            const u64 mp = d->b_p[B];
             const auto *BtoMsk = kc(d->B_to_mskm);
             u64 lo = 0, hi = 0;
             if constexpr (KMAX < 0)
             {
                 static_for<KA + 1>([&](auto J) {
-                    if (J.value < B)
+                    if (lt_B(J.value))
                         tbs[J.value] = SplitT(tb[J.value]);
                 });
                 DotAcc<KA + 1> acc2;
                 static_for<KA + 1>([&](auto J) {
-                    if (J.value < B)
+                    if (lt_B(J.value))
                         acc2.template add<J.value>(tbs[J.value], BtoMsk[J.value]);
                 });
                 acc2.finish(lo, hi);
@@ -376,10 +428,10 @@ namespace sealhip
             {
 #pragma unroll
                 for (int j = 0; j < KA + 1; j++)
-                    if (j < B)
+                    if (lt_B(j))
                         mac128(lo, hi, tb[j], BtoMsk[j]);
             }
-            const u64 conv_sk = redc_finish(redc128(lo, hi, mp, Msk->ninv), mp, Msk->rdp, small);
+            const u64 conv_sk = redc_finish(redc128(lo, hi, mp, d->b_ninv[B]), mp, d->b_rdp[B], small);
             const u64 alpha = mulmod_shoup(conv_sk + (mp - fl_sk), d->inv_prod_B_mod_msk, d->inv_prod_B_mod_msk_s, mp);
             const bool neg = alpha > (mp >> 1); // rns.cpp:909
             const u64 a2 = neg ? mp - alpha : alpha;
@@ -389,7 +441,6 @@ namespace sealhip
             const auto *BtoQ = kc(d->B_to_qm);
             for (int i = 0; i < k; i++)
             {
-                const auto *Q = primes + d->q_prime[i];
                 const u64 c = neg ? pBm[i] : nBm[i];
                 const auto *mrow = BtoQ + i * B;
                 u64 l2, h2;
@@ -398,7 +449,7 @@ namespace sealhip
                     DotAcc<KA + 2> acc2;
                     acc2.template add<0>(a2s, c);
                     static_for<KA + 1>([&](auto J) {
-                        if (J.value < B)
+                        if (lt_B(J.value))
                             acc2.template add<J.value + 1>(tbs[J.value], mrow[J.value]);
                     });
                     acc2.finish(l2, h2);
@@ -409,11 +460,14 @@ namespace sealhip
                     h2 = mulhi(a2, c);
 #pragma unroll
                     for (int j = 0; j < KA + 1; j++)
-                        if (j < B)
+                        if (lt_B(j))
                             mac128(l2, h2, tb[j], mrow[j]);
                 }
-                const u64 qp = Q->p;
-                pout[i * N] = redc_finish(redc128(l2, h2, qp, Q->ninv), qp, Q->rdp, small);
+                const u64 qp = d->q_p[i];
+                pout[i * N] = redc_finish(redc128(l2, h2, qp, d->q_ninv[i]), qp, d->q_rdp[i], small);
+#if !defined(SEALHIP_FLOOR_VARIANT) || SEALHIP_FLOOR_VARIANT != 1
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
 
@@ -741,7 +795,7 @@ namespace sealhip
         if (h.k <= 32 && !e.unfused_rns)
         {
 #define SEALHIP_LIFT2(KM) bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn)
-            switch (h.k)
+            switch (h.redc_small ? h.k : 0)
             {
             case 1: SEALHIP_LIFT2(-1); break;
             case 2: SEALHIP_LIFT2(-2); break;
@@ -812,7 +866,7 @@ namespace sealhip
             bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,      \
                                                                             out_stride, count, e.logn, 0);          \
     } while (0)
-            switch (h.k)
+            switch (h.redc_small ? h.k : 0)
             {
             case 1: SEALHIP_FLOOR2(-1); break;
             case 2: SEALHIP_FLOOR2(-2); break;
