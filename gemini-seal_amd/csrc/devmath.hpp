@@ -250,11 +250,34 @@ namespace sealhip
     }
     // forward lazy butterfly (ntt.cpp:245-252): X = u + v, Y = u - v + 2p with v = y*w - q*p.
     // X falls out of the multiply-accumulate chain (u is its initial accumulator); Y = (2u + 2p) - X.
-    template <bool WU>
+    // APX: the quotient estimate without hi32(y0 * s0), i.e. floor(y s / 2^64) or one less: one multiplier instruction
+    // saved, the product lands in [0, 3p), and the caller passes 3p as `two_p` (Y = u - v + 3p stays non-negative).
+    template <bool SU>
+    __device__ __forceinline__ u64 mulhi_apx(u64 x, u64 s)
+    {
+        const u32 x0 = static_cast<u32>(x), x1 = static_cast<u32>(x >> 32);
+        const u32 s0 = static_cast<u32>(s), s1 = static_cast<u32>(s >> 32);
+        const u64 A = mul64<SU>(x1, s0);
+        u64 B;
+        u32 cb;
+        if (SU)
+            asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, vcc"
+                : "=&v"(B), "=&v"(cb)
+                : "v"(x0), "s"(s1), "v"(A)
+                : "vcc");
+        else
+            asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, vcc"
+                : "=&v"(B), "=&v"(cb)
+                : "v"(x0), "v"(s1), "v"(A)
+                : "vcc");
+        const u64 addend = static_cast<u64>(static_cast<u32>(B >> 32)) | (static_cast<u64>(cb) << 32);
+        return mad64<SU>(x1, s1, addend);
+    }
+    template <bool WU, bool APX = false>
     __device__ __forceinline__ void butterfly_fwd_hs(u64 &xu, u64 &xy, u64 w, u64 wshoup, u64 neg_p, u64 two_p)
     {
         const u64 u = xu;
-        const u64 X = mullo2_acc<WU>(u, xy, w, mulhi_c<WU>(xy, wshoup), neg_p);
+        const u64 X = mullo2_acc<WU>(u, xy, w, APX ? mulhi_apx<WU>(xy, wshoup) : mulhi_c<WU>(xy, wshoup), neg_p);
         xu = X;
         xy = (u << 1) + two_p - X;
     }
@@ -287,7 +310,7 @@ namespace sealhip
             asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "+s"(cy) : "v"(a), "v"(b));
         return d;
     }
-    template <bool WU, int IL>
+    template <bool WU, int IL, bool APX = false>
     __device__ __forceinline__ void butterflies_fwd_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
                                                        u64 neg_p, u64 two_p)
     {
@@ -297,9 +320,10 @@ namespace sealhip
         u32 cb[IL];
         u64 cy[IL] = {};
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 1: A = y1*s0 + hi32(y0*s0)
-            A[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]),
-                              static_cast<u64>(__umulhi(static_cast<u32>(y[j]), static_cast<u32>(ws[j]))), cy[j]);
+        for (int j = 0; j < IL; j++) // 1: A = y1*s0 + hi32(y0*s0)   (APX: without the second term, see butterfly_fwd_hs)
+            A[j] = APX ? mul64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]), cy[j])
+                       : mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]),
+                                    static_cast<u64>(__umulhi(static_cast<u32>(y[j]), static_cast<u32>(ws[j]))), cy[j]);
 #pragma unroll
         for (int j = 0; j < IL; j++) // 2: E = y0*w1
             E[j] = mul64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j] >> 32), cy[j]);

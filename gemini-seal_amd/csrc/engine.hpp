@@ -50,6 +50,7 @@ namespace sealhip
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
     constexpr int kNttAnyRep = 8;    // inverse: the consumer canonicalises, any representative below 2p may be stored
     constexpr int kNttReduceOut = 0x10; // forward, single-pass kernel: one more conditional subtraction, outputs in [0, 2p)
+    constexpr int kNttApprox = 0x20;   // forward, with kNttAnyRep or a consumer that takes outputs below 5p: approximate quotient
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
 

@@ -386,7 +386,7 @@ namespace sealhip
 #define NTT_EXP(flags, bit) false
 #endif
 
-        template <int T, bool STRICT, int G, bool ROUT>
+        template <int T, int STRICT, int G, bool ROUT>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -406,11 +406,11 @@ namespace sealhip
                         continue;
                     const int s = (G << f) | e;
                     const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
-                    if (STRICT)
+                    if (STRICT == 1)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
-                    butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
+                    butterfly_fwd_hs<false, STRICT == 2>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
                 }
             }
 #pragma unroll
@@ -443,7 +443,7 @@ namespace sealhip
             }
         }
 
-        template <int T, bool STRICT, int G, int NG, bool ROUT>
+        template <int T, int STRICT, int G, int NG, bool ROUT>
         struct FinalGroups
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
@@ -455,7 +455,7 @@ namespace sealhip
                 FinalGroups<T, STRICT, G + 1, NG, ROUT>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, bool STRICT, int NG, bool ROUT>
+        template <int T, int STRICT, int NG, bool ROUT>
         struct FinalGroups<T, STRICT, NG, NG, ROUT>
         {
             __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
@@ -493,7 +493,7 @@ namespace sealhip
             }
         }
 
-        template <int T, bool STRICT, int G, bool ROUT>
+        template <int T, int STRICT, int G, bool ROUT>
         __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
                                                            int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -512,11 +512,11 @@ namespace sealhip
                         continue;
                     const int s = (G << f) | e;
                     const u64x2 Wv = tg[(1 << (f - 1 - W)) - 1 + (e >> (W + 1))];
-                    if (STRICT)
+                    if (STRICT == 1)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
-                    butterfly_fwd_hs<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, two_p);
+                    butterfly_fwd_hs<false, STRICT == 2>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
                 }
             }
 #pragma unroll
@@ -557,7 +557,7 @@ namespace sealhip
                     StageTw<T, ST, I + 1>::load(tg, tw, jb, N);
             }
         };
-        template <int T, bool STRICT, bool ROUT, int ST, int I = 0>
+        template <int T, int STRICT, bool ROUT, int ST, int I = 0>
         struct StageRun
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
@@ -569,7 +569,7 @@ namespace sealhip
                     StageRun<T, STRICT, ROUT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, bool STRICT, bool ROUT, int ST>
+        template <int T, int STRICT, bool ROUT, int ST>
         struct FinalPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
@@ -590,7 +590,7 @@ namespace sealhip
         // ---- a compute round as a pipeline of stages. Stage K = kIL butterflies of one layer (layers W = 4, 3, 2, 1,
         // 16 / kIL stages each). The twiddles of stage K+1 are requested before stage K is computed (pinned with
         // sched_barrier), the first stage's before the preceding LDS exchange: no twiddle latency is exposed.
-        template <int T, int R, bool STRICT, bool UNIFORM, int K>
+        template <int T, int R, int STRICT, bool UNIFORM, int K>
         struct RoundStage
         {
             static constexpr int PER = 16 / kIL;
@@ -626,10 +626,10 @@ namespace sealhip
                 {
                     u[j] = x[slot(j)];
                     y[j] = x[slot(j) | bit];
-                    if (STRICT)
+                    if (STRICT == 1)
                         u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
                 }
-                butterflies_fwd_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // ForwardLazy, ntt.cpp:245-252
+                butterflies_fwd_hs<UNIFORM, kIL, STRICT == 2>(u, y, w, ws, neg_p, STRICT == 2 ? two_p - neg_p : two_p); // ForwardLazy, ntt.cpp:245-252
 #pragma unroll
                 for (int j = 0; j < kIL; j++)
                 {
@@ -638,7 +638,7 @@ namespace sealhip
                 }
             }
         };
-        template <int T, int R, bool STRICT, bool UNIFORM, int K = 0>
+        template <int T, int R, int STRICT, bool UNIFORM, int K = 0>
         struct RoundPipe
         {
             static constexpr int NST = 4 * (16 / kIL);
@@ -659,7 +659,7 @@ namespace sealhip
 #define SEALHIP_NTT_LOAD_BATCH 4
 #endif
         constexpr int kLoadBatch = SEALHIP_NTT_LOAD_BATCH; // (lo, hi) 16-byte pairs per lane in flight during the load phase
-        template <int T, bool STRICT, int HALF, int REDUCE>
+        template <int T, int STRICT, int HALF, int REDUCE>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
                                                    const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1)
         {
@@ -704,13 +704,13 @@ namespace sealhip
                     u64 u[4] = {lo[i].x, lo[i].y, lo[i + 1].x, lo[i + 1].y};
                     u64 y[4] = {hi[i].x, hi[i].y, hi[i + 1].x, hi[i + 1].y};
                     const u64 w[4] = {W1.x, W1.x, W1.x, W1.x}, ws[4] = {W1.y, W1.y, W1.y, W1.y};
-                    if (STRICT)
+                    if (STRICT == 1)
                     {
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
                     }
-                    butterflies_fwd_hs<true, 4>(u, y, w, ws, neg_p, two_p);
+                    butterflies_fwd_hs<true, 4, STRICT == 2>(u, y, w, ws, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         x[s + j] = HALF ? y[j] : u[j];
@@ -783,7 +783,7 @@ namespace sealhip
             return v;
         }
 
-        template <int LOGN, bool STRICT, int REDUCE>
+        template <int LOGN, int STRICT, int REDUCE>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
             unsigned *__restrict__ tickets, unsigned *__restrict__ timeout_flag, unsigned spin_limit, NttSource src,
@@ -1440,7 +1440,7 @@ namespace sealhip
             if (const char *ex = std::getenv("SEALHIP_NTT_LDS_EXTRA")) // lower the occupancy on purpose
             {
                 lds_bytes += std::strtoul(ex, nullptr, 0);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
             }
 #endif
@@ -1516,27 +1516,44 @@ namespace sealhip
                     return hipErrorInvalidValue; // an in-place, non-canonical launch option
                 red = 3;
             }
-            if (flags & kNttStrict)
+            // butterfly mode 2 (approximate Shoup quotient, one multiplier instruction less per butterfly): the product then
+            // lies in [0, 3p), every layer adds 3p instead of 2p and the outputs are below 50p (kNttAnyRep) or 5p. Only where
+            // the consumer reduces whatever representative it reads, nothing expects the [0, 4p) range (no canonicalising
+            // wrapper, no kNttReduceOut) and 50p cannot wrap: every live prime below 2^58.
+            static const bool no_apx = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
+            bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0;
+            for (int i = 0; apx && i < live.n; i++)
+                apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
+            if (apx)
+            {
+                if (red == 2)
+                    SEALHIP_FWD_HALF(2, 2);
+                else if (red == 1)
+                    SEALHIP_FWD_HALF(2, 1);
+                else
+                    SEALHIP_FWD_HALF(2, 0);
+            }
+            else if (flags & kNttStrict)
             {
                 if (red == 3)
-                    SEALHIP_FWD_HALF(true, 3);
+                    SEALHIP_FWD_HALF(1, 3);
                 else if (red == 2)
-                    SEALHIP_FWD_HALF(true, 2);
+                    SEALHIP_FWD_HALF(1, 2);
                 else if (red == 1)
-                    SEALHIP_FWD_HALF(true, 1);
+                    SEALHIP_FWD_HALF(1, 1);
                 else
-                    SEALHIP_FWD_HALF(true, 0);
+                    SEALHIP_FWD_HALF(1, 0);
             }
             else
             {
                 if (red == 3)
-                    SEALHIP_FWD_HALF(false, 3);
+                    SEALHIP_FWD_HALF(0, 3);
                 else if (red == 2)
-                    SEALHIP_FWD_HALF(false, 2);
+                    SEALHIP_FWD_HALF(0, 2);
                 else if (red == 1)
-                    SEALHIP_FWD_HALF(false, 1);
+                    SEALHIP_FWD_HALF(0, 1);
                 else
-                    SEALHIP_FWD_HALF(false, 0);
+                    SEALHIP_FWD_HALF(0, 0);
             }
 #undef SEALHIP_FWD_HALF
             return hipGetLastError();
@@ -1547,14 +1564,17 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[8] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 3>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 3>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 0>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 1>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, false, 2>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 0>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 1>),
-                                   reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, true, 2>) };
+            const void *fwd[11] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 3>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 3>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 0>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 1>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 2>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 0>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 1>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 2>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 2, 0>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 2, 1>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 2, 2>) };
             for (const void *f : fwd)
             {
                 err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

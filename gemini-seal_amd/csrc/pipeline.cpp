@@ -191,7 +191,7 @@ namespace sealhip
                         ns.code[r] = static_cast<unsigned short>(j | (p_src <= p_dst ? 0 : kSrcReduce));
                     }
                     // (the inner product reduces canonically: any representative of the transformed rows will do)
-                    check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, kNttAnyRep), "ntt(ext, gathered)");
+                    check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, kNttAnyRep | kNttApprox), "ntt(ext, gathered)");
                 }
                 else
                     check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
@@ -338,12 +338,14 @@ namespace sealhip
                 // two launches over disjoint rows: the q rows only feed the tensor product, which reduces canonically, so
                 // their last layer may skip its Barrett step (kNttAnyRep); the 60-bit Bsk rows wrap in the reference (F2)
                 // and keep its exact sequence. (The fused tensor product multiplies the q rows without reducing them first
-                // and needs them below 4p: there the last layer keeps its Barrett step.)
+                // and needs them below 5p: there the last layer keeps its Barrett step.) kNttApprox: the approximate Shoup
+                // quotient where every prime is below 2^58 (one multiplier instruction less per butterfly).
                 RowMap mq = big, mb = big;
                 for (int s = 0; s < sin; s++)
                     for (int r = 0; r < kb; r++)
                         (r < k ? mb : mq).prime[s * kb + r] = kSkipRow;
-                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, fused_tensor ? 0 : kNttAnyRep), "ntt(X, gathered q rows)");
+                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, fused_tensor ? kNttApprox : (kNttAnyRep | kNttApprox)),
+                      "ntt(X, gathered q rows)");
                 // (fused tensor product: the wrapped Bsk words are brought below 2p as they are stored -- the residue class
                 //  is all the dyadic product depends on)
                 check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? kNttReduceOut : 0), "ntt(X, Bsk rows)");
