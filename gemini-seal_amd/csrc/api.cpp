@@ -338,6 +338,21 @@ long sealhip_synchronize(sealhip_context *ctx)
     });
 }
 
+long sealhip_context_lane_count(sealhip_context *ctx, uint32_t *lanes)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(lanes);
+    return guarded([&] {
+        Engine &e = *ctx->engine;
+        *lanes = 0;
+        if (e.lanes)
+        {
+            std::lock_guard<std::mutex> lock(e.lanes->mu);
+            *lanes = static_cast<uint32_t>(e.lanes->all.size());
+        }
+    });
+}
+
 long sealhip_debug_ntt_handoff(sealhip_context *ctx, uint32_t spin_limit, int32_t suppress_signal)
 {
     REQUIRE_PTR(ctx);
@@ -773,6 +788,103 @@ long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, 
     });
 }
 
+namespace
+{
+    // Evaluator::multiply (evaluator.cpp:235-527) on device batches
+    void do_multiply(Engine &e, uint32_t k, const u64 *a, uint32_t size_a, const u64 *b, uint32_t size_b, size_t count, u64 *out)
+    {
+        check_level(e, k);
+        // SEAL_CIPHERTEXT_SIZE_MIN/MAX (util/defines.h:56-57)
+        if (size_a < 2 || size_b < 2 || size_a + size_b - 1 > 16)
+            throw std::invalid_argument("encrypted1 or encrypted2 is not valid for encryption parameters");
+        if (out == a || out == b)
+            throw std::invalid_argument("out must not alias an operand");
+        if (e.scheme == 1)
+            op_bfv_multiply(e, static_cast<int>(k), a, static_cast<int>(size_a), b, static_cast<int>(size_b), count, out);
+        else
+            op_ckks_multiply(e, static_cast<int>(k), a, static_cast<int>(size_a), b, static_cast<int>(size_b), count, out);
+    }
+
+    // relinearize_internal (evaluator.cpp:772-827) on a device batch
+    void do_relinearize(Engine &e, uint32_t k, u64 *p, uint32_t size, size_t count, const sealhip_kswitch_key *const *relin_keys,
+                        uint32_t n_relin_keys)
+    {
+        check_level(e, k);
+        if (size < 2 || size > 16)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (size == 2)
+            return; // evaluator.cpp:798-802
+        if (!relin_keys || n_relin_keys < size - 2)
+            throw std::invalid_argument("not enough relinearization keys"); // :793-796
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        // :811-815 -- the target stays the LAST polynomial for every step, exactly like the reference
+        for (uint32_t I = 0; I + 2 < size; I++)
+        {
+            const uint32_t key_power = size - 1 - I;
+            const sealhip_kswitch_key *key = relin_keys[key_power - 2];
+            if (!key)
+                throw std::invalid_argument("not enough relinearization keys");
+            op_switch_key(e, static_cast<int>(k), p, size * poly, p + (size - 1) * poly, size * poly, count, key->key);
+        }
+    }
+
+    // rotate_internal (evaluator.cpp:1945-2000) on a device batch of size-2 ciphertexts
+    void do_rotate(Engine &e, uint32_t k, u64 *ct, size_t count, int32_t steps, const uint32_t *galois_elts,
+                   const sealhip_kswitch_key *const *galois_keys, uint32_t n_keys)
+    {
+        check_level(e, k);
+        std::function<void(int)> rotate = [&](int st) {
+            if (st == 0)
+                return;
+            const std::uint32_t elt = host_galois_elt_from_step(e.n, st);
+            for (uint32_t i = 0; i < n_keys; i++)
+                if (galois_elts[i] == elt)
+                {
+                    if (!galois_keys[i])
+                        throw std::invalid_argument("Galois key not present");
+                    op_apply_galois(e, static_cast<int>(k), ct, count, elt, galois_keys[i]->key);
+                    return;
+                }
+            // non-adjacent form, util/numth.h:22-42
+            std::vector<int> naf;
+            {
+                const bool sign = st < 0;
+                int value = std::abs(st);
+                for (int i = 0; value; i++)
+                {
+                    const int zi = (value % 2) ? 2 - (value % 4) : 0;
+                    value = (value - zi) / 2;
+                    if (zi)
+                        naf.push_back((sign ? -zi : zi) * (1 << i));
+                }
+            }
+            if (naf.size() == 1)
+                throw std::invalid_argument("Galois key not present");
+            for (int s : naf)
+                if (static_cast<std::size_t>(std::abs(s)) != (e.n >> 1))
+                    rotate(s);
+        };
+        rotate(steps);
+    }
+
+    // mod_switch_to_next (evaluator.cpp:996-1036) / rescale_to_next (:1090-1126) on a device batch
+    void do_level_down(Engine &e, uint32_t k, const u64 *in, uint32_t size, size_t count, u64 *o, bool rescale)
+    {
+        check_level(e, k);
+        if (k < 2)
+            throw std::invalid_argument("end of modulus switching chain reached");
+        if (rescale && e.scheme != 2)
+            throw std::invalid_argument("unsupported operation for scheme type"); // evaluator.cpp:1108-1109
+        if (rescale || e.scheme == 1)
+            op_mod_switch_scale(e, static_cast<int>(k), in, static_cast<int>(size), count, o);
+        else
+            // mod_switch_drop_to_next (evaluator.cpp:894-957): keep the first k-1 rows of every polynomial
+            check_launch(launch_copy_rows(e, in, static_cast<std::size_t>(k) * e.n, o, static_cast<std::size_t>(k - 1) * e.n,
+                                          count * size, static_cast<int>(k - 1)),
+                         "mod_switch_drop");
+    }
+} // namespace
+
 /* ---------------------------------------------------------------- Evaluator level */
 long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a,
                                 const uint64_t *b, uint32_t size_b, size_t count, uint64_t *out)
@@ -783,20 +895,8 @@ long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        check_level(e, k);
-        // SEAL_CIPHERTEXT_SIZE_MIN/MAX (util/defines.h:56-57)
-        if (size_a < 2 || size_b < 2 || size_a + size_b - 1 > 16)
-            throw std::invalid_argument("encrypted1 or encrypted2 is not valid for encryption parameters");
-        if (out == a || out == b)
-            throw std::invalid_argument("out must not alias an operand");
-        if (e.scheme == 1)
-            op_bfv_multiply(e, static_cast<int>(k), reinterpret_cast<const u64 *>(a), static_cast<int>(size_a),
-                            reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), count,
-                            reinterpret_cast<u64 *>(out));
-        else
-            op_ckks_multiply(e, static_cast<int>(k), reinterpret_cast<const u64 *>(a), static_cast<int>(size_a),
-                             reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), count,
-                             reinterpret_cast<u64 *>(out));
+        do_multiply(e, k, reinterpret_cast<const u64 *>(a), size_a, reinterpret_cast<const u64 *>(b), size_b, count,
+                    reinterpret_cast<u64 *>(out));
     });
 }
 
@@ -832,25 +932,132 @@ long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *c
     REQUIRE_PTR(ct);
     return guarded([&] {
         Engine &e = device_engine(ctx);
+        do_relinearize(e, k, reinterpret_cast<u64 *>(ct), size, count, relin_keys, n_relin_keys);
+    });
+}
+
+/* ---------------------------------------------------------------- batches of separately allocated HOST ciphertexts */
+long sealhip_evaluator_multiply_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *a, uint32_t size_a,
+                                     const uint64_t *const *b, uint32_t size_b, size_t count, uint64_t *const *out,
+                                     const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys)
+{
+    REQUIRE_PTR(ctx);
+    if (count)
+    {
+        REQUIRE_PTR(a);
+        REQUIRE_PTR(b);
+        REQUIRE_PTR(out);
+    }
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (size_a < 2 || size_b < 2 || size_a + size_b - 1 > 16)
+            throw std::invalid_argument("encrypted1 or encrypted2 is not valid for encryption parameters");
+        const uint32_t dest = size_a + size_b - 1;
+        const bool relin = relin_keys != nullptr && dest > 2;
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        HostBatchIO io;
+        io.in.push_back({ reinterpret_cast<const u64 *const *>(a), size_a * poly });
+        io.in.push_back({ reinterpret_cast<const u64 *const *>(b), size_b * poly });
+        io.out.push_back({ reinterpret_cast<u64 *const *>(out), (relin ? 2 : dest) * poly });
+        io.tmp_words = relin ? dest * poly : 0;
+        run_host_batch(e, io, count, [&](Engine &en, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *tmp,
+                                         std::size_t m) {
+            if (!relin)
+                return do_multiply(en, k, d_in[0], size_a, d_in[1], size_b, m, d_out[0]);
+            do_multiply(en, k, d_in[0], size_a, d_in[1], size_b, m, tmp);
+            do_relinearize(en, k, tmp, dest, m, relin_keys, n_relin_keys);
+            check_launch(launch_copy_rows(en, tmp, dest * poly, d_out[0], 2 * poly, m, static_cast<int>(2 * k)), "resize"); // :819
+        });
+    });
+}
+
+long sealhip_evaluator_relinearize_host(sealhip_context *ctx, uint32_t k, uint64_t *const *ct, uint32_t size, size_t count,
+                                        const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys)
+{
+    REQUIRE_PTR(ctx);
+    if (count)
+        REQUIRE_PTR(ct);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
         check_level(e, k);
         if (size < 2 || size > 16)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (size == 2)
-            return; // evaluator.cpp:798-802
-        if (!relin_keys || n_relin_keys < size - 2)
-            throw std::invalid_argument("not enough relinearization keys"); // :793-796
+            return;
         const std::size_t poly = static_cast<std::size_t>(k) * e.n;
-        u64 *p = reinterpret_cast<u64 *>(ct);
-        // :811-815 -- the target stays the LAST polynomial for every step, exactly like the reference
-        for (uint32_t I = 0; I + 2 < size; I++)
-        {
-            const uint32_t key_power = size - 1 - I;
-            const sealhip_kswitch_key *key = relin_keys[key_power - 2];
-            if (!key)
-                throw std::invalid_argument("not enough relinearization keys");
-            op_switch_key(e, static_cast<int>(k), p, size * poly, p + (size - 1) * poly, size * poly, count, key->key);
-        }
+        HostBatchIO io;
+        io.in.push_back({ reinterpret_cast<const u64 *const *>(ct), size * poly });
+        io.out.push_back({ reinterpret_cast<u64 *const *>(ct), 2 * poly });
+        run_host_batch(e, io, count, [&](Engine &en, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *,
+                                         std::size_t m) {
+            do_relinearize(en, k, d_in[0], size, m, relin_keys, n_relin_keys);
+            check_launch(launch_copy_rows(en, d_in[0], size * poly, d_out[0], 2 * poly, m, static_cast<int>(2 * k)), "resize");
+        });
     });
+}
+
+long sealhip_evaluator_rotate_vector_host(sealhip_context *ctx, uint32_t k, uint64_t *const *ct, size_t count, int32_t steps,
+                                          const uint32_t *galois_elts, const sealhip_kswitch_key *const *galois_keys,
+                                          uint32_t n_keys)
+{
+    REQUIRE_PTR(ctx);
+    if (count)
+        REQUIRE_PTR(ct);
+    if (n_keys)
+    {
+        REQUIRE_PTR(galois_elts);
+        REQUIRE_PTR(galois_keys);
+    }
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        const std::size_t item = 2 * static_cast<std::size_t>(k) * e.n;
+        HostBatchIO io;
+        io.in.push_back({ reinterpret_cast<const u64 *const *>(ct), item });
+        io.out.push_back({ reinterpret_cast<u64 *const *>(ct), item });
+        run_host_batch(e, io, count, [&](Engine &en, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *,
+                                         std::size_t m) {
+            do_rotate(en, k, d_in[0], m, steps, galois_elts, galois_keys, n_keys);
+            SEALHIP_CHECK(hipMemcpyAsync(d_out[0], d_in[0], m * item * sizeof(u64), hipMemcpyDeviceToDevice, en.lane().stream));
+        });
+    });
+}
+
+static long level_down_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size, size_t count,
+                            uint64_t *const *out, bool rescale)
+{
+    REQUIRE_PTR(ctx);
+    if (count)
+    {
+        REQUIRE_PTR(ct);
+        REQUIRE_PTR(out);
+    }
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (k < 2)
+            throw std::invalid_argument("end of modulus switching chain reached");
+        if (size < 1 || size > 16)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        HostBatchIO io;
+        io.in.push_back({ reinterpret_cast<const u64 *const *>(ct), static_cast<std::size_t>(size) * k * e.n });
+        io.out.push_back({ reinterpret_cast<u64 *const *>(out), static_cast<std::size_t>(size) * (k - 1) * e.n });
+        run_host_batch(e, io, count, [&](Engine &en, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *,
+                                         std::size_t m) { do_level_down(en, k, d_in[0], size, m, d_out[0], rescale); });
+    });
+}
+
+long sealhip_evaluator_mod_switch_to_next_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size,
+                                               size_t count, uint64_t *const *out)
+{
+    return level_down_host(ctx, k, ct, size, count, out, false);
+}
+
+long sealhip_evaluator_rescale_to_next_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size,
+                                            size_t count, uint64_t *const *out)
+{
+    return level_down_host(ctx, k, ct, size, count, out, true);
 }
 
 long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
@@ -861,18 +1068,7 @@ long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, cons
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        check_level(e, k);
-        if (k < 2)
-            throw std::invalid_argument("end of modulus switching chain reached");
-        const u64 *in = reinterpret_cast<const u64 *>(ct);
-        u64 *o = reinterpret_cast<u64 *>(out);
-        if (e.scheme == 1)
-            op_mod_switch_scale(e, static_cast<int>(k), in, static_cast<int>(size), count, o);
-        else
-            // mod_switch_drop_to_next (evaluator.cpp:894-957): keep the first k-1 rows of every polynomial
-            check_launch(launch_copy_rows(e, in, static_cast<std::size_t>(k) * e.n, o,
-                                          static_cast<std::size_t>(k - 1) * e.n, count * size, static_cast<int>(k - 1)),
-                         "mod_switch_drop");
+        do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false);
     });
 }
 
@@ -884,11 +1080,7 @@ long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const u
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        check_level(e, k);
-        if (e.scheme != 2)
-            throw std::invalid_argument("unsupported operation for scheme type"); // evaluator.cpp:1108-1109
-        op_mod_switch_scale(e, static_cast<int>(k), reinterpret_cast<const u64 *>(ct), static_cast<int>(size), count,
-                            reinterpret_cast<u64 *>(out));
+        do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), true);
     });
 }
 
@@ -1065,40 +1257,7 @@ long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t 
     }
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        check_level(e, k);
-        // rotate_internal (evaluator.cpp:1945-2000)
-        std::function<void(int)> rotate = [&](int st) {
-            if (st == 0)
-                return;
-            const std::uint32_t elt = host_galois_elt_from_step(e.n, st);
-            for (uint32_t i = 0; i < n_keys; i++)
-                if (galois_elts[i] == elt)
-                {
-                    if (!galois_keys[i])
-                        throw std::invalid_argument("Galois key not present");
-                    op_apply_galois(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), count, elt, galois_keys[i]->key);
-                    return;
-                }
-            // non-adjacent form, util/numth.h:22-42
-            std::vector<int> naf;
-            {
-                const bool sign = st < 0;
-                int value = std::abs(st);
-                for (int i = 0; value; i++)
-                {
-                    const int zi = (value % 2) ? 2 - (value % 4) : 0;
-                    value = (value - zi) / 2;
-                    if (zi)
-                        naf.push_back((sign ? -zi : zi) * (1 << i));
-                }
-            }
-            if (naf.size() == 1)
-                throw std::invalid_argument("Galois key not present");
-            for (int s : naf)
-                if (static_cast<std::size_t>(std::abs(s)) != (e.n >> 1))
-                    rotate(s);
-        };
-        rotate(steps);
+        do_rotate(e, k, reinterpret_cast<u64 *>(ct), count, steps, galois_elts, galois_keys, n_keys);
     });
 }
 

@@ -149,6 +149,8 @@ namespace sealhip
             if (r.stop)
                 (void)hipEventDestroy(r.stop);
         }
+        if (stage)
+            free_host_stage(stage);
         if (ws)
             (void)hipFree(ws);
         if (d_tickets)
@@ -257,6 +259,11 @@ namespace sealhip
         }
         else
             SEALHIP_CHECK(hipStreamSynchronize(lane().stream));
+        check_fault();
+    }
+
+    void Engine::check_fault() const
+    {
         if (h_fault && __atomic_load_n(h_fault, __ATOMIC_ACQUIRE))
         {
             __atomic_store_n(h_fault, 0u, __ATOMIC_RELEASE);

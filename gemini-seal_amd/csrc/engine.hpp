@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -186,9 +187,12 @@ namespace sealhip
     // MemoryPoolHandle of the call), so every host thread that calls into a context gets its own lane -- HIP stream,
     // temporaries arena, forward-NTT tickets, launch profiler, graph capture state -- and operations of different
     // threads overlap instead of serialising. Tables, level constants and keys are shared and immutable.
+    struct HostStage; // pinned staging buffers and copy streams of the *_host batch entries (hostbatch.cpp)
+    void free_host_stage(HostStage *s);
     struct Lane
     {
         int device = -1;
+        HostStage *stage = nullptr;
         hipStream_t stream = nullptr;
         bool own_stream = false;
         unsigned long long alloc_generation = 0; // bumps when the arena or the ticket buffer is re-allocated
@@ -200,6 +204,7 @@ namespace sealhip
         void *ws = nullptr; // workspace arena (stream-ordered reuse)
         std::size_t ws_bytes = 0, ws_used = 0;
         std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
+        std::size_t ws_budget = 0; // cap of this lane's arena, fixed at first use (pipeline.cpp)
         std::recursive_mutex busy; // held for the duration of an operation (a graph may be launched from another thread)
         ~Lane();
     };
@@ -234,6 +239,7 @@ namespace sealhip
         // stream synchronisation (sync_and_check) and fails with E_UNEXPECTED.
         unsigned *h_fault = nullptr, *d_fault = nullptr;
         void sync_and_check(bool all_lanes = false) const;
+        void check_fault() const; // the flag alone, after a synchronisation the caller has done itself
         // debug hooks of the NTT hand-off (sealhip_debug_ntt_handoff): spin limit of the sibling wait and
         // suppression of the "finished reading" signal, to drive the failure path in the tests
         unsigned ntt_spin_limit = 1u << 24;
@@ -414,6 +420,28 @@ namespace sealhip
     hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
                                       std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
                                       std::size_t ct_item_stride, std::size_t npolys, int add_into_ct);
+
+    // ---- batches of separately allocated host ciphertexts (hostbatch.cpp) ----
+    struct HostBatchIO
+    {
+        struct In
+        {
+            const u64 *const *ptrs; // one host pointer per item
+            std::size_t words;      // words per item
+        };
+        struct Out
+        {
+            u64 *const *ptrs;
+            std::size_t words;
+        };
+        std::vector<In> in;
+        std::vector<Out> out;
+        std::size_t tmp_words = 0; // device scratch per item for the chunk function
+    };
+    // enqueues the operation for m items on the calling thread's lane: d_in[a] / d_out[a] hold the items of array a back to back
+    using HostChunkFn = std::function<void(Engine &, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *d_tmp,
+                                           std::size_t m)>;
+    void run_host_batch(Engine &e, const HostBatchIO &io, std::size_t count, const HostChunkFn &fn);
 
     // ---- composed operations (pipeline.cpp) ----
     void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,

@@ -14,24 +14,31 @@ namespace sealhip
 {
     namespace
     {
-        std::size_t workspace_budget_bytes()
+        std::size_t workspace_budget_bytes(const Engine &e)
         {
-            static const std::size_t budget = [] {
-                // cap of the temporaries arena (it grows on demand up to this): SEALHIP_WORKSPACE_MB, else a sixth of
-                // the memory free on the device at first use, between 2 and 48 GiB -- sized for 288 GB of HBM, where
-                // larger chunks mean larger launches (bench: +3 % from 8 to 48 GiB)
+            // cap of a lane's temporaries arena (it grows on demand up to this): SEALHIP_WORKSPACE_MB, else a sixth of the
+            // memory free on the device when the lane first needs it, between 2 and 48 GiB -- sized for 288 GB of HBM,
+            // where larger chunks mean larger launches (bench: +3 % from 8 to 48 GiB). Fixed per lane (an operation that
+            // parks scratch at the front of the arena relies on the nested operation seeing the same cap); a lane created
+            // later sees what the earlier ones left, so the caps of all threads' lanes cannot add up to more than the device.
+            Lane &l = e.lane();
+            if (l.ws_budget)
+                return l.ws_budget;
+            static const std::size_t env_budget = [] {
                 if (const char *env = std::getenv("SEALHIP_WORKSPACE_MB"))
                 {
                     std::size_t mb = static_cast<std::size_t>(std::strtoull(env, nullptr, 10));
                     return (mb < 64 ? std::size_t(64) : mb) << 20;
                 }
-                std::size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
-                    return std::size_t(8192) << 20;
-                const std::size_t lo = std::size_t(2) << 30, hi = std::size_t(48) << 30;
-                return std::min(hi, std::max(lo, free_b / 6));
+                return std::size_t(0);
             }();
-            return budget;
+            if (env_budget)
+                return l.ws_budget = env_budget;
+            std::size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+                return l.ws_budget = std::size_t(8192) << 20;
+            const std::size_t lo = std::size_t(2) << 30, hi = std::size_t(48) << 30;
+            return l.ws_budget = std::min(hi, std::max(lo, (free_b + l.ws_bytes) / 6));
         }
 
         std::size_t pad256(std::size_t words)
@@ -42,7 +49,7 @@ namespace sealhip
         // how many items fit the arena, given the padded byte need of one item (sum over its buffers)
         std::size_t plan_chunk(Engine &e, std::size_t count, std::size_t bytes_per_item, int n_buffers)
         {
-            const std::size_t budget = workspace_budget_bytes();
+            const std::size_t budget = workspace_budget_bytes(e);
             std::size_t chunk = budget / (bytes_per_item ? bytes_per_item : 1);
             chunk = std::max<std::size_t>(1, std::min(chunk, count));
             e.ws_reserve(e.lane().ws_floor + chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
@@ -511,7 +518,7 @@ namespace sealhip
                 // size the arena now exactly as the nested op_switch_key will ask for, so that it cannot move
                 // while the scratch is live
                 const std::size_t ks_item = switch_key_item_bytes(e, k);
-                const std::size_t ks_chunk = std::max<std::size_t>(1, std::min(workspace_budget_bytes() / ks_item, m));
+                const std::size_t ks_chunk = std::max<std::size_t>(1, std::min(workspace_budget_bytes(e) / ks_item, m));
                 e.ws_reserve(e.lane().ws_floor + ks_chunk * ks_item + 4 * 256);
             }
             u64 *scratch = reinterpret_cast<u64 *>(static_cast<char *>(e.lane().ws) + guard.saved);

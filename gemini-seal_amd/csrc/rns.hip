@@ -326,13 +326,21 @@ namespace sealhip
                     ru[i] = DEFER ? pitem[i * N + c_lo] : pin[i * N];
                     rv[i] = DEFER ? pitem[i * N + c_lo + half] : 0;
                 }
-#pragma unroll
-            for (int j = 0; j < KA + 2; j++)
+            const auto load_bsk = [&](int j) {
                 if (le_B(j))
                 {
                     ru[KA + j] = DEFER ? pitem[(k + j) * N + c_lo] : pin[(k + j) * N];
                     rv[KA + j] = DEFER ? pitem[(k + j) * N + c_lo + half] : 0;
                 }
+            };
+            if constexpr (KMAX < 0)
+                static_for<KA + 2>([&](auto J) { load_bsk(J.value); });
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < KA + 2; j++)
+                    load_bsk(j);
+            }
             __builtin_amdgcn_sched_barrier(0);
             u64 t[KA];
             // mont (kernel-uniform): the input words carry the Montgomery factor 2^-64 of the tensor product formed inside
@@ -373,8 +381,7 @@ namespace sealhip
                 static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
             const auto *G1m = DEFER ? kc(d->floor_G1m_top[top_sel]) : kc(d->floor_G1m);
             const auto *G2m = kc(d->floor_G2m);
-#pragma unroll
-            for (int j = 0; j < KA + 2; j++)
+            const auto bsk_row = [&](int j) {
                 if (le_B(j))
                 {
                     const u64 bp = d->b_p[j];
@@ -404,10 +411,16 @@ namespace sealhip
                         fl_sk = v;
                     // one row's constants at a time: left alone the scheduler requests the constants of every row up front
                     // and spills scalar registers to scratch
-#if !defined(SEALHIP_FLOOR_VARIANT) || SEALHIP_FLOOR_VARIANT != 1
                     __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
+            };
+            // (compile-time row indices for an exact K: a `#pragma unroll` gives up on these loops from K = 15 on and leaves
+            //  run-time indexed register arrays, i.e. scratch)
+            if constexpr (KMAX < 0)
+                static_for<KA + 2>([&](auto J) { bsk_row(J.value); });
+            else
+                for (int j = 0; j < KA + 2; j++)
+                    bsk_row(j);
             const u64 mp = d->b_p[B];
             const auto *BtoMsk = kc(d->B_to_mskm);
             u64 lo = 0, hi = 0;
@@ -439,8 +452,7 @@ namespace sealhip
             const auto *pBm = kc(d->pBm);
             const auto *nBm = kc(d->nBm);
             const auto *BtoQ = kc(d->B_to_qm);
-            for (int i = 0; i < k; i++)
-            {
+            const auto q_row = [&](int i) {
                 const u64 c = neg ? pBm[i] : nBm[i];
                 const auto *mrow = BtoQ + i * B;
                 u64 l2, h2;
@@ -465,10 +477,13 @@ namespace sealhip
                 }
                 const u64 qp = d->q_p[i];
                 pout[i * N] = redc_finish(redc128(l2, h2, qp, d->q_ninv[i]), qp, d->q_rdp[i], small);
-#if !defined(SEALHIP_FLOOR_VARIANT) || SEALHIP_FLOOR_VARIANT != 1
                 __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
+            };
+            if constexpr (KMAX < 0)
+                static_for<KA>([&](auto I) { q_row(I.value); });
+            else
+                for (int i = 0; i < k; i++)
+                    q_row(i);
         }
 
         // fast_floor (rns.cpp:983-1023), optionally preceded by the multiplication by t of

@@ -15,6 +15,7 @@
 // Exceptions mirror the reference: std::invalid_argument / std::logic_error (evaluator.cpp:238-271).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <stdexcept>
@@ -248,6 +249,76 @@ namespace sealhip_host
             for (int s : naf)
                 if (std::size_t(s < 0 ? -s : s) != (ctx_.n() >> 1))
                     rotate_vector_inplace(encrypted, s, galois_keys);
+        }
+
+        // ---- batches: what `for (auto &ct : cts) evaluator.multiply_inplace(ct, other)` does in the reference, as one call
+        // that pipelines the separately allocated ciphertexts through the device (sealhip_evaluator_multiply_host).
+        // encrypted1[i] *= encrypted2[i]; with relin_keys the products come back relinearized (size 2).
+        void multiply_inplace(std::vector<CT *> &encrypted1, const std::vector<const CT *> &encrypted2,
+                              const std::vector<const KSwitchKeys *> *relin_keys = nullptr)
+        {
+            const std::size_t count = encrypted1.size();
+            if (count != encrypted2.size())
+                throw std::invalid_argument("encrypted1 and encrypted2 batch size mismatch");
+            if (!count)
+                return;
+            const std::size_t k = encrypted1[0]->coeff_modulus_size(), s1 = encrypted1[0]->size(), s2 = encrypted2[0]->size();
+            const bool bfv = ctx_.scheme() == SEALHIP_SCHEME_BFV;
+            for (std::size_t i = 0; i < count; i++)
+            {
+                check_pair(*encrypted1[i], *encrypted2[i]);
+                if (encrypted1[i]->coeff_modulus_size() != k || encrypted1[i]->size() != s1 || encrypted2[i]->size() != s2)
+                    throw std::invalid_argument("a batch must be uniform in level and size");
+                if (bfv && (encrypted1[i]->is_ntt_form() || encrypted2[i]->is_ntt_form()))
+                    throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
+                if (!bfv && !(encrypted1[i]->is_ntt_form() && encrypted2[i]->is_ntt_form()))
+                    throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+            }
+            const std::size_t dest = s1 + s2 - 1, out_size = relin_keys && dest > 2 ? 2 : dest;
+            std::vector<const sealhip_kswitch_key *> raw;
+            if (relin_keys)
+                for (auto *rk : *relin_keys)
+                    raw.push_back(rk ? rk->get() : nullptr);
+            // the results land in fresh buffers of the final size, then replace the operands' storage
+            std::vector<std::vector<std::uint64_t>> res(count, std::vector<std::uint64_t>(out_size * k * ctx_.n()));
+            std::vector<const std::uint64_t *> pa(count), pb(count);
+            std::vector<std::uint64_t *> po(count);
+            for (std::size_t i = 0; i < count; i++)
+            {
+                pa[i] = encrypted1[i]->data();
+                pb[i] = encrypted2[i]->data();
+                po[i] = res[i].data();
+            }
+            throw_on(sealhip_evaluator_multiply_host(ctx_.get(), std::uint32_t(k), pa.data(), std::uint32_t(s1), pb.data(),
+                                                     std::uint32_t(s2), count, po.data(), relin_keys ? raw.data() : nullptr,
+                                                     std::uint32_t(raw.size())));
+            for (std::size_t i = 0; i < count; i++)
+            {
+                encrypted1[i]->resize_raw(out_size, k);
+                std::copy(res[i].begin(), res[i].end(), encrypted1[i]->data());
+            }
+        }
+        void rotate_vector_inplace(std::vector<CT *> &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (encrypted.empty() || steps == 0)
+                return;
+            const std::size_t k = encrypted[0]->coeff_modulus_size();
+            std::vector<std::uint64_t *> p;
+            for (CT *ct : encrypted)
+            {
+                if (ct->size() != 2 || ct->coeff_modulus_size() != k)
+                    throw std::invalid_argument("encrypted size must be 2"); // :1884-1887
+                p.push_back(ct->data());
+            }
+            std::vector<std::uint32_t> elts;
+            std::vector<const sealhip_kswitch_key *> keys;
+            for (auto &kv : galois_keys)
+            {
+                elts.push_back(kv.first);
+                keys.push_back(kv.second ? kv.second->get() : nullptr);
+            }
+            throw_on(sealhip_evaluator_rotate_vector_host(ctx_.get(), std::uint32_t(k), p.data(), p.size(), steps, elts.data(),
+                                                          keys.data(), std::uint32_t(elts.size())));
         }
 
         // ---- the rest of the Evaluator surface

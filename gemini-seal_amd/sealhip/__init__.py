@@ -62,6 +62,7 @@ SYMBOLS = {
     "sealhip_set_stream": [_vp, _vp],
     "sealhip_use_default_stream": [_vp],
     "sealhip_synchronize": [_vp],
+    "sealhip_context_lane_count": [_vp, C.POINTER(_u32)],
     "sealhip_debug_ntt_handoff": [_vp, _u32, _i32],
     "sealhip_malloc": [_vp, _sz, C.POINTER(_vp)],
     "sealhip_free": [_vp, _vp],
@@ -97,6 +98,11 @@ SYMBOLS = {
     "sealhip_evaluator_multiply": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_square": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_relinearize": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
+    "sealhip_evaluator_multiply_host": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp, C.POINTER(_vp), _u32],
+    "sealhip_evaluator_relinearize_host": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
+    "sealhip_evaluator_rotate_vector_host": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
+    "sealhip_evaluator_mod_switch_to_next_host": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_rescale_to_next_host": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_mod_switch_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_rescale_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_apply_galois": [_vp, _u32, _vp, _sz, _u32, _vp],
@@ -326,6 +332,11 @@ class Context:
     def set_stream(self, stream_ptr):
         """hipStream_t of the calling thread's lane (None/0: back to a private stream)"""
         _check(lib().sealhip_set_stream(self.handle, stream_ptr))
+
+    def lane_count(self):
+        v = C.c_uint32()
+        _check(lib().sealhip_context_lane_count(self.handle, C.byref(v)))
+        return v.value
 
     def use_default_stream(self):
         _check(lib().sealhip_use_default_stream(self.handle))
@@ -611,6 +622,36 @@ class Evaluator:
         ea = (_u32 * max(1, len(elts)))(*elts)
         ka = (_vp * max(1, len(elts)))(*[galois_keys[g].handle for g in elts])
         _check(lib().sealhip_evaluator_rotate_vector(self.ctx.handle, k, _ptr(ct), count, steps, ea, ka, len(elts)))
+
+    # ---- batches of separately allocated HOST ciphertexts (lists of numpy arrays: what a vector<Ciphertext> is)
+    @staticmethod
+    def _host_ptrs(arrays):
+        for a in arrays:
+            assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+        return (C.c_void_p * max(1, len(arrays)))(*[a.ctypes.data for a in arrays])
+
+    def multiply_host(self, a, size_a, b, size_b, k, out, relin_keys=None):
+        """Evaluator::multiply (+ relinearize when relin_keys is given) over lists of host ciphertexts; out[i] is written"""
+        keys = (C.c_void_p * max(1, len(relin_keys or [])))(*[rk.handle for rk in (relin_keys or [])])
+        _check(lib().sealhip_evaluator_multiply_host(self.ctx.handle, k, self._host_ptrs(a), size_a, self._host_ptrs(b), size_b,
+                                                     len(a), self._host_ptrs(out), keys if relin_keys else None,
+                                                     len(relin_keys or [])))
+
+    def relinearize_host(self, cts, size, k, relin_keys):
+        keys = (C.c_void_p * max(1, len(relin_keys)))(*[rk.handle for rk in relin_keys])
+        _check(lib().sealhip_evaluator_relinearize_host(self.ctx.handle, k, self._host_ptrs(cts), size, len(cts), keys,
+                                                        len(relin_keys)))
+
+    def rotate_vector_host(self, cts, k, steps, galois_keys):
+        elts = list(galois_keys.keys())
+        ea = (_u32 * max(1, len(elts)))(*elts)
+        ka = (_vp * max(1, len(elts)))(*[galois_keys[g].handle for g in elts])
+        _check(lib().sealhip_evaluator_rotate_vector_host(self.ctx.handle, k, self._host_ptrs(cts), len(cts), steps, ea, ka,
+                                                          len(elts)))
+
+    def mod_switch_to_next_host(self, cts, size, k, out, rescale=False):
+        fn = lib().sealhip_evaluator_rescale_to_next_host if rescale else lib().sealhip_evaluator_mod_switch_to_next_host
+        _check(fn(self.ctx.handle, k, self._host_ptrs(cts), size, len(cts), self._host_ptrs(out)))
 
     # ---- SURVEY 8(f1): the rest of the Evaluator surface on device-resident batches
     def negate(self, ct, size, k, count, out):

@@ -91,6 +91,8 @@ long sealhip_set_stream(sealhip_context *ctx, void *hip_stream);
 long sealhip_use_default_stream(sealhip_context *ctx);
 /* waits for the work of every lane of the context (all host threads) and reports a pending device-side failure */
 long sealhip_synchronize(sealhip_context *ctx);
+/* introspection: lanes (per-thread stream + arena) the context has created so far */
+long sealhip_context_lane_count(sealhip_context *ctx, uint32_t *lanes);
 
 /* device memory helpers for hosts that do not bring their own allocator */
 long sealhip_malloc(sealhip_context *ctx, size_t bytes, void **dptr);
@@ -210,6 +212,36 @@ long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *
 long sealhip_evaluator_transform_to_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size, size_t count);
 long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size,
                                           size_t count);
+
+/* ---------------------------------------------------------------- batches of separately allocated HOST ciphertexts
+   What the reference's objects look like from C: a std::vector<seal::Ciphertext> is one separately allocated buffer per
+   ciphertext (Ciphertext::data() of each element; native/src/seal/ciphertext.h:327-392,709-721). These entries take arrays of
+   HOST pointers, one per ciphertext, and pipeline the batch through the device in chunks (SEALHIP_HOST_CHUNK, default 64):
+   host threads gather the caller's buffers into pinned staging memory, host->device copy, the operation and device->host
+   copy run on three HIP streams with two staging slots, host threads scatter the results -- so PCIe traffic in both
+   directions overlaps the kernels. The calls return when every result is in the caller's buffers (they synchronise and
+   report device-side failures). The library never frees or reallocates caller memory: every out[i] must already have room.
+
+   Evaluator::multiply (evaluator.cpp:235-527) per pair (a[i], b[i]) -> out[i]. With relin_keys != NULL the product is
+   relinearized before it leaves the device (Evaluator::relinearize_inplace, :772-827; relin_keys as in
+   sealhip_evaluator_relinearize) and out[i] receives 2 polynomials; otherwise size_a + size_b - 1. */
+long sealhip_evaluator_multiply_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *a, uint32_t size_a,
+                                     const uint64_t *const *b, uint32_t size_b, size_t count, uint64_t *const *out,
+                                     const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys);
+/* Evaluator::relinearize_inplace: ct[i] holds `size` polynomials on entry; its first 2 polynomials are the result (the
+   caller shrinks its object, evaluator.cpp:819). */
+long sealhip_evaluator_relinearize_host(sealhip_context *ctx, uint32_t k, uint64_t *const *ct, uint32_t size, size_t count,
+                                        const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys);
+/* Evaluator::rotate_vector_inplace / rotate_rows_inplace (evaluator.h:1201-1239) on size-2 ciphertexts, in place; keys as in
+   sealhip_evaluator_rotate_vector. */
+long sealhip_evaluator_rotate_vector_host(sealhip_context *ctx, uint32_t k, uint64_t *const *ct, size_t count, int32_t steps,
+                                          const uint32_t *galois_elts, const sealhip_kswitch_key *const *galois_keys,
+                                          uint32_t n_keys);
+/* Evaluator::mod_switch_to_next / rescale_to_next: ct[i] (size x k x N) -> out[i] (size x (k-1) x N) */
+long sealhip_evaluator_mod_switch_to_next_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size,
+                                               size_t count, uint64_t *const *out);
+long sealhip_evaluator_rescale_to_next_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size,
+                                            size_t count, uint64_t *const *out);
 
 /* ---------------------------------------------------------------- Evaluator surface beyond the hot path */
 /* Ciphertext batches [count][size][k][N]. Evaluator::negate_inplace (evaluator.cpp:65-88); out may alias ct. */

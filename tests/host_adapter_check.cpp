@@ -74,6 +74,53 @@ int main(int argc, char **argv)
         std::printf("f1 identities %s\n", ok ? "ok" : "FAILED");
         if (!ok)
             return 1;
+        // A batch of separately allocated ciphertexts (what a vector<Ciphertext> is): multiply + relinearize through the
+        // pointer-array entry must give, per item, what the one-at-a-time calls above give. 11 items with a chunk of 4
+        // (SEALHIP_HOST_CHUNK=4 from the test) walks the double-buffered staging pipeline through three chunks.
+        {
+            std::uint64_t st2 = 0xC0FFEE + 1;
+            for (std::size_t i = 0; i < key.size(); i++)
+                (void)splitmix(st2); // same stream position as after the key fill above
+            HostCiphertext a0, b0;
+            for (HostCiphertext *ct : { &a0, &b0 })
+            {
+                ct->n_ = n;
+                ct->resize_raw(2, k);
+                for (std::size_t s = 0; s < 2; s++)
+                    for (std::size_t r = 0; r < k; r++)
+                        for (std::size_t c2 = 0; c2 < n; c2++)
+                            ct->words[(s * k + r) * n + c2] = splitmix(st2) % mods[r];
+            }
+            HostCiphertext one_by_one = a0;
+            ev.multiply_inplace(one_by_one, b0);
+            ev.relinearize_inplace(one_by_one, { &rk });
+            const std::size_t count = 11;
+            std::vector<HostCiphertext> xs(count, a0), ys(count, b0);
+            // make the items differ (and scatter the allocations): item i gets its first word bumped by i
+            for (std::size_t i = 0; i < count; i++)
+                xs[i].words[0] = (xs[i].words[0] + i) % mods[0];
+            std::vector<HostCiphertext *> px;
+            std::vector<const HostCiphertext *> py;
+            for (std::size_t i = 0; i < count; i++)
+            {
+                px.push_back(&xs[i]);
+                py.push_back(&ys[i]);
+            }
+            const std::vector<const KSwitchKeys *> rks{ &rk };
+            ev.multiply_inplace(px, py, &rks);
+            bool batch_ok = xs[0].words == one_by_one.words && xs[0].size() == 2;
+            for (std::size_t i = 1; i < count && batch_ok; i++)
+            {
+                HostCiphertext ref = a0;
+                ref.words[0] = (ref.words[0] + i) % mods[0];
+                ev.multiply_inplace(ref, b0);
+                ev.relinearize_inplace(ref, { &rk });
+                batch_ok = xs[i].words == ref.words;
+            }
+            std::printf("host batch %s\n", batch_ok ? "ok" : "FAILED");
+            if (!batch_ok)
+                return 1;
+        }
     }
     catch (const std::exception &e)
     {

@@ -543,11 +543,13 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
     import test_host
 
     exe = test_host._build_adapter(tmp_path)
-    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, SEALHIP_HOST_CHUNK="4"))
     assert out.returncode == 0, out.stdout + out.stderr
     want = [r for r in DIG["end_to_end"] if r["cfg"] == 1][0]["digests"]["modswitch"]
     assert "modswitch digest " + want in out.stdout, out.stdout
     assert "f1 identities ok" in out.stdout, out.stdout
+    # the batch overloads: 11 separately allocated ciphertexts through the pointer-array entry in chunks of 4
+    assert "host batch ok" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("logn", [14, 15, 16])
@@ -1517,6 +1519,121 @@ def test_full_size_batched_pipeline_semantics_cfg3(sealhip):
     assert np.array_equal(decrypt_decode(ca, 2, k), (va + vb) % t)
     ev.multiply_plain_inplace(cb, 2, k, count, pa, plain_stride=n, ntt_form=False)
     assert np.array_equal(decrypt_decode(cb, 2, k), (va * vb) % t)
+
+
+# ---------------------------------------------------------------- separately allocated host ciphertexts, re-entrancy
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_host_pointer_array_entries_match_the_device_batch_path(sealhip, scheme):
+    """A std::vector<seal::Ciphertext> is one separately allocated buffer per ciphertext (ciphertext.h:709-721): the *_host
+    entries take arrays of host pointers and pipeline them through the device in chunks (default 64). 150 scattered
+    ciphertexts = three chunks, the last one ragged; every result must equal what the contiguous device-batch entries
+    produce, which the tests above pin to the oracle and the golden digests."""
+    logn, n, nsp = 12, 4096, 1
+    kmods = O.coeff_modulus_create(n, [40] * 4)
+    k, count = 3, 150
+    t = 65537 if scheme == 1 else 0
+    ctx = sealhip.Context(scheme, logn, kmods, nsp, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(31 + scheme)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    # separately allocated, differently aligned host buffers
+    ha = [a[i].copy() for i in range(count)]
+    hb = [np.ascontiguousarray(np.concatenate([np.zeros(i % 3 + 1, dtype=np.uint64), b[i].ravel()])[i % 3 + 1:]).reshape(2, k, n)
+          for i in range(count)]
+    # reference: the device-batch path
+    d3 = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, d3)
+    mul = d3.download((count, 3, k, n)).copy()
+    ev.relinearize_inplace(d3, 3, k, count, [dkey])
+    relin = d3.download((count, 3, k, n))[:, :2].copy()
+    out3 = [np.zeros((3, k, n), dtype=np.uint64) for _ in range(count)]
+    ev.multiply_host(ha, 2, hb, 2, k, out3)
+    out2 = [np.zeros((2, k, n), dtype=np.uint64) for _ in range(count)]
+    ev.multiply_host(ha, 2, hb, 2, k, out2, relin_keys=[dkey])
+    for i in range(count):
+        assert np.array_equal(out3[i], mul[i]), i
+        assert np.array_equal(out2[i], relin[i]), i
+    ev.relinearize_host(out3, 3, k, [dkey])  # in place: the first two polynomials of every buffer
+    for i in range(count):
+        assert np.array_equal(out3[i][:2], relin[i]), i
+    # level switch and rotation
+    low = ctx.alloc(count * 2 * (k - 1) * n)
+    drel = ctx.upload(relin)
+    (ev.rescale_to_next if scheme == 2 else ev.mod_switch_to_next)(drel, 2, k, count, low)
+    want_low = low.download((count, 2, k - 1, n))
+    hlow = [np.zeros((2, k - 1, n), dtype=np.uint64) for _ in range(count)]
+    ev.mod_switch_to_next_host(out2, 2, k, hlow, rescale=scheme == 2)
+    for i in range(count):
+        assert np.array_equal(hlow[i], want_low[i]), i
+    elt = ctx.galois_elt_from_step(3)
+    ev.rotate_vector_inplace(drel, k, count, 3, {elt: dkey})
+    want_rot = drel.download((count, 2, k, n))
+    ev.rotate_vector_host(out2, k, 3, {elt: dkey})
+    for i in range(count):
+        assert np.array_equal(out2[i], want_rot[i]), i
+    # errors: a null pointer in the batch, a missing key
+    with pytest.raises(ValueError):
+        ev.rotate_vector_host(out2, k, 5, {elt: dkey})
+    ev.multiply_host([], 2, [], 2, k, [])  # empty batch
+
+
+def test_context_is_reentrant_one_lane_per_thread(sealhip):
+    """seal::Evaluator is re-entrant (evaluator.h:1375-1377). Four host threads drive ONE context with different operations at
+    the same time; each gets its own lane (stream + arena), nothing serialises on a context lock, and every result equals
+    the single-threaded one."""
+    import threading
+
+    logn, n, nsp, t = 13, 8192, 1, 786433
+    kmods = O.coeff_modulus_create(n, [50] * 4)
+    k, count = 3, 6
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, nsp, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(77)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+
+    def work(which, reps, out):
+        for _ in range(reps):
+            if which == 0:
+                o = ctx.alloc(count * 3 * k * n)
+                ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, o)
+                ev.relinearize_inplace(o, 3, k, count, [dkey])
+                out[which] = o.download((count, 3, k, n))[:, :2].copy()
+            elif which == 1:
+                d = ctx.upload(a)
+                ctx.ntt_negacyclic_harvey(d, count * 2, k)
+                ctx.inverse_ntt_negacyclic_harvey(d, count * 2, k)
+                out[which] = d.download(a.shape)
+            elif which == 2:
+                res = [np.zeros((2, k, n), dtype=np.uint64) for _ in range(count)]
+                ev.multiply_host([a[i] for i in range(count)], 2, [b[i] for i in range(count)], 2, k, res, relin_keys=[dkey])
+                out[which] = np.stack(res)
+            else:
+                d = ctx.upload(a)
+                o = ctx.alloc(count * 2 * (k - 1) * n)
+                ev.mod_switch_to_next(d, 2, k, count, o)
+                out[which] = o.download((count, 2, k - 1, n))
+
+    single = {}
+    for w in range(4):
+        work(w, 1, single)
+    lanes_before = ctx.lane_count()
+    multi = {}
+    threads = [threading.Thread(target=work, args=(w, 5, multi)) for w in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    ctx.synchronize()
+    assert ctx.lane_count() >= lanes_before + 3  # (a finished thread's lane may be re-used by a later one)
+    for w in range(4):
+        assert np.array_equal(multi[w], single[w]), w
+    assert np.array_equal(single[1], a) and np.array_equal(single[0], single[2])
 
 
 # ---------------------------------------------------------------- the launch shapes bench.py is timed on
