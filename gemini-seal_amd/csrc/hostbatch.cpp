@@ -123,13 +123,23 @@ namespace sealhip
             return items;
         }
 
+        std::size_t host_threads()
+        {
+            static const std::size_t n = [] {
+                const char *env = std::getenv("SEALHIP_HOST_THREADS");
+                const std::size_t v = env ? static_cast<std::size_t>(std::strtoull(env, nullptr, 10)) : 12;
+                return v ? v : std::size_t(12);
+            }();
+            return n;
+        }
+
         // items [0, m) split over a few host threads (the copies between user buffers and the pinned staging area are
         // what a single core cannot keep up with: one core moves ~10 GB/s, the link takes ~50)
         template <class F>
         void parallel_items(std::size_t m, F &&body)
         {
             const unsigned hw = std::thread::hardware_concurrency();
-            const std::size_t nthreads = std::max<std::size_t>(1, std::min<std::size_t>({ 8, hw ? hw : 1, m }));
+            const std::size_t nthreads = std::max<std::size_t>(1, std::min<std::size_t>({ host_threads(), hw ? hw : 1, m }));
             if (nthreads == 1)
             {
                 for (std::size_t i = 0; i < m; i++)
