@@ -1235,14 +1235,21 @@ namespace sealhip
             }
         }
 
-        template <int LOGN, bool LZ, bool DY>
+        // TOPF: the top layer (gap N/2, BackwardLazyLast ntt.cpp:274-281) in the same launch. Both workgroups of a row store
+        // their lazy half (plain stores: they should stay in L2), publish it (fence + ticket), and whichever finishes SECOND
+        // -- it still holds its own half in registers -- reads the sibling's half back, applies the layer to both halves and
+        // stores the whole row. Nobody waits for anybody: the first finisher just leaves. Saves the separate streaming
+        // kernel (read N + write N from HBM) of the standalone inverse transforms.
+        template <int LOGN, bool LZ, bool DY, bool TOPF = false>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
                                                                                   std::size_t chunk,
                                                                                   const u64 *__restrict__ src,
                                                                                   std::size_t src_poly_stride,
-                                                                                  LiveSlots live, DyadicSrc dy)
+                                                                                  LiveSlots live, DyadicSrc dy,
+                                                                                  unsigned *__restrict__ tickets = nullptr,
+                                                                                  int canonical = 0)
         {
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
@@ -1313,12 +1320,73 @@ namespace sealhip
             RoundStageInv<T, 1, true, 0>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh(tid));
             RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
+            if constexpr (!TOPF)
             {
                 const int jb = Arr<T, 1>::tid_index(fresh(tid));
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
                     store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
+                }
+            }
+            else
+            {
+                const int jb = Arr<T, 1>::tid_index(fresh(tid));
+                // The half is published with agent-scope (sc1) stores: written through this XCD's L2, so the sibling can read
+                // it wherever it runs. A device-wide release fence instead would write back the whole L2 (one per XCD on this
+                // chip) for every workgroup -- measured 5x slower than the two-launch form. What remains to be ordered is
+                // "my stores have completed before my ticket": a wait for the outstanding stores (workgroup-scope fence).
+#pragma unroll
+                for (int s = 0; s < 32; s++)
+                    __hip_atomic_store(halfp + jb + Arr<T, 1>::slot_index(s), x[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                unsigned *flag = reinterpret_cast<unsigned *>(lds); // (the exchange buffer is free: the barrier above)
+                if (tid == 0)
+                    *flag = __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (*flag == 0)
+                    return; // the sibling finishes later and does the top layer for both
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                u64 *lo_half = data + (row << LOGN);
+                const u64 *sib = lo_half + ((half ^ 1) << T);
+#pragma unroll
+                for (int batch = 0; batch < 4; batch++)
+                {
+                    ulonglong2 sv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) // agent-scope loads: past any stale line of this CU's L1 / a foreign L2
+                    {
+                        const u64 *q = sib + jb + Arr<T, 1>::slot_index((batch * 4 + i) * 2);
+                        sv[i].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sv[i].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const int s = (batch * 4 + i) * 2;
+                        ulonglong2 r0, r1;
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; e2++)
+                        {
+                            const u64 mine = x[s + e2], other = e2 ? sv[i].y : sv[i].x;
+                            const u64 u = half ? other : mine, v = half ? mine : other; // u: lower half, v: upper half
+                            u64 tt = u + v;
+                            tt = tt >= two_p ? tt - two_p : tt;
+                            u64 a0 = mulmod_lazy_hs<true>(tt, P.inv_n, P.inv_n_shoup, neg_p);
+                            u64 a1 = mulmod_lazy_hs<true>(u - v + two_p, P.inv_n_w, P.inv_n_w_shoup, neg_p);
+                            if (canonical)
+                            {
+                                a0 = a0 >= p ? a0 - p : a0;
+                                a1 = a1 >= p ? a1 - p : a1;
+                            }
+                            (e2 ? r0.y : r0.x) = a0;
+                            (e2 ? r1.y : r1.x) = a1;
+                        }
+                        const int idx = jb + Arr<T, 1>::slot_index(s);
+                        store_nt(lo_half + idx, r0.x, r0.y);
+                        store_nt(lo_half + (1 << T) + idx, r1.x, r1.y);
+                    }
                 }
             }
         }
@@ -1394,14 +1462,36 @@ namespace sealhip
                 // lazy-sum schedule (InvLazy): the stored values keep their residue class and stay below 2p, but not the
                 // reference's representative -- only where the caller says so (kNttAnyRep: its inputs are below 2p and
                 // the consuming kernel canonicalises) and no live prime can wrap
+                // (the canonicalising wrapper, ntt.h:328-333, erases the representative too: its inputs are what the reference
+                //  itself requires of an inverse transform, values below 2p)
                 static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_INV") != nullptr;
-                bool lazy = (flags & kNttAnyRep) != 0 && !exact_only;
+                bool lazy = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !exact_only;
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
                 const DyadicSrc dy = dyadic ? *dyadic : DyadicSrc{};
+                // standalone transforms (top layer not left to a consumer): SEALHIP_NTT_INV_ONE_LAUNCH=1 lets the second
+                // finisher of every row apply the top layer instead of the streaming top-layer kernel. Bit-exact, measured
+                // (profiles/r02): 6.7 vs 7.4 M NTT/s at N = 2^14, 3.29 vs 3.26 at 2^15, 1.43 vs 1.41 at 2^16 -- what the
+                // second launch costs, the longer-lived workgroups cost too; so the two-launch form stays the default.
+                static const bool one_launch = std::getenv("SEALHIP_NTT_INV_ONE_LAUNCH") != nullptr;
+                const bool topf = !(flags & kNttDeferTop) && !dyadic && one_launch;
+                unsigned *tickets = topf ? e.ntt_tickets(nrows) : nullptr;
+                if (topf && !tickets)
+                    return hipErrorOutOfMemory;
 #define SEALHIP_INV_HALF(LZ_, DY_)                                                                                    \
     ntt_inv_half_kernel<LOGN, LZ_, DY_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy)
+#define SEALHIP_INV_HALF_TOP(LZ_)                                                                                      \
+    ntt_inv_half_kernel<LOGN, LZ_, false, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
+        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, tickets, (flags & kNttCanonical) ? 1 : 0)
+                if (topf)
+                {
+                    if (lazy)
+                        SEALHIP_INV_HALF_TOP(true);
+                    else
+                        SEALHIP_INV_HALF_TOP(false);
+                    return hipGetLastError();
+                }
                 if (dyadic)
                 {
                     if (lazy)
@@ -1414,6 +1504,7 @@ namespace sealhip
                 else
                     SEALHIP_INV_HALF(false, false);
 #undef SEALHIP_INV_HALF
+#undef SEALHIP_INV_HALF_TOP
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -1581,7 +1672,9 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            const void *inv[4] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false>),
+            const void *inv[6] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, false, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, true>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, true>) };
