@@ -936,6 +936,108 @@ long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *c
     });
 }
 
+/* Evaluator::multiply_many (evaluator.cpp:1180-1255) and exponentiate_inplace (:1257-1288) on device batches of size-2
+   ciphertexts: the reference's queue order -- neighbours multiplied left to right, an odd last operand appended, then
+   products of products appended until one is left -- every product relinearized. Temporaries come from the stream-ordered
+   allocator of the calling thread's lane: nothing here synchronises. */
+namespace
+{
+    void do_multiply_many(Engine &e, uint32_t k, const u64 *const *enc, std::size_t n_enc, size_t count,
+                          const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys, u64 *out)
+    {
+        check_level(e, k);
+        if (n_enc == 0)
+            throw std::invalid_argument("encrypteds vector must not be empty"); // :1185-1188
+        if (e.scheme != 1)
+            throw std::logic_error("unsupported scheme"); // :1212-1215
+        for (std::size_t i = 0; i < n_enc; i++)
+        {
+            if (!enc[i])
+                throw std::invalid_argument("encrypteds is not valid for encryption parameters");
+            if (enc[i] == out)
+                throw std::invalid_argument("encrypteds must be different from destination"); // :1193-1199
+        }
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n, two = count * 2 * poly * sizeof(u64);
+        hipStream_t stream = e.lane().stream;
+        if (n_enc == 1 || count == 0)
+        {
+            if (count)
+                SEALHIP_CHECK(hipMemcpyAsync(out, enc[0], two, hipMemcpyDeviceToDevice, stream)); // :1218-1222
+            return;
+        }
+        std::vector<void *> owned;
+        struct Cleanup
+        {
+            std::vector<void *> &v;
+            hipStream_t s;
+            ~Cleanup()
+            {
+                for (void *p : v)
+                    (void)hipFreeAsync(p, s);
+            }
+        } cleanup{ owned, stream };
+        auto product = [&](const u64 *a, const u64 *b) {
+            void *wide = nullptr, *narrow = nullptr;
+            SEALHIP_CHECK(hipMallocAsync(&wide, count * 3 * poly * sizeof(u64), stream));
+            owned.push_back(wide);
+            SEALHIP_CHECK(hipMallocAsync(&narrow, two, stream));
+            owned.push_back(narrow);
+            // (multiply(x, x) and square(x) give the same canonical residues, :1228-1235)
+            do_multiply(e, k, a, 2, b, 2, count, static_cast<u64 *>(wide));
+            do_relinearize(e, k, static_cast<u64 *>(wide), 3, count, relin_keys, n_relin_keys);
+            check_launch(launch_copy_rows(e, static_cast<u64 *>(wide), 3 * poly, static_cast<u64 *>(narrow), 2 * poly, count,
+                                          static_cast<int>(2 * k)),
+                         "resize");
+            return static_cast<const u64 *>(narrow);
+        };
+        std::vector<const u64 *> queue;
+        for (std::size_t i = 0; i + 1 < n_enc; i += 2)
+            queue.push_back(product(enc[i], enc[i + 1]));
+        if (n_enc & 1)
+            queue.push_back(enc[n_enc - 1]);
+        for (std::size_t i = 0; i + 1 < queue.size(); i += 2)
+            queue.push_back(product(queue[i], queue[i + 1]));
+        SEALHIP_CHECK(hipMemcpyAsync(out, queue.back(), two, hipMemcpyDeviceToDevice, stream));
+    }
+} // namespace
+
+long sealhip_evaluator_multiply_many(sealhip_context *ctx, uint32_t k, const uint64_t *const *encrypteds, uint32_t n_encrypteds,
+                                     size_t count, const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys,
+                                     uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(out);
+    if (n_encrypteds)
+        REQUIRE_PTR(encrypteds);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        do_multiply_many(e, k, reinterpret_cast<const u64 *const *>(encrypteds), n_encrypteds, count, relin_keys, n_relin_keys,
+                         reinterpret_cast<u64 *>(out));
+    });
+}
+
+long sealhip_evaluator_exponentiate(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint64_t exponent, size_t count,
+                                    const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        if (exponent == 0)
+            throw std::invalid_argument("exponent cannot be 0"); // :1275-1278
+        if (exponent > (1u << 16))
+            throw std::invalid_argument("exponent is too large"); // (the reference would copy the ciphertext `exponent` times)
+        if (ct == out && exponent > 1)
+            throw std::invalid_argument("out must not alias the operand");
+        // :1286-1287 -- multiply_many over `exponent` copies of the ciphertext
+        const std::vector<const u64 *> copies(static_cast<std::size_t>(exponent), reinterpret_cast<const u64 *>(ct));
+        if (exponent == 1 && ct == out)
+            return;
+        do_multiply_many(e, k, copies.data(), copies.size(), count, relin_keys, n_relin_keys, reinterpret_cast<u64 *>(out));
+    });
+}
+
 /* ---------------------------------------------------------------- batches of separately allocated HOST ciphertexts */
 long sealhip_evaluator_multiply_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *a, uint32_t size_a,
                                      const uint64_t *const *b, uint32_t size_b, size_t count, uint64_t *const *out,

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -249,6 +250,46 @@ namespace sealhip_host
             for (int s : naf)
                 if (std::size_t(s < 0 ? -s : s) != (ctx_.n() >> 1))
                     rotate_vector_inplace(encrypted, s, galois_keys);
+        }
+
+        // Evaluator::multiply_many (evaluator.cpp:1180-1255): destination = product of all, relinearized after every step
+        void multiply_many(const std::vector<CT> &encrypteds, const std::vector<const KSwitchKeys *> &relin_keys, CT &destination)
+        {
+            if (encrypteds.empty())
+                throw std::invalid_argument("encrypteds vector must not be empty"); // :1185-1188
+            for (const CT &c : encrypteds)
+                if (&c == &destination)
+                    throw std::invalid_argument("encrypteds must be different from destination"); // :1193-1199
+            const std::size_t k = encrypteds[0].coeff_modulus_size(), n = ctx_.n(), words = 2 * k * n;
+            std::vector<std::unique_ptr<Staged>> dev;
+            std::vector<const std::uint64_t *> ptrs;
+            for (const CT &c : encrypteds)
+            {
+                if (c.size() != 2 || c.coeff_modulus_size() != k || c.poly_modulus_degree() != n)
+                    throw std::invalid_argument("encrypteds is not valid for encryption parameters");
+                dev.emplace_back(new Staged(ctx_, words));
+                dev.back()->up(c.data(), words);
+                ptrs.push_back(dev.back()->ptr());
+            }
+            std::vector<const sealhip_kswitch_key *> raw;
+            for (auto *rk : relin_keys)
+                raw.push_back(rk ? rk->get() : nullptr);
+            Staged o(ctx_, words);
+            throw_on(sealhip_evaluator_multiply_many(ctx_.get(), std::uint32_t(k), ptrs.data(), std::uint32_t(ptrs.size()), 1,
+                                                     raw.data(), std::uint32_t(raw.size()), o.ptr()));
+            destination = encrypteds[0];
+            destination.resize_raw(2, k);
+            o.down(destination.data(), words);
+        }
+        // Evaluator::exponentiate_inplace (evaluator.cpp:1257-1288)
+        void exponentiate_inplace(CT &encrypted, std::uint64_t exponent, const std::vector<const KSwitchKeys *> &relin_keys)
+        {
+            if (exponent == 0)
+                throw std::invalid_argument("exponent cannot be 0"); // :1275-1278
+            if (exponent == 1)
+                return; // :1281-1284
+            const std::vector<CT> copies(static_cast<std::size_t>(exponent), encrypted);
+            multiply_many(copies, relin_keys, encrypted);
         }
 
         // ---- batches: what `for (auto &ct : cts) evaluator.multiply_inplace(ct, other)` does in the reference, as one call

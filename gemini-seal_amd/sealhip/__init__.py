@@ -98,6 +98,8 @@ SYMBOLS = {
     "sealhip_evaluator_multiply": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_square": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_relinearize": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
+    "sealhip_evaluator_multiply_many": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32, _vp],
+    "sealhip_evaluator_exponentiate": [_vp, _u32, _vp, _u64, _sz, C.POINTER(_vp), _u32, _vp],
     "sealhip_evaluator_multiply_host": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp, C.POINTER(_vp), _u32],
     "sealhip_evaluator_relinearize_host": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
     "sealhip_evaluator_rotate_vector_host": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
@@ -701,38 +703,22 @@ class Evaluator:
             self.add(out, size, c, size, k, count, out)
 
     def multiply_many(self, cts, k, count, relin_keys):
-        """Evaluator::multiply_many (evaluator.cpp:1180-1255), BFV, size-2 operands: the reference's queue order
-        (pairs left to right, odd one appended, then products of products appended until one is left), each product
-        relinearized. Returns the device buffer of the result ([count][2][k][N])."""
-        if not cts:
-            raise ValueError("encrypteds vector must not be empty")
-        if self.ctx.scheme != SCHEME_BFV:
-            raise LogicError("unsupported scheme")
-        if len(cts) == 1:
-            return self.resize(cts[0], 2, 2, k, count)
-
-        def product(a, b):
-            wide = self.ctx.alloc(count * 3 * k * self.ctx.n)
-            self.multiply(a, 2, b, 2, k, count, wide)
-            self.relinearize_inplace(wide, 3, k, count, relin_keys)
-            out = self.resize(wide, 3, 2, k, count)
-            wide.free()
-            return out
-
-        queue = [product(cts[i], cts[i + 1]) for i in range(0, len(cts) - 1, 2)]
-        if len(cts) & 1:
-            queue.append(cts[-1])
-        i = 0
-        while i < len(queue) - 1:
-            queue.append(product(queue[i], queue[i + 1]))
-            i += 2
-        return queue[-1]
+        """Evaluator::multiply_many (evaluator.cpp:1180-1255), BFV, size-2 operands, behind the C ABI
+        (sealhip_evaluator_multiply_many): the reference's queue order, each product relinearized. Returns the device buffer
+        of the result ([count][2][k][N])."""
+        out = self.ctx.alloc(count * 2 * k * self.ctx.n)
+        ptrs = (C.c_void_p * max(1, len(cts)))(*[_ptr(c) for c in cts])
+        keys = (C.c_void_p * max(1, len(relin_keys)))(*[rk.handle for rk in relin_keys])
+        _check(lib().sealhip_evaluator_multiply_many(self.ctx.handle, k, ptrs, len(cts), count, keys, len(relin_keys), _ptr(out)))
+        return out
 
     def exponentiate(self, ct, exponent, k, count, relin_keys):
-        """Evaluator::exponentiate_inplace (evaluator.cpp:1257-1288): multiply_many over `exponent` copies"""
-        if exponent == 0:
-            raise ValueError("exponent cannot be 0")
-        return self.multiply_many([ct] * int(exponent), k, count, relin_keys)
+        """Evaluator::exponentiate_inplace (evaluator.cpp:1257-1288) behind the C ABI (sealhip_evaluator_exponentiate)"""
+        out = self.ctx.alloc(count * 2 * k * self.ctx.n)
+        keys = (C.c_void_p * max(1, len(relin_keys)))(*[rk.handle for rk in relin_keys])
+        _check(lib().sealhip_evaluator_exponentiate(self.ctx.handle, k, _ptr(ct), int(exponent), count, keys, len(relin_keys),
+                                                    _ptr(out)))
+        return out
 
     def mod_switch_to(self, ct, size, k, k_target, count):
         """Evaluator::mod_switch_to_inplace (evaluator.cpp:1038-1088): mod_switch_to_next until level k_target"""

@@ -213,6 +213,17 @@ long sealhip_evaluator_transform_to_ntt(sealhip_context *ctx, uint32_t k, uint64
 long sealhip_evaluator_transform_from_ntt(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint32_t size,
                                           size_t count);
 
+/* Evaluator::multiply_many (evaluator.cpp:1180-1255), BFV: encrypteds[0..n) are device batches of count size-2 ciphertexts
+   ([count][2][k][N]); out receives their product, relinearized after every multiplication, in the reference's queue order
+   (neighbours left to right, an odd last operand appended, products of products until one is left). relin_keys as in
+   sealhip_evaluator_relinearize. out must not be one of the operands. Asynchronous (stream-ordered temporaries). */
+long sealhip_evaluator_multiply_many(sealhip_context *ctx, uint32_t k, const uint64_t *const *encrypteds, uint32_t n_encrypteds,
+                                     size_t count, const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys,
+                                     uint64_t *out);
+/* Evaluator::exponentiate_inplace (evaluator.cpp:1257-1288): multiply_many over `exponent` copies; E_INVALIDARG for 0. */
+long sealhip_evaluator_exponentiate(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint64_t exponent, size_t count,
+                                    const sealhip_kswitch_key *const *relin_keys, uint32_t n_relin_keys, uint64_t *out);
+
 /* ---------------------------------------------------------------- batches of separately allocated HOST ciphertexts
    What the reference's objects look like from C: a std::vector<seal::Ciphertext> is one separately allocated buffer per
    ciphertext (Ciphertext::data() of each element; native/src/seal/ciphertext.h:327-392,709-721). These entries take arrays of

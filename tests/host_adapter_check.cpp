@@ -120,6 +120,29 @@ int main(int argc, char **argv)
             std::printf("host batch %s\n", batch_ok ? "ok" : "FAILED");
             if (!batch_ok)
                 return 1;
+            // multiply_many / exponentiate_inplace through the adapter: x^2 == relinearize(x * x), and a three-operand product
+            // follows the reference's queue order [a0*b0, a0] -> (a0*b0)*a0
+            HostCiphertext sq = a0, want_sq = a0;
+            ev.exponentiate_inplace(sq, 2, rks);
+            ev.multiply_inplace(want_sq, a0);
+            ev.relinearize_inplace(want_sq, { &rk });
+            HostCiphertext many, want_many = one_by_one; // one_by_one = relin(a0 * b0)
+            ev.multiply_many({ a0, b0, a0 }, rks, many);
+            ev.multiply_inplace(want_many, a0);
+            ev.relinearize_inplace(want_many, { &rk });
+            bool threw = false;
+            try
+            {
+                ev.exponentiate_inplace(sq, 0, rks);
+            }
+            catch (const std::invalid_argument &)
+            {
+                threw = true;
+            }
+            const bool many_ok = sq.words == want_sq.words && many.words == want_many.words && threw;
+            std::printf("multiply_many %s\n", many_ok ? "ok" : "FAILED");
+            if (!many_ok)
+                return 1;
         }
     }
     catch (const std::exception &e)

@@ -550,6 +550,7 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
     assert "f1 identities ok" in out.stdout, out.stdout
     # the batch overloads: 11 separately allocated ciphertexts through the pointer-array entry in chunks of 4
     assert "host batch ok" in out.stdout, out.stdout
+    assert "multiply_many ok" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("logn", [14, 15, 16])
@@ -1248,6 +1249,11 @@ def test_f1_multiply_many_exponentiate_add_many_resize(sealhip):
     want = ref_product(ref_product(x, x), x)  # queue: [x*x, x] -> (x*x)*x
     got = ev.exponentiate(ctx.upload(x), 3, k, count, [rk])
     assert np.array_equal(got.download((count, 2, k, n)), want)
+    with pytest.raises(ValueError, match="exponent cannot be 0"):
+        ev.exponentiate(ctx.upload(x), 0, k, count, [rk])
+    with pytest.raises(ValueError, match="must not be empty"):
+        ev.multiply_many([], k, count, [rk])
+    assert np.array_equal(ev.exponentiate(ctx.upload(x), 1, k, count, [rk]).download(x.shape), x)
     # add_many
     out = ctx.alloc(count * 2 * k * n)
     ev.add_many([ctx.upload(c) for c in cts[:3]], 2, k, count, out)
