@@ -5,6 +5,7 @@
 #include "../../include/sealhip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -1593,6 +1594,28 @@ long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t co
     });
 }
 
+long sealhip_batch_encode_int64(sealhip_context *ctx, const int64_t *values, size_t n_values, size_t count, uint64_t *plain)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(values);
+    REQUIRE_PTR(plain);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        op_batch_encode(e, reinterpret_cast<const u64 *>(values), n_values, count, reinterpret_cast<u64 *>(plain), true);
+    });
+}
+
+long sealhip_batch_decode_int64(sealhip_context *ctx, const uint64_t *plain, size_t count, int64_t *values)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    REQUIRE_PTR(values);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        op_batch_decode(e, reinterpret_cast<const u64 *>(plain), count, reinterpret_cast<u64 *>(values), true);
+    });
+}
+
 long sealhip_ckks_encode(sealhip_context *ctx, uint32_t k, const double *values, size_t n_values, size_t count, double scale,
                          uint64_t *plain)
 {
@@ -1604,6 +1627,86 @@ long sealhip_ckks_encode(sealhip_context *ctx, uint32_t k, const double *values,
         Engine &e = device_engine(ctx);
         check_level(e, k);
         op_ckks_encode(e, static_cast<int>(k), values, n_values, count, scale, reinterpret_cast<u64 *>(plain));
+    });
+}
+
+// CKKSEncoder::encode_internal(double value, ...) (ckks.cpp:80-216): every slot holds `value`, i.e. the plaintext is the
+// constant polynomial round(value * scale), whose NTT form is that constant in every position of every row. The three
+// decomposition branches of the reference (<= 64 bits, <= 128 bits, multi-precision) are exact decompositions of one
+// integer -- a 53-bit mantissa times a power of two -- so one exact path gives their residues.
+long sealhip_ckks_encode_value(sealhip_context *ctx, uint32_t k, double value, double scale, size_t count, uint64_t *plain)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (e.scheme != 2)
+            throw std::invalid_argument("unsupported scheme"); // ckks.cpp:27-30
+        const int total_bits = e.total_coeff_modulus_bit_count(static_cast<int>(k));
+        if (scale <= 0 || (static_cast<int>(std::log2(scale)) >= total_bits))
+            throw std::invalid_argument("scale out of bounds"); // :105-109
+        value *= scale; // :112
+        const int coeff_bit_count = static_cast<int>(std::log2(std::fabs(value))) + 2;
+        if (coeff_bit_count >= total_bits)
+            throw std::invalid_argument("encoded value is too large"); // :114-118
+        double coeffd = std::round(value);
+        const bool is_negative = std::signbit(coeffd);
+        coeffd = std::fabs(coeffd);
+        int exp2 = 0;
+        const double frac = std::frexp(coeffd, &exp2);                      // coeffd = frac * 2^exp2, frac in [0.5, 1)
+        const u64 mant = static_cast<u64>(std::ldexp(frac, 53));             // exact: 53-bit mantissa
+        const int shift = exp2 - 53;                                          // coeffd = mant * 2^shift (shift may be < 0)
+        u64 rows[kMaxModuli];
+        for (uint32_t j = 0; j < k; j++)
+        {
+            const u64 q = e.key_moduli[j];
+            u64 r;
+            if (coeffd == 0)
+                r = 0;
+            else if (shift <= 0)
+                r = (mant >> (-shift)) % q; // an integer: the low -shift bits of the mantissa are zero
+            else
+            {
+                u64 pw = 1 % q, base = 2 % q; // 2^shift mod q
+                for (int s2 = shift; s2; s2 >>= 1)
+                {
+                    if (s2 & 1)
+                        pw = static_cast<u64>(static_cast<unsigned __int128>(pw) * base % q);
+                    base = static_cast<u64>(static_cast<unsigned __int128>(base) * base % q);
+                }
+                r = static_cast<u64>(static_cast<unsigned __int128>(mant % q) * pw % q);
+            }
+            rows[j] = is_negative ? (r ? q - r : 0) : r; // negate_uint_mod, :137-140
+        }
+        check_launch(launch_fill_rows(e, reinterpret_cast<u64 *>(plain), rows, static_cast<int>(k), count), "ckks encode value");
+    });
+}
+
+// CKKSEncoder::encode_internal(int64_t value, ...) (ckks.cpp:218-275): scale 1.0, residues exactly as the reference forms them
+long sealhip_ckks_encode_int64(sealhip_context *ctx, uint32_t k, int64_t value, size_t count, uint64_t *plain)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(plain);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        if (e.scheme != 2)
+            throw std::invalid_argument("unsupported scheme");
+        const u64 mag = static_cast<u64>(value < 0 ? -(value + 1) : value) + (value < 0 ? 1u : 0u); // llabs without overflow
+        const int bits = mag ? 64 - __builtin_clzll(mag) : 0;
+        if (bits + 2 >= e.total_coeff_modulus_bit_count(static_cast<int>(k)))
+            throw std::invalid_argument("encoded value is too large"); // :240-244
+        u64 rows[kMaxModuli];
+        for (uint32_t j = 0; j < k; j++)
+        {
+            const u64 q = e.key_moduli[j];
+            u64 tmp = static_cast<u64>(value);
+            if (value < 0)
+                tmp += q; // :254-257 (wrapping, as written there)
+            rows[j] = tmp % q;
+        }
+        check_launch(launch_fill_rows(e, reinterpret_cast<u64 *>(plain), rows, static_cast<int>(k), count), "ckks encode int64");
     });
 }
 

@@ -341,6 +341,7 @@ namespace sealhip
     hipError_t launch_tensor_product(const Engine &e, const u64 *a, int sa, std::size_t a_stride, const u64 *b, int sb,
                                      std::size_t b_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                      const RowMap &map);
+    hipError_t launch_fill_rows(const Engine &e, u64 *dst, const u64 *row_values, int rows, std::size_t count);
     hipError_t launch_copy_rows(const Engine &e, const u64 *src, std::size_t src_poly_stride, u64 *dst,
                                 std::size_t dst_poly_stride, std::size_t npolys, int rows);
 
@@ -490,7 +491,8 @@ namespace sealhip
     hipError_t launch_rlwe_stage(const Engine &e, int stage, const RlweArgs &a, std::size_t count);
     hipError_t launch_scaling_variant(const Engine &e, const ScalingArgs &a, std::size_t count);
     hipError_t launch_batch_permute(const Engine &e, bool encode, const u64 *in, std::size_t in_item_stride,
-                                    std::size_t nvalues, u64 *out, const std::uint32_t *map, std::size_t count);
+                                    std::size_t nvalues, u64 *out, const std::uint32_t *map, std::size_t count,
+                                    u64 signed_t = 0);
     // util/rlwe.cpp:204-300: ct[item] = ([-(a*s + e)]_q, a) over key primes 0..rows-1; a_ntt = count x rows x N
     // uniform words in NTT form, e = count x N, sk_ntt = rows x N (row stride N)
     void op_encrypt_zero_symmetric(Engine &e, int rows, bool is_ntt_form, const u64 *a_ntt, const std::int32_t *noise,
@@ -502,8 +504,8 @@ namespace sealhip
     void op_scaling_variant(Engine &e, int k, const u64 *plain, std::size_t plain_item_stride, u64 *ct,
                             std::size_t ct_item_stride, std::size_t count, bool sub);
     // batchencoder.cpp:113-154 / :339-376 (needs a prime plain modulus = 1 mod 2N: Engine::plain_prime >= 0)
-    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain);
-    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values);
+    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain, bool is_signed = false);
+    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values, bool is_signed = false);
 
     // CKKSEncoder (ckks_encoder.hip)
     hipError_t launch_ckks_encode_front(const Engine &e, const double *values, std::size_t n_values, std::size_t count,

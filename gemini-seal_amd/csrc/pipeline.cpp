@@ -751,16 +751,17 @@ namespace sealhip
         }
     } // namespace
 
-    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain)
+    void op_batch_encode(Engine &e, const u64 *values, std::size_t nvalues, std::size_t count, u64 *plain, bool is_signed)
     {
         const RowMap map = plain_row_map(e);
         if (nvalues > e.n)
             throw std::logic_error("values_matrix size is too large"); // batchencoder.cpp:119-122
-        check(launch_batch_permute(e, true, values, nvalues, nvalues, plain, e.batch_map(), count), "batch scatter");
+        check(launch_batch_permute(e, true, values, nvalues, nvalues, plain, e.batch_map(), count, is_signed ? e.t : 0),
+              "batch scatter");
         check(launch_ntt(e, plain, count, map, true, kNttCanonical), "intt(plain)");
     }
 
-    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values)
+    void op_batch_decode(Engine &e, const u64 *plain, std::size_t count, u64 *values, bool is_signed)
     {
         const RowMap map = plain_row_map(e);
         const std::size_t N = e.n;
@@ -772,7 +773,7 @@ namespace sealhip
             u64 *tmp = e.ws_alloc(N * m);
             check(launch_copy_rows(e, plain + off * N, N, tmp, N, m, 1), "copy(plain)");
             check(launch_ntt(e, tmp, m, map, false, kNttCanonical), "ntt(plain)");
-            check(launch_batch_permute(e, false, tmp, N, N, values + off * N, e.batch_map(), m), "batch gather");
+            check(launch_batch_permute(e, false, tmp, N, N, values + off * N, e.batch_map(), m, is_signed ? e.t : 0), "batch gather");
         }
     }
     // ---------------------------------------------------------------- CKKSEncoder

@@ -377,6 +377,43 @@ namespace sealhip
         return hipGetLastError();
     }
 
+    namespace
+    {
+        struct RowValues
+        {
+            u64 v[kMaxModuli];
+        };
+        // dst[count][rows][N]: row r of every item filled with vals.v[r] (the single-value CKKS encodings, ckks.cpp:80-260)
+        __global__ __launch_bounds__(kThreads) void fill_rows_kernel(u64 *__restrict__ dst, RowValues vals, int rows, int logn,
+                                                                    std::size_t npairs)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < npairs; i += stride)
+            {
+                const u64 v = vals.v[((2 * i) >> logn) % rows];
+                ulonglong2 o;
+                o.x = v;
+                o.y = v;
+                reinterpret_cast<ulonglong2 *>(dst)[i] = o;
+            }
+        }
+    } // namespace
+
+    hipError_t launch_fill_rows(const Engine &e, u64 *dst, const u64 *row_values, int rows, std::size_t count)
+    {
+        if (rows < 1 || rows > kMaxModuli)
+            return hipErrorInvalidValue;
+        const std::size_t npairs = (count * static_cast<std::size_t>(rows) << e.logn) / 2;
+        if (!npairs)
+            return hipSuccess;
+        RowValues rv{};
+        for (int r = 0; r < rows; r++)
+            rv.v[r] = row_values[r];
+        ProfScope prof(e, "fill_rows", 0);
+        fill_rows_kernel<<<grid_for(npairs), kThreads, 0, e.lane().stream>>>(dst, rv, rows, e.logn, npairs);
+        return hipGetLastError();
+    }
+
     hipError_t launch_copy_rows(const Engine &e, const u64 *src, std::size_t src_poly_stride, u64 *dst,
                                 std::size_t dst_poly_stride, std::size_t npolys, int rows)
     {

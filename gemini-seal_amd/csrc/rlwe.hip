@@ -132,8 +132,10 @@ namespace sealhip
         __global__ __launch_bounds__(kThreads) void batch_permute_kernel(const u64 *__restrict__ in, u64 *__restrict__ out,
                                                                          const std::uint32_t *__restrict__ map, int logn,
                                                                          std::size_t in_item_stride, std::size_t nvalues,
-                                                                         std::size_t total)
+                                                                         std::size_t total, u64 signed_t)
         {
+            // signed_t != 0: the int64 overloads (batchencoder.cpp:156-198, :378-420) -- negative values are stored as t + v,
+            // slot values above t/2 come back as v - t (two's complement words)
             const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
             const std::size_t n = std::size_t(1) << logn;
             for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < total; i += stride)
@@ -142,10 +144,18 @@ namespace sealhip
                 if (ENCODE)
                 {
                     const std::uint32_t src = map[n + s]; // inverse permutation: plain[s] = values[map^{-1}(s)]
-                    out[(item << logn) + s] = src < nvalues ? in[item * in_item_stride + src] : 0;
+                    u64 v = src < nvalues ? in[item * in_item_stride + src] : 0;
+                    if (signed_t && static_cast<long long>(v) < 0)
+                        v += signed_t;
+                    out[(item << logn) + s] = v;
                 }
                 else
-                    out[(item << logn) + s] = in[item * in_item_stride + map[s]];
+                {
+                    u64 v = in[item * in_item_stride + map[s]];
+                    if (signed_t && v > (signed_t >> 1))
+                        v -= signed_t;
+                    out[(item << logn) + s] = v;
+                }
             }
         }
     } // namespace
@@ -186,7 +196,7 @@ namespace sealhip
     }
 
     hipError_t launch_batch_permute(const Engine &e, bool encode, const u64 *in, std::size_t in_item_stride,
-                                    std::size_t nvalues, u64 *out, const std::uint32_t *map, std::size_t count)
+                                    std::size_t nvalues, u64 *out, const std::uint32_t *map, std::size_t count, u64 signed_t)
     {
         const std::size_t total = count * e.n;
         if (!total)
@@ -194,10 +204,10 @@ namespace sealhip
         ProfScope prof(e, "batch_permute", static_cast<double>(total));
         if (encode)
             batch_permute_kernel<true><<<grid_for(total), kThreads, 0, e.lane().stream>>>(in, out, map, e.logn, in_item_stride,
-                                                                                  nvalues, total);
+                                                                                  nvalues, total, signed_t);
         else
             batch_permute_kernel<false><<<grid_for(total), kThreads, 0, e.lane().stream>>>(in, out, map, e.logn, in_item_stride,
-                                                                                   nvalues, total);
+                                                                                   nvalues, total, signed_t);
         return hipGetLastError();
     }
 } // namespace sealhip

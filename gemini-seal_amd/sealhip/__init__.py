@@ -127,6 +127,8 @@ SYMBOLS = {
     "sealhip_context_using_batching": [_vp, C.POINTER(_i32)],
     "sealhip_batch_encode": [_vp, _vp, _sz, _sz, _vp],
     "sealhip_batch_decode": [_vp, _vp, _sz, _vp],
+    "sealhip_batch_encode_int64": [_vp, _vp, _sz, _sz, _vp],
+    "sealhip_batch_decode_int64": [_vp, _vp, _sz, _vp],
     "sealhip_context_set_parms_id": [_vp, _u32, _vp],
     "sealhip_ciphertext_peek": [_vp, _sz, _vp],
     "sealhip_ciphertext_load": [_vp, _vp, _sz, _vp, _vp, _sz],
@@ -141,6 +143,8 @@ SYMBOLS = {
     "sealhip_graph_destroy": [_vp, _vp],
     "sealhip_ckks_encode": [_vp, _u32, _vp, _sz, _sz, C.c_double, _vp],
     "sealhip_ckks_decode": [_vp, _u32, _vp, _sz, C.c_double, _vp],
+    "sealhip_ckks_encode_value": [_vp, _u32, C.c_double, C.c_double, _sz, _vp],
+    "sealhip_ckks_encode_int64": [_vp, _u32, C.c_int64, _sz, _vp],
 }
 
 
@@ -459,6 +463,16 @@ class Context:
         dv.free()
         return plain
 
+    def ckks_encode_value(self, value, k, scale, count=1, plain=None):
+        """CKKSEncoder::encode(double value, ...) (ckks.cpp:80-216); an int value takes the int64 overload (:218-275)"""
+        if plain is None:
+            plain = self.alloc(count * k * self.n)
+        if isinstance(value, (int, np.integer)):
+            _check(lib().sealhip_ckks_encode_int64(self.handle, k, int(value), count, _ptr(plain)))
+        else:
+            _check(lib().sealhip_ckks_encode_value(self.handle, k, float(value), float(scale), count, _ptr(plain)))
+        return plain
+
     def ckks_decode(self, plain, k, count, scale):
         """CKKSEncoder::decode (ckks.h:623-747) -> numpy complex array [count][N/2]"""
         out = self.alloc(count * self.n)
@@ -524,6 +538,14 @@ class Context:
     def batch_decode(self, plain, count, values):
         """BatchEncoder::decode (batchencoder.cpp:339-376)"""
         _check(lib().sealhip_batch_decode(self.handle, _ptr(plain), count, _ptr(values)))
+
+    def batch_encode_int64(self, values, n_values, count, plain):
+        """BatchEncoder::encode(vector<int64_t>) (batchencoder.cpp:156-198); values = device words holding int64"""
+        _check(lib().sealhip_batch_encode_int64(self.handle, _ptr(values), n_values, count, _ptr(plain)))
+
+    def batch_decode_int64(self, plain, count, values):
+        """BatchEncoder::decode(vector<int64_t>) (batchencoder.cpp:378-420)"""
+        _check(lib().sealhip_batch_decode_int64(self.handle, _ptr(plain), count, _ptr(values)))
 
     def negate_poly_coeffmod(self, a, count, k, result, base=BASE_Q):
         _check(lib().sealhip_negate_poly_coeffmod(self.handle, _ptr(a), count, k, base, _ptr(result)))

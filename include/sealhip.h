@@ -349,6 +349,10 @@ long sealhip_context_using_batching(const sealhip_context *ctx, int32_t *using_b
    E_INVALIDARG when the parameters do not support batching. Device memory. */
 long sealhip_batch_encode(sealhip_context *ctx, const uint64_t *values, size_t n_values, size_t count, uint64_t *plain);
 long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t count, uint64_t *values);
+/* the vector<int64_t> overloads (batchencoder.cpp:156-198, :378-420): values in (-t/2, t/2]; a negative value is stored as
+   t + v, a decoded slot above t/2 comes back as v - t */
+long sealhip_batch_encode_int64(sealhip_context *ctx, const int64_t *values, size_t n_values, size_t count, uint64_t *plain);
+long sealhip_batch_decode_int64(sealhip_context *ctx, const uint64_t *plain, size_t count, int64_t *values);
 
 /* CKKSEncoder::encode (ckks.h:405-617) / decode (:623-747), double precision. values: complex numbers as (re, im) pairs
    of doubles in device memory. encode: values[count][n_values] (n_values <= N/2; the other slots are zero) -> plain
@@ -358,6 +362,11 @@ long sealhip_batch_decode(sealhip_context *ctx, const uint64_t *plain, size_t co
 long sealhip_ckks_encode(sealhip_context *ctx, uint32_t k, const double *values, size_t n_values, size_t count, double scale,
                          uint64_t *plain);
 long sealhip_ckks_decode(sealhip_context *ctx, uint32_t k, const uint64_t *plain, size_t count, double scale, double *values);
+/* CKKSEncoder::encode(double value, ...) (ckks.cpp:80-216): `value` in every slot = the constant polynomial round(value*scale);
+   plain[count][k][N] (the same plaintext `count` times), NTT form. Errors as the reference: "scale out of bounds", "encoded
+   value is too large". sealhip_ckks_encode_int64: CKKSEncoder::encode(int64_t value, ...) (ckks.cpp:218-275), scale 1. */
+long sealhip_ckks_encode_value(sealhip_context *ctx, uint32_t k, double value, double scale, size_t count, uint64_t *plain);
+long sealhip_ckks_encode_int64(sealhip_context *ctx, uint32_t k, int64_t value, size_t count, uint64_t *plain);
 
 /* Ciphertext::resize (ciphertext.cpp:84-124) over a device-resident batch: dst[count][dst_size][k][N] receives the first
    min(src_size, dst_size) polynomials of every src[count][src_size][k][N]; added polynomials are zero (IntArray::resize).

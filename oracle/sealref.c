@@ -1792,6 +1792,30 @@ void ref_batch_encode(const ref_ntt_tables *plain_tables, const uint64_t *values
     free(map);
 }
 
+/* batchencoder.cpp:156-198: the int64 overload -- a negative value v is stored as t + v */
+void ref_batch_encode_signed(const ref_ntt_tables *plain_tables, const int64_t *values, size_t count, uint64_t *plain)
+{
+    const size_t n = plain_tables->n;
+    const uint64_t t = plain_tables->mod.value;
+    uint64_t *u = (uint64_t *)calloc(n, sizeof(uint64_t));
+    for (size_t i = 0; i < count && i < n; i++)
+        u[i] = values[i] < 0 ? t + (uint64_t)values[i] : (uint64_t)values[i];
+    ref_batch_encode(plain_tables, u, count, plain);
+    free(u);
+}
+
+/* batchencoder.cpp:378-420: the int64 overload -- slot values above t/2 come back negative */
+void ref_batch_decode_signed(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, int64_t *values)
+{
+    const size_t n = plain_tables->n;
+    const uint64_t t = plain_tables->mod.value, half = t >> 1;
+    uint64_t *u = (uint64_t *)calloc(n, sizeof(uint64_t));
+    ref_batch_decode(plain_tables, plain, count, u);
+    for (size_t i = 0; i < n; i++)
+        values[i] = u[i] > half ? (int64_t)u[i] - (int64_t)t : (int64_t)u[i];
+    free(u);
+}
+
 /* batchencoder.cpp:339-376: plaintext coefficients (count <= n) -> n values */
 void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, uint64_t *values)
 {
@@ -1895,6 +1919,78 @@ static int total_bit_count(const ref_context *c, size_t rows)
     for (size_t l = rows; l-- > 0;)
         if (q[l])
             return (int)(64 * l) + 64 - __builtin_clzll(q[l]);
+    return 0;
+}
+
+/* CKKSEncoder::encode_internal(double value, ...), ckks.cpp:80-216, branch by branch. out: rows x n (every coefficient of
+ * row j holds the residue). returns 0, -1 scale out of bounds, -2 encoded value is too large */
+int ref_ckks_encode_value(const ref_context *c, size_t rows, double value, double scale, uint64_t *out)
+{
+    const size_t n = c->n;
+    const int total_bits = total_bit_count(c, rows);
+    if (scale <= 0 || ((int)log2(scale) >= total_bits)) /* :105-109 */
+        return -1;
+    value *= scale;
+    const int coeff_bit_count = (int)log2(fabs(value)) + 2;
+    if (coeff_bit_count >= total_bits) /* :114-118 */
+        return -2;
+    const double two_pow_64 = pow(2.0, 64);
+    double coeffd = round(value);
+    const int is_negative = signbit(coeffd);
+    coeffd = fabs(coeffd);
+    for (size_t j = 0; j < rows; j++)
+    {
+        const uint64_t q = c->key_mod[j].value;
+        uint64_t r;
+        if (coeff_bit_count <= 64) /* :131-151 */
+            r = (uint64_t)fabs(coeffd) % q;
+        else if (coeff_bit_count <= 128) /* :152-176 */
+        {
+            const unsigned __int128 v =
+                ((unsigned __int128)(uint64_t)(coeffd / two_pow_64) << 64) | (uint64_t)fmod(coeffd, two_pow_64);
+            r = (uint64_t)(v % q);
+        }
+        else /* :177-209: limbs by repeated fmod / division, then the multi-precision remainder */
+        {
+            uint64_t limbs[64] = { 0 };
+            size_t nl = 0;
+            double d = coeffd;
+            while (d >= 1 && nl < 64)
+            {
+                limbs[nl++] = (uint64_t)fmod(d, two_pow_64);
+                d /= two_pow_64;
+            }
+            unsigned __int128 acc = 0;
+            for (size_t l = nl; l-- > 0;)
+                acc = ((acc << 64) | limbs[l]) % q;
+            r = (uint64_t)acc;
+        }
+        if (is_negative)
+            r = r ? q - r : 0; /* negate_uint_mod */
+        for (size_t i = 0; i < n; i++)
+            out[j * n + i] = r;
+    }
+    return 0;
+}
+
+/* CKKSEncoder::encode_internal(int64_t value, ...), ckks.cpp:218-275. returns 0, -2 encoded value is too large */
+int ref_ckks_encode_int64(const ref_context *c, size_t rows, int64_t value, uint64_t *out)
+{
+    const size_t n = c->n;
+    const uint64_t mag = value < 0 ? (uint64_t)(-(value + 1)) + 1 : (uint64_t)value;
+    const int bits = mag ? 64 - __builtin_clzll(mag) : 0;
+    if (bits + 2 >= total_bit_count(c, rows))
+        return -2;
+    for (size_t j = 0; j < rows; j++)
+    {
+        const uint64_t q = c->key_mod[j].value;
+        uint64_t tmp = (uint64_t)value;
+        if (value < 0)
+            tmp += q; /* :254-257, wrapping as written */
+        tmp %= q;
+        for (size_t i = 0; i < n; i++)
+            out[j * n + i] = tmp;
+    }
     return 0;
 }
 

@@ -225,6 +225,8 @@ void ref_multiply_add_plain_with_scaling_variant(const ref_context *c, size_t k,
 void ref_batch_index_map(int logn, uint32_t *map);
 void ref_batch_encode(const ref_ntt_tables *plain_tables, const uint64_t *values, size_t count, uint64_t *plain);
 void ref_batch_decode(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, uint64_t *values);
+void ref_batch_encode_signed(const ref_ntt_tables *plain_tables, const int64_t *values, size_t count, uint64_t *plain);
+void ref_batch_decode_signed(const ref_ntt_tables *plain_tables, const uint64_t *plain, size_t count, int64_t *values);
 /* ---- CKKSEncoder (ckks.cpp:14-77, ckks.h:405-747), double precision ---- */
 typedef struct
 {
@@ -240,6 +242,8 @@ void ref_ckks_encoder_free(ref_ckks_encoder *enc);
  * 0 ok, -1 scale out of bounds, -2 encoded values are too large */
 int ref_ckks_encode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const double *values, size_t n_values,
                     double scale, uint64_t *out);
+int ref_ckks_encode_value(const ref_context *c, size_t rows, double value, double scale, uint64_t *out);
+int ref_ckks_encode_int64(const ref_context *c, size_t rows, int64_t value, uint64_t *out);
 /* plain: rows x n (NTT form) -> n/2 complex numbers */
 int ref_ckks_decode(const ref_context *c, const ref_ckks_encoder *enc, size_t rows, const uint64_t *plain, double scale,
                     double *values);

@@ -215,11 +215,16 @@ def lib():
     L.ref_batch_encode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
     L.ref_batch_decode.restype = None
     L.ref_batch_decode.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
+    for fn in (L.ref_batch_encode_signed, L.ref_batch_decode_signed):
+        fn.restype = None
+        fn.argtypes = [C.POINTER(NttTables), C.c_void_p, szt, C.c_void_p]
     L.ref_ckks_encoder_init.argtypes = [C.POINTER(CkksEncoder), C.c_int]
     L.ref_ckks_encoder_free.argtypes = [C.POINTER(CkksEncoder)]
     L.ref_ckks_encoder_free.restype = None
     L.ref_ckks_encode.argtypes = [C.POINTER(Context), C.POINTER(CkksEncoder), szt, C.c_void_p, szt, C.c_double, C.c_void_p]
     L.ref_ckks_decode.argtypes = [C.POINTER(Context), C.POINTER(CkksEncoder), szt, C.c_void_p, C.c_double, C.c_void_p]
+    L.ref_ckks_encode_value.argtypes = [C.POINTER(Context), szt, C.c_double, C.c_double, C.c_void_p]
+    L.ref_ckks_encode_int64.argtypes = [C.POINTER(Context), szt, C.c_int64, C.c_void_p]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]

@@ -1134,6 +1134,36 @@ def test_f4_batch_encoder_parity(sealhip, logn, t):
         assert np.array_equal(res[i], exp), i
 
 
+@pytest.mark.parametrize("logn,t", [(6, 257), (13, 786433), (15, 786433)])
+def test_f4_batch_encoder_int64_overloads(sealhip, logn, t):
+    """BatchEncoder::encode / decode for vector<int64_t> (batchencoder.cpp:156-198, :378-420) on the device against the
+    oracle's restatement (pinned by BatchUnbatchIntVector's known answers in tests/test_oracle.py)."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, [50, 50])
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    tb = O.Tables(logn, t)
+    rng = np.random.default_rng(logn)
+    count = 3
+    vals = rng.integers(-(t // 2), t // 2 + 1, size=(count, n), dtype=np.int64)
+    vals[0] = -5
+    plain = ctx.alloc(count * n)
+    ctx.batch_encode_int64(ctx.upload(vals.view(np.uint64)), n, count, plain)
+    got = plain.download((count, n))
+    for i in range(count):
+        exp = np.zeros(n, dtype=np.uint64)
+        L.ref_batch_encode_signed(C.byref(tb.t), O.ptr(np.ascontiguousarray(vals[i]).view(np.uint64)), n, O.ptr(exp))
+        assert np.array_equal(got[i], exp), i
+    assert got[0, 0] == t - 5 and not got[0, 1:].any()
+    back = ctx.alloc(count * n)
+    ctx.batch_decode_int64(plain, count, back)
+    assert np.array_equal(back.download((count, n)).view(np.int64), vals)
+    nv = 20  # short input: the remaining slots are zero
+    ctx.batch_encode_int64(ctx.upload(np.ascontiguousarray(vals[:, :nv]).view(np.uint64)), nv, count, plain)
+    ctx.batch_decode_int64(plain, count, back)
+    res = back.download((count, n)).view(np.int64)
+    assert np.array_equal(res[:, :nv], vals[:, :nv]) and not res[:, nv:].any()
+
+
 def test_f4_batching_unavailable_is_reported(sealhip):
     n = 1024
     kmods = O.coeff_modulus_create(n, [40, 40])
@@ -1320,6 +1350,33 @@ def test_f4_ckks_encoder_parity(sealhip, logn, bits, scale_log2):
         low = ctx.ckks_encode(v, 1, 2.0 ** 16).download((count, 1, n))
         for i in range(count):
             assert np.array_equal(low[i], ck.encode(v[i], 1, 2.0 ** 16)[1]), i
+
+
+def test_f4_ckks_single_value_encode(sealhip):
+    """CKKSEncoder::encode(double value, ...) / encode(int64_t value, ...) (ckks.cpp:80-275) against the oracle's
+    branch-by-branch restatement, through all three decomposition regimes and both signs; error classes as the reference."""
+    logn, n = 12, 4096
+    kmods = O.coeff_modulus_create(n, [50] * 5)
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ref = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    k = 4
+    for v, scale in ((3.141592653589793, 2.0**40), (-2.718281828, 2.0**40), (12345.678, 2.0**20), (-0.3, 2.0**90),
+                     (7.0, 2.0**150), (0.0, 2.0**30), (-1e-30, 2.0**40)):
+        exp = np.zeros((k, n), dtype=np.uint64)
+        assert L.ref_ckks_encode_value(C.byref(ref.c), k, v, scale, O.ptr(exp)) == 0
+        got = ctx.ckks_encode_value(v, k, scale, count=2).download((2, k, n))
+        assert np.array_equal(got[0], exp) and np.array_equal(got[1], exp), (v, scale)
+    for iv in (0, 5, -5, 2**62, -(2**62), -(2**63)):
+        exp = np.zeros((k, n), dtype=np.uint64)
+        assert L.ref_ckks_encode_int64(C.byref(ref.c), k, iv, O.ptr(exp)) == 0
+        assert np.array_equal(ctx.ckks_encode_value(iv, k, 1.0).download((1, k, n))[0], exp), iv
+    with pytest.raises(ValueError, match="scale out of bounds"):
+        ctx.ckks_encode_value(1.0, k, 2.0**250)
+    with pytest.raises(ValueError, match="encoded value is too large"):
+        ctx.ckks_encode_value(2.0**150, k, 2.0**100)
+    # and it decodes to the value in every slot (the reference test's bound, ckks.cpp:271-275)
+    plain = ctx.ckks_encode_value(1234.5, k, 2.0**40)
+    assert np.max(np.abs(ctx.ckks_decode(plain, k, 1, 2.0**40)[0] - 1234.5)) < 0.5
 
 
 def test_f4_ckks_encoder_errors(sealhip):

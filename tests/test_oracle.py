@@ -510,6 +510,60 @@ def test_f2_asymmetric_encrypt_add_plain_semantics():
 
 
 # ---------------------------------------------------------------- BatchEncoder
+def test_f4_ckks_single_value_encode_decodes_to_the_value_in_every_slot():
+    """CKKSEncoderEncodeSingleDecodeTest (native/tests/seal/ckks.cpp:249-310): N = 64, {40} x 4, scale 2^16 -- a value below
+    2^30 encoded with encode(double) decodes to itself (|error| < 0.5) in every slot; encode(int) likewise at scale 1. Also
+    the negative and the multi-limb branches of the decomposition (:152-209) against exact Python integers."""
+    logn, n = 6, 64
+    kmods = O.coeff_modulus_create(n, [40] * 4)
+    ref = O.RefContext(2, logn, kmods, nsp=1, t=0)
+    enc = O.CkksRef(ref)
+    k = 4
+    rng = np.random.default_rng(4)
+    for _ in range(10):
+        v = float(rng.integers(0, 1 << 30))
+        out = np.zeros((k, n), dtype=np.uint64)
+        assert L.ref_ckks_encode_value(C.byref(ref.c), k, v, 2.0**16, O.ptr(out)) == 0
+        assert np.max(np.abs(enc.decode(out, 2.0**16).real - v)) < 0.5
+        iv = int(rng.integers(0, 1 << 30))
+        assert L.ref_ckks_encode_int64(C.byref(ref.c), k, iv, O.ptr(out)) == 0
+        assert np.max(np.abs(enc.decode(out, 1.0).real - iv)) < 0.5
+    for v, scale in ((-3.25, 2.0**40), (1.75, 2.0**70), (-123456.5, 2.0**100), (0.0, 2.0**20)):
+        out = np.zeros((k, n), dtype=np.uint64)
+        assert L.ref_ckks_encode_value(C.byref(ref.c), k, v, scale, O.ptr(out)) == 0
+        exact = int(round(v * scale))  # (v * scale is exact in double for these values)
+        for j in range(k):
+            assert (out[j] == exact % kmods[j]).all(), (v, j)
+    out = np.zeros((k, n), dtype=np.uint64)
+    assert L.ref_ckks_encode_value(C.byref(ref.c), k, 1.0, 2.0**200, O.ptr(out)) == -1  # scale out of bounds
+    assert L.ref_ckks_encode_value(C.byref(ref.c), k, 2.0**100, 2.0**100, O.ptr(out)) == -2  # too large
+    assert L.ref_ckks_encode_int64(C.byref(ref.c), k, -7, O.ptr(out)) == 0
+    assert all((out[j] == kmods[j] - 7).all() for j in range(k))
+
+
+def test_f4_batch_encoder_int64_reference_kats():
+    """BatchEncoderTest.BatchUnbatchIntVector (native/tests/seal/batchencoder.cpp:71-122): N = 64, t = 257; the alternating-sign
+    vector i * (1 - 2 (i % 2)) round-trips; the all -5 matrix encodes to the constant polynomial 0xFC; short inputs are
+    zero-padded."""
+    logn, n, t = 6, 64, 257
+    tb = O.Tables(logn, t)
+    vals = np.array([i * (1 - (i % 2) * 2) for i in range(n)], dtype=np.int64)
+    plain = np.zeros(n, dtype=np.uint64)
+    back = np.zeros(n, dtype=np.int64)
+    L.ref_batch_encode_signed(C.byref(tb.t), O.ptr(vals.view(np.uint64)), n, O.ptr(plain))
+    L.ref_batch_decode_signed(C.byref(tb.t), O.ptr(plain), n, O.ptr(back.view(np.uint64)))
+    assert np.array_equal(back, vals)
+    m5 = np.full(n, -5, dtype=np.int64)
+    L.ref_batch_encode_signed(C.byref(tb.t), O.ptr(m5.view(np.uint64)), n, O.ptr(plain))
+    assert plain[0] == 0xFC and not plain[1:].any()  # plain.to_string() == "FC"
+    L.ref_batch_decode_signed(C.byref(tb.t), O.ptr(plain), n, O.ptr(back.view(np.uint64)))
+    assert np.array_equal(back, m5)
+    short = np.array([i * (1 - (i & 1) * 2) for i in range(20)], dtype=np.int64)
+    L.ref_batch_encode_signed(C.byref(tb.t), O.ptr(short.view(np.uint64)), 20, O.ptr(plain))
+    L.ref_batch_decode_signed(C.byref(tb.t), O.ptr(plain), n, O.ptr(back.view(np.uint64)))
+    assert np.array_equal(back[:20], short) and not back[20:].any()
+
+
 def test_f4_batch_encoder_reference_kats_and_slot_semantics():
     """The reference's own expectations (native/tests/seal/batchencoder.cpp:18-69, 124-175: N = 64, t = 257; the all-5
     matrix encodes to the constant polynomial 5; encode/decode round-trips; short inputs are zero-padded), plus the
