@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 
+#include "blake2xb.hpp"
 #include "engine.hpp"
 
 using namespace sealhip;
@@ -28,6 +29,10 @@ namespace sealhip
     std::size_t wire_save(Engine &e, const sealhip_ciphertext_info &ci, const u64 *src, void *bytes, std::size_t capacity);
     std::uint32_t wire_load_kswitch_key(Engine &e, const void *bytes, std::size_t len, std::uint32_t index, u64 **d_out,
                                         std::size_t *words_out, std::uint64_t *dim1_out);
+    std::size_t wire_kswitch_save_size(const Engine &e, const KSwitchKey *const *keys, std::size_t n_slots);
+    std::vector<u64> wire_expand_seed(const Engine &e, int rows, const unsigned char *seed_bytes);
+    std::size_t wire_save_kswitch_keys(Engine &e, const KSwitchKey *const *keys, std::size_t n_slots, void *bytes,
+                                       std::size_t capacity);
 } // namespace sealhip
 
 struct sealhip_context
@@ -1820,6 +1825,50 @@ long sealhip_kswitch_key_load_stream(sealhip_context *ctx, const void *bytes, si
         k->key.words = words;
         k->key.d_data = dev;
         *key = k.release();
+    });
+}
+
+long sealhip_debug_blake2xb(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen)
+{
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        if (!blake2xb(out, outlen, in, inlen, key, keylen))
+            throw std::invalid_argument("blake2xb: bad arguments");
+    });
+}
+
+long sealhip_expand_seed_host(sealhip_context *ctx, uint32_t rows, const uint64_t seed[8], uint64_t *out_host)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(seed);
+    REQUIRE_PTR(out_host);
+    return guarded([&] {
+        Engine &e = *ctx->engine; // host work: also on host-only contexts
+        if (rows < 1 || static_cast<int>(rows) > e.n_key)
+            throw std::invalid_argument("level k out of range");
+        const std::vector<u64> c1 = wire_expand_seed(e, static_cast<int>(rows), reinterpret_cast<const unsigned char *>(seed));
+        std::memcpy(out_host, c1.data(), c1.size() * sizeof(u64));
+    });
+}
+
+long sealhip_kswitch_keys_save(sealhip_context *ctx, const sealhip_kswitch_key *const *keys, uint32_t n_slots, void *bytes,
+                               size_t capacity, size_t *written)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(written);
+    if (n_slots)
+        REQUIRE_PTR(keys);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        std::vector<const KSwitchKey *> raw(n_slots, nullptr);
+        for (uint32_t i = 0; i < n_slots; i++)
+            raw[i] = keys[i] ? &keys[i]->key : nullptr;
+        if (!bytes) // size query
+        {
+            *written = wire_kswitch_save_size(e, raw.data(), n_slots);
+            return;
+        }
+        *written = wire_save_kswitch_keys(e, raw.data(), n_slots, bytes, capacity);
     });
 }
 

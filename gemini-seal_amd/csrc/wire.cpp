@@ -9,6 +9,7 @@
 
 #include <cstring>
 
+#include "blake2xb.hpp"
 #include "engine.hpp"
 
 namespace sealhip
@@ -130,6 +131,20 @@ namespace sealhip
         }
     } // namespace
 
+    // Ciphertext::expand_seed (ciphertext.cpp:126-133): the rows x N words of c_1 from the 64-byte seed that follows the
+    // single stored polynomial of a seeded ciphertext (:296-309). Host work (BLAKE2Xb, sequential rejection sampling).
+    std::vector<u64> wire_expand_seed(const Engine &e, int rows, const unsigned char *seed_bytes)
+    {
+        std::uint64_t seed[8];
+        std::memcpy(seed, seed_bytes, sizeof(seed));
+        BlakePrng prng(seed);
+        std::vector<u64> c1(static_cast<std::size_t>(rows) * e.n);
+        static_assert(sizeof(u64) == sizeof(std::uint64_t), "word size");
+        sample_poly_uniform(prng, reinterpret_cast<const std::uint64_t *>(e.key_moduli.data()), static_cast<std::size_t>(rows),
+                            e.n, reinterpret_cast<std::uint64_t *>(c1.data()));
+        return c1;
+    }
+
     void wire_set_parms_id(Engine &e, int k, const std::uint64_t *id)
     {
         if (k < 1 || k > e.n_key)
@@ -154,14 +169,23 @@ namespace sealhip
         const std::uint64_t total = static_cast<std::uint64_t>(ps.info.size) * e.n * k;
         if (ps.info.data_words > total)
             throw std::logic_error("unexpected size"); // intarray.h:633-638
-        if (ps.info.seeded)
-            // expand_seed needs the reference's Blake2xb PRNG (ciphertext.cpp:301-309): the host library expands
-            // seeded ciphertexts before handing them over
-            throw std::logic_error("seeded ciphertext: expand the seed on the host before loading");
-        if (ps.info.data_words != total)
-            throw std::logic_error("ciphertext data is invalid"); // is_buffer_valid, valcheck.cpp:228-240
         if (total > capacity_words)
             throw std::invalid_argument("destination buffer is too small");
+        if (ps.info.seeded)
+        {
+            // one stored polynomial + the seed: c_0 comes from the stream, c_1 is re-sampled from the seed
+            // (ciphertext.cpp:296-309 -> expand_seed :126-133)
+            const std::size_t half = static_cast<std::size_t>(k) * e.n;
+            if (ps.info.size != 2 || ps.info.data_words != half)
+                throw std::logic_error("ciphertext data is invalid");
+            const std::vector<u64> c1 = wire_expand_seed(e, k, ps.words + half * 8);
+            SEALHIP_CHECK(hipMemcpyAsync(dst, ps.words, half * 8, hipMemcpyHostToDevice, e.lane().stream));
+            SEALHIP_CHECK(hipMemcpyAsync(dst + half, c1.data(), half * 8, hipMemcpyHostToDevice, e.lane().stream));
+            SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream));
+            return;
+        }
+        if (ps.info.data_words != total)
+            throw std::logic_error("ciphertext data is invalid"); // is_buffer_valid, valcheck.cpp:228-240
         if (total)
             SEALHIP_CHECK(hipMemcpyAsync(dst, ps.words, total * 8, hipMemcpyHostToDevice, e.lane().stream));
         SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream)); // the caller's buffer may go away after the call
@@ -214,6 +238,78 @@ namespace sealhip
         }
         return total;
     }
+    // KSwitchKeys::save (kswitchkeys.cpp:43-85 inside Serialization::Save): outer header, parms_id, keys_dim1, then per slot
+    // keys_dim2 and that many PublicKey = Ciphertext streams (size 2, key level, NTT form, scale 1.0), whose words are copied
+    // straight from the resident K1 buffer. keys[i] == nullptr: an unused slot (keys_dim2 = 0), as GaloisKeys has.
+    std::size_t wire_kswitch_save_size(const Engine &e, const KSwitchKey *const *keys, std::size_t n_slots)
+    {
+        std::size_t total = sizeof(Header) + 32 + 8;
+        for (std::size_t i = 0; i < n_slots; i++)
+            total += 8 + (keys[i] ? keys[i]->n_digits * wire_save_size(2, static_cast<std::uint32_t>(e.n_key), e.n) : 0);
+        return total;
+    }
+
+    std::size_t wire_save_kswitch_keys(Engine &e, const KSwitchKey *const *keys, std::size_t n_slots, void *bytes,
+                                       std::size_t capacity)
+    {
+        std::array<std::uint64_t, 4> pid{};
+        {
+            std::lock_guard<std::mutex> lock(e.mu);
+            const auto it = e.parms_ids.find(e.n_key);
+            if (it == e.parms_ids.end())
+                throw std::logic_error("the key level's parms_id is not registered (sealhip_context_set_parms_id)");
+            pid = it->second;
+        }
+        const std::size_t total = wire_kswitch_save_size(e, keys, n_slots);
+        if (capacity < total)
+            throw std::invalid_argument("destination buffer is too small");
+        const std::size_t digit_words = static_cast<std::size_t>(2) * e.n_key * e.n;
+        unsigned char *p = static_cast<unsigned char *>(bytes);
+        const Header outer{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, total };
+        std::memcpy(p, &outer, sizeof(outer));
+        p += sizeof(outer);
+        std::memcpy(p, pid.data(), 32);
+        const std::uint64_t dim1 = n_slots;
+        std::memcpy(p + 32, &dim1, 8);
+        p += 40;
+        const double one = 1.0;
+        for (std::size_t i = 0; i < n_slots; i++)
+        {
+            const std::uint64_t dim2 = keys[i] ? keys[i]->n_digits : 0;
+            std::memcpy(p, &dim2, 8);
+            p += 8;
+            for (std::uint64_t j = 0; j < dim2; j++)
+            {
+                if (keys[i]->words != dim2 * digit_words)
+                    throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                const std::size_t ct_total = wire_save_size(2, static_cast<std::uint32_t>(e.n_key), e.n);
+                const Header h{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, ct_total };
+                std::memcpy(p, &h, sizeof(h));
+                p += sizeof(h);
+                std::memcpy(p, pid.data(), 32);
+                p += 32;
+                *p++ = 1; // keys are kept in NTT form (keygenerator.cpp:347-352)
+                const std::uint64_t size64 = 2, n64 = e.n, k64 = static_cast<std::uint64_t>(e.n_key);
+                std::memcpy(p, &size64, 8);
+                std::memcpy(p + 8, &n64, 8);
+                std::memcpy(p + 16, &k64, 8);
+                std::memcpy(p + 24, &one, 8);
+                p += 32;
+                const Header inner{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, sizeof(Header) + 8 + digit_words * 8 };
+                std::memcpy(p, &inner, sizeof(inner));
+                p += sizeof(inner);
+                const std::uint64_t count = digit_words;
+                std::memcpy(p, &count, 8);
+                p += 8;
+                SEALHIP_CHECK(hipMemcpyAsync(p, keys[i]->d_data + j * digit_words, digit_words * 8, hipMemcpyDeviceToHost,
+                                             e.lane().stream));
+                p += digit_words * 8;
+            }
+        }
+        e.sync_and_check();
+        return total;
+    }
+
     // KSwitchKeys::load (kswitchkeys.cpp:87-150): outer header, parms_id, keys_dim1, then per index keys_dim2 and that many
     // PublicKey streams, each a complete Ciphertext stream (publickey.h:107-111). The digits of keys_[index] are
     // concatenated straight into one device buffer, which is the K1 layout (keygenerator.cpp:325-369) the key switch reads.
@@ -286,11 +382,24 @@ namespace sealhip
                             ps.info.poly_modulus_degree != e.n || !ps.info.is_ntt_form)
                             throw std::logic_error("kswitch_keys is not valid for encryption parameters");
                         if (ps.info.seeded)
-                            throw std::logic_error("seeded key: expand the seed on the host before loading");
-                        if (ps.info.data_words != digit_words)
-                            throw std::logic_error("kswitch_keys is not valid for encryption parameters");
-                        SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words, ps.words, digit_words * sizeof(u64),
-                                                     hipMemcpyHostToDevice, e.lane().stream));
+                        {
+                            // keys saved through Serializable<> carry c_1 as a seed (keygenerator.cpp:325-369 with save_seed)
+                            if (ps.info.data_words != digit_words / 2)
+                                throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                            const std::vector<u64> c1 = wire_expand_seed(e, e.n_key, ps.words + (digit_words / 2) * 8);
+                            SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words, ps.words, (digit_words / 2) * sizeof(u64),
+                                                         hipMemcpyHostToDevice, e.lane().stream));
+                            SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words + digit_words / 2, c1.data(),
+                                                         (digit_words / 2) * sizeof(u64), hipMemcpyHostToDevice, e.lane().stream));
+                            SEALHIP_CHECK(hipStreamSynchronize(e.lane().stream)); // c1 is a local buffer
+                        }
+                        else
+                        {
+                            if (ps.info.data_words != digit_words)
+                                throw std::logic_error("kswitch_keys is not valid for encryption parameters");
+                            SEALHIP_CHECK(hipMemcpyAsync(dev + j * digit_words, ps.words, digit_words * sizeof(u64),
+                                                         hipMemcpyHostToDevice, e.lane().stream));
+                        }
                     }
                     p += ps.info.total_bytes;
                 }

@@ -137,6 +137,9 @@ SYMBOLS = {
     "sealhip_is_data_valid_for": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
     "sealhip_kswitch_key_load_stream": [_vp, _vp, _sz, _u32, C.POINTER(_vp), C.POINTER(_u64)],
+    "sealhip_expand_seed_host": [_vp, _u32, _vp, _vp],
+    "sealhip_debug_blake2xb": [_vp, _sz, _vp, _sz, _vp, _sz],
+    "sealhip_kswitch_keys_save": [_vp, C.POINTER(_vp), _u32, _vp, _sz, C.POINTER(_sz)],
     "sealhip_graph_capture_begin": [_vp],
     "sealhip_graph_capture_end": [_vp, C.POINTER(_vp)],
     "sealhip_graph_launch": [_vp, _vp],
@@ -284,6 +287,25 @@ class KSwitchKeys:
                 self.handle = None
         except Exception:
             pass
+
+
+def blake2xb(outlen, data, key=b""):
+    """BLAKE2Xb of csrc/blake2xb.cpp (the PRNG under Ciphertext::expand_seed)"""
+    out = C.create_string_buffer(outlen)
+    _check(lib().sealhip_debug_blake2xb(out, outlen, data, len(data), key if key else None, len(key)))
+    return out.raw
+
+
+def save_kswitch_keys(ctx, keys):
+    """KSwitchKeys::save (kswitchkeys.cpp:43-85): keys = list of KSwitchKeys or None (unused slot) -> the reference's byte
+    stream, digit words copied straight from HBM"""
+    arr = (C.c_void_p * max(1, len(keys)))(*[(k.handle if k is not None else None) for k in keys])
+    need = _sz(0)
+    _check(lib().sealhip_kswitch_keys_save(ctx.handle, arr, len(keys), None, 0, C.byref(need)))
+    buf = (C.c_char * need.value)()
+    written = _sz(0)
+    _check(lib().sealhip_kswitch_keys_save(ctx.handle, arr, len(keys), C.addressof(buf), need.value, C.byref(written)))
+    return bytes(buf[: written.value])
 
 
 class Graph:
@@ -499,6 +521,13 @@ class Context:
     def set_parms_id(self, k, parms_id):
         arr = (C.c_uint64 * 4)(*[int(x) for x in parms_id])
         _check(lib().sealhip_context_set_parms_id(self.handle, k, C.addressof(arr)))
+
+    def expand_seed(self, rows, seed_words):
+        """Ciphertext::expand_seed (ciphertext.cpp:126-133) on the host: rows x N words of c_1"""
+        seed = np.array([int(x) for x in seed_words], dtype=np.uint64)
+        out = np.zeros((rows, self.n), dtype=np.uint64)
+        _check(lib().sealhip_expand_seed_host(self.handle, rows, seed.ctypes.data, out.ctypes.data))
+        return out
 
     def load_ciphertext(self, raw, dst, capacity_words=None):
         """Ciphertext::load (ciphertext.cpp:228-330): words go from `raw` (host bytes) straight into dst (device)"""

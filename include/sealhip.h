@@ -397,8 +397,11 @@ long sealhip_context_set_parms_id(sealhip_context *ctx, uint32_t k, const uint64
    ("loaded SEALHeader is invalid" / "incompatible version"), truncated input -> E_UNEXPECTED ("I/O error"). */
 long sealhip_ciphertext_peek(const void *bytes, size_t len, sealhip_ciphertext_info *info);
 /* Ciphertext::load (ciphertext.cpp:228-330, uncompressed stream): validates the metadata against the context and
-   copies the coefficient words from `bytes` (host) straight into dst_device (capacity in words). Seeded ciphertexts
-   are reported (info->seeded) and refused: expanding the seed needs the host library's PRNG. */
+   copies the coefficient words from `bytes` (host) straight into dst_device (capacity in words). A seeded ciphertext
+   (info->seeded: one stored polynomial + a 64-byte seed, what Encryptor::encrypt_symmetric(...).save() writes) is expanded
+   like Ciphertext::expand_seed does (:126-133): c_1 is re-sampled on the host from the seed with the reference's
+   BlakePRNG (BLAKE2Xb, randomgen.cpp:63-73) and sample_poly_uniform (util/rlwe.cpp:101-129), re-implemented in
+   csrc/blake2xb.cpp from the BLAKE2 specifications; dst_device receives both polynomials. */
 long sealhip_ciphertext_load(sealhip_context *ctx, const void *bytes, size_t len, sealhip_ciphertext_info *info,
                              uint64_t *dst_device, size_t capacity_words);
 /* Ciphertext::save_size(compr_mode_type::none) (ciphertext.cpp:135-168) and Ciphertext::save: the stream is written
@@ -409,9 +412,20 @@ long sealhip_ciphertext_save(sealhip_context *ctx, const sealhip_ciphertext_info
 /* KSwitchKeys::load (kswitchkeys.cpp:87-150; RelinKeys / GaloisKeys streams, uncompressed): loads keys_[index] -- RelinKeys:
    index = key_power - 2 (relinkeys.h:61-68), GaloisKeys: index = (galois_elt - 1) / 2 (galoiskeys.h:52-55) -- with its
    decomposition digits concatenated straight from the stream into HBM. *key = NULL when that slot is empty; n_slots (may
-   be NULL) receives keys_.size(). Needs the key level's parms_id registered (k = n_key_moduli). */
+   be NULL) receives keys_.size(). Needs the key level's parms_id registered (k = n_key_moduli). Seeded digits (keys saved
+   as Serializable<RelinKeys>) are expanded as in sealhip_ciphertext_load. */
 long sealhip_kswitch_key_load_stream(sealhip_context *ctx, const void *bytes, size_t len, uint32_t index,
                                      sealhip_kswitch_key **key, uint64_t *n_slots);
+/* Ciphertext::expand_seed on the host (works on host-only contexts): out_host[rows][N] = the words of c_1 for `seed`
+   (random_seed_type: 8 x uint64) over the first `rows` key primes. sealhip_debug_blake2xb: the BLAKE2Xb function under it. */
+long sealhip_expand_seed_host(sealhip_context *ctx, uint32_t rows, const uint64_t seed[8], uint64_t *out_host);
+long sealhip_debug_blake2xb(void *out, size_t outlen, const void *in, size_t inlen, const void *key, size_t keylen);
+/* KSwitchKeys::save (kswitchkeys.cpp:43-85 under Serialization::Save, uncompressed): writes a RelinKeys / GaloisKeys stream
+   whose keys_[i] is keys[i] (NULL = unused slot, keys_dim2 = 0) with the digit words copied straight from HBM. bytes == NULL:
+   only the size is reported in *written. Needs the key level's parms_id registered. The stream round-trips through
+   sealhip_kswitch_key_load_stream and is what the reference's KSwitchKeys::load reads. */
+long sealhip_kswitch_keys_save(sealhip_context *ctx, const sealhip_kswitch_key *const *keys, uint32_t n_slots, void *bytes,
+                               size_t capacity, size_t *written);
 /* is_data_valid_for (valcheck.cpp:284-317) on device-resident ciphertexts: valid[i] = 1 iff every coefficient of
    ciphertext i is below its row's prime (what an ingesting service checks before evaluating untrusted input). */
 long sealhip_is_data_valid_for(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,

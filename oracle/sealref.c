@@ -2358,3 +2358,158 @@ void ref_fill_rows(uint64_t *dst, size_t rows, size_t n, const uint64_t *moduli,
         for (size_t j = 0; j < n; j++)
             dst[i * n + j] = ref_splitmix64(state) % moduli[i];
 }
+
+/* ------------------------------------------------------------------------------------------
+ * seeded ciphertexts. Ciphertext::expand_seed (ciphertext.cpp:126-133) = sample_poly_uniform
+ * (util/rlwe.cpp:101-129) driven by BlakePRNG (randomgen.h:199-222, randomgen.cpp:63-73), which fills 4096-byte buffers
+ * with blake2xb(counter; key = seed) (util/blake2xb.c, vendored BLAKE2 reference code). BLAKE2b below is RFC 7693's
+ * pseudocode written out; the parameter block and the XOF construction follow the BLAKE2 / BLAKE2X specifications.
+ * Pinned by tests/golden/prng_vectors.json, generated with the reference's own blake2b.c / blake2xb.c (oracle/_ref).
+ * ---------------------------------------------------------------------------------------- */
+static const uint64_t b2_iv[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                   0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+static const uint8_t b2_sigma[10][16] = {
+    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 },
+    { 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4 }, { 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8 },
+    { 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13 }, { 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9 },
+    { 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11 }, { 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10 },
+    { 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5 }, { 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0 }
+};
+#define B2_ROTR(x, n) (((x) >> (n)) | ((x) << (64 - (n))))
+/* F(h, m, t, f): RFC 7693 section 3.2; t is the 128-bit byte counter (only its low word is ever non-zero here) */
+static void b2_F(uint64_t h[8], const uint8_t block[128], uint64_t t, int last)
+{
+    uint64_t m[16], v[16];
+    for (int i = 0; i < 16; i++)
+    {
+        m[i] = 0;
+        for (int b = 7; b >= 0; b--)
+            m[i] = (m[i] << 8) | block[8 * i + b];
+    }
+    for (int i = 0; i < 8; i++)
+    {
+        v[i] = h[i];
+        v[i + 8] = b2_iv[i];
+    }
+    v[12] ^= t;
+    if (last)
+        v[14] ^= 0xFFFFFFFFFFFFFFFFULL;
+    static const int idx[8][4] = { { 0, 4, 8, 12 }, { 1, 5, 9, 13 }, { 2, 6, 10, 14 }, { 3, 7, 11, 15 },
+                                   { 0, 5, 10, 15 }, { 1, 6, 11, 12 }, { 2, 7, 8, 13 }, { 3, 4, 9, 14 } };
+    for (int r = 0; r < 12; r++)
+    {
+        const uint8_t *sg = b2_sigma[r % 10];
+        for (int g = 0; g < 8; g++)
+        {
+            const int a = idx[g][0], b = idx[g][1], c = idx[g][2], d = idx[g][3];
+            v[a] = v[a] + v[b] + m[sg[2 * g]];
+            v[d] = B2_ROTR(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];
+            v[b] = B2_ROTR(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + m[sg[2 * g + 1]];
+            v[d] = B2_ROTR(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];
+            v[b] = B2_ROTR(v[b] ^ v[c], 63);
+        }
+    }
+    for (int i = 0; i < 8; i++)
+        h[i] ^= v[i] ^ v[i + 8];
+}
+/* one BLAKE2b instance over a message held in memory, with the full parameter block */
+static void b2_hash(uint8_t *out, unsigned outlen, const uint8_t *msg, size_t msglen, const uint8_t *key, unsigned keylen,
+                    unsigned fanout, unsigned depth, uint32_t leaf_length, uint32_t node_offset, uint32_t xof_length,
+                    unsigned inner_length)
+{
+    uint8_t p[64] = { 0 };
+    p[0] = (uint8_t)outlen;
+    p[1] = (uint8_t)keylen;
+    p[2] = (uint8_t)fanout;
+    p[3] = (uint8_t)depth;
+    for (int i = 0; i < 4; i++)
+    {
+        p[4 + i] = (uint8_t)(leaf_length >> (8 * i));
+        p[8 + i] = (uint8_t)(node_offset >> (8 * i));
+        p[12 + i] = (uint8_t)(xof_length >> (8 * i));
+    }
+    p[17] = (uint8_t)inner_length;
+    uint64_t h[8];
+    for (int i = 0; i < 8; i++)
+    {
+        uint64_t w = 0;
+        for (int b = 7; b >= 0; b--)
+            w = (w << 8) | p[8 * i + b];
+        h[i] = b2_iv[i] ^ w;
+    }
+    /* the data to compress: the key padded to one block (if any), then the message; the last block is zero padded */
+    const size_t total = (keylen ? 128 : 0) + msglen;
+    uint8_t *data = (uint8_t *)calloc(total + 128, 1);
+    if (keylen)
+        memcpy(data, key, keylen);
+    memcpy(data + (keylen ? 128 : 0), msg, msglen);
+    const size_t nblocks = total ? (total + 127) / 128 : 1;
+    for (size_t b = 0; b < nblocks; b++)
+    {
+        const int last = b + 1 == nblocks;
+        b2_F(h, data + 128 * b, last ? total : 128 * (b + 1), last);
+    }
+    free(data);
+    for (unsigned i = 0; i < outlen; i++)
+        out[i] = (uint8_t)(h[i >> 3] >> (8 * (i & 7)));
+}
+/* BLAKE2Xb (blake2xb.c:36-187): root hash with the XOF length in its parameter block, then one 64-byte-input node per
+ * output block */
+int ref_blake2xb(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen, const uint8_t *key, size_t keylen)
+{
+    if (outlen == 0 || outlen > 0xFFFFFFFFULL || keylen > 64)
+        return -1;
+    uint8_t h0[64];
+    b2_hash(h0, 64, in, inlen, key, (unsigned)keylen, 1, 1, 0, 0, (uint32_t)outlen, 0);
+    size_t done = 0;
+    for (uint32_t i = 0; done < outlen; i++)
+    {
+        const unsigned take = (unsigned)(outlen - done < 64 ? outlen - done : 64);
+        b2_hash(out + done, take, h0, 64, NULL, 0, 0, 0, 64, i, (uint32_t)outlen, 64);
+        done += take;
+    }
+    return 0;
+}
+/* expand_seed: rows x n words, row j uniform below moduli[j] (util/rlwe.cpp:101-129 over BlakePRNG) */
+void ref_expand_seed(const uint64_t seed[8], const uint64_t *moduli, size_t rows, size_t n, uint64_t *dst)
+{
+    uint8_t key[64], buffer[4096];
+    for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 8; b++)
+            key[8 * i + b] = (uint8_t)(seed[i] >> (8 * b));
+    uint64_t counter = 0;
+    size_t head = sizeof(buffer);
+    const uint64_t max_random = 0x7FFFFFFFFFFFFFFFULL;
+    for (size_t j = 0; j < rows; j++)
+    {
+        const uint64_t q = moduli[j], max_multiple = max_random - max_random % q - 1;
+        for (size_t i = 0; i < n; i++)
+        {
+            uint64_t r;
+            do
+            {
+                uint32_t w[2];
+                for (int t = 0; t < 2; t++)
+                {
+                    if (head == sizeof(buffer)) /* randomgen.cpp:63-73 */
+                    {
+                        uint8_t ctr[8];
+                        for (int b = 0; b < 8; b++)
+                            ctr[b] = (uint8_t)(counter >> (8 * b));
+                        ref_blake2xb(buffer, sizeof(buffer), ctr, 8, key, 64);
+                        counter++;
+                        head = 0;
+                    }
+                    w[t] = (uint32_t)buffer[head] | ((uint32_t)buffer[head + 1] << 8) | ((uint32_t)buffer[head + 2] << 16) |
+                           ((uint32_t)buffer[head + 3] << 24);
+                    head += 4;
+                }
+                r = ((uint64_t)w[0] << 31) | ((uint64_t)w[1] >> 1); /* rlwe.cpp:124 */
+            } while (r >= max_multiple);
+            dst[j * n + i] = r % q;
+        }
+    }
+}

@@ -269,4 +269,8 @@ void ref_fill_rows(uint64_t *dst, size_t rows, size_t n, const uint64_t *moduli,
 #ifdef __cplusplus
 }
 #endif
+/* seeded ciphertexts -- BLAKE2Xb, BlakePRNG and sample_poly_uniform restated */
+int ref_blake2xb(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen, const uint8_t *key, size_t keylen);
+void ref_expand_seed(const uint64_t seed[8], const uint64_t *moduli, size_t rows, size_t n, uint64_t *dst);
+
 #endif

@@ -225,6 +225,9 @@ def lib():
     L.ref_ckks_decode.argtypes = [C.POINTER(Context), C.POINTER(CkksEncoder), szt, C.c_void_p, C.c_double, C.c_void_p]
     L.ref_ckks_encode_value.argtypes = [C.POINTER(Context), szt, C.c_double, C.c_double, C.c_void_p]
     L.ref_ckks_encode_int64.argtypes = [C.POINTER(Context), szt, C.c_int64, C.c_void_p]
+    L.ref_blake2xb.argtypes = [C.c_void_p, szt, C.c_void_p, szt, C.c_void_p, szt]
+    L.ref_expand_seed.restype = None
+    L.ref_expand_seed.argtypes = [C.c_void_p, C.c_void_p, szt, szt, C.c_void_p]
     L.ref_fill_rows.argtypes = [C.c_void_p, szt, szt, C.c_void_p, u64p]
     L.ref_fnv1a64.argtypes = [C.c_void_p, szt]
     L.ref_splitmix64.argtypes = [u64p]
@@ -316,6 +319,21 @@ class SplitMix:
         assert len(mods) == rows
         lib().ref_fill_rows(ptr(out), rows, n, ptr(mods), C.byref(self.state))
         return out
+
+
+def blake2xb(outlen, data, key=b""):
+    out = C.create_string_buffer(outlen)
+    assert lib().ref_blake2xb(out, outlen, data, len(data), key if key else None, len(key)) == 0
+    return out.raw
+
+
+def expand_seed(seed_words, moduli, n):
+    """Ciphertext::expand_seed (ciphertext.cpp:126-133): the rows x n words of c_1"""
+    seed = np.array([int(s) for s in seed_words], dtype=np.uint64)
+    mods = np.array([int(q) for q in moduli], dtype=np.uint64)
+    out = np.zeros((len(mods), n), dtype=np.uint64)
+    lib().ref_expand_seed(ptr(seed), ptr(mods), len(mods), n, ptr(out))
+    return out
 
 
 def fnv(a):

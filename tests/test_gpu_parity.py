@@ -1235,13 +1235,68 @@ def test_f3_ciphertext_load_save_roundtrip_and_validation(sealhip):
         ctx.load_ciphertext(W.save_ciphertext(ids[k], False, size, n, k, 1.0, a.reshape(-1)[:-1]), da)
     with pytest.raises(sealhip.LogicError, match="unexpected size"):
         ctx.load_ciphertext(W.save_ciphertext(ids[k], False, size, n, k, 1.0, np.concatenate([a.reshape(-1), a[0, 0]])), da)
-    with pytest.raises(sealhip.LogicError, match="seeded"):
-        ctx.load_ciphertext(W.save_ciphertext(ids[k], False, 2, n, k, 1.0, a.reshape(-1)[: k * n], seed=bytes(64)), da)
+    if size == 2:  # a seeded stream is expanded on load (test_f3_seeded_ciphertexts_and_keys_are_expanded_on_load)
+        si = ctx.load_ciphertext(W.save_ciphertext(ids[k], False, 2, n, k, 1.0, a.reshape(-1)[: k * n], seed=bytes(64)), da)
+        assert si.seeded == 1 and np.array_equal(da.download(a.shape)[0], a[0])
     with pytest.raises(ValueError, match="too small"):
         ctx.load_ciphertext(raw_a, da, capacity_words=a.size - 1)
 
 
 # ---------------------------------------------------------------- host-side trees over the device ops
+def test_f3_seeded_ciphertexts_and_keys_are_expanded_on_load(sealhip):
+    """A seeded ciphertext on the wire is c_0 plus the 64-byte seed of c_1 (ciphertext.cpp:189-208); loading it re-samples
+    c_1 like Ciphertext::expand_seed (:126-133, :296-309). The loaded words equal c_0 || oracle expansion, a seeded
+    RelinKeys stream loads to the same key as its expanded form, and evaluating with either gives identical results."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wire_format", os.path.join(os.path.dirname(HERE), "oracle", "wire_format.py"))
+    W = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(W)
+    logn, n, t = 12, 4096, 65537
+    kmods = O.coeff_modulus_create(n, [45] * 4)
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(19)
+    n_key, k = 4, 3
+    pid, key_id = (5, 6, 7, 8), (9, 10, 11, 12)
+    ctx.set_parms_id(k, pid)
+    ctx.set_parms_id(n_key, key_id)
+    seed = [int(x) for x in rng.integers(0, 2**63, size=8)]
+    seed_bytes = np.array(seed, dtype="<u8").tobytes()
+    c0 = rand_rows(rng, kmods[:k], n)
+    raw = W.save_ciphertext(pid, False, 2, n, k, 1.0, c0.reshape(-1), seed=seed_bytes)
+    dst = ctx.alloc(2 * k * n)
+    info = ctx.load_ciphertext(raw, dst)
+    assert info.seeded == 1 and info.size == 2
+    got = dst.download((2, k, n))
+    assert np.array_equal(got[0], c0) and np.array_equal(got[1], O.expand_seed(seed, kmods[:k], n))
+    assert ctx.is_data_valid_for(dst, 2, k, 1).all()
+    with pytest.raises(ValueError, match="too small"):
+        ctx.load_ciphertext(raw, ctx.alloc(k * n))
+    # a seeded key stream: every digit stores component 0 and the seed of component 1
+    d = 3
+    digits0 = [rand_rows(rng, kmods, n) for _ in range(d)]
+    seeds = [[int(x) for x in rng.integers(0, 2**63, size=8)] for _ in range(d)]
+    full = np.stack([np.stack([digits0[j], O.expand_seed(seeds[j], kmods, n)]) for j in range(d)])
+    body = struct_pack_kswitch_seeded(W, key_id, digits0, seeds, n, n_key)
+    rk_seeded = sealhip.KSwitchKeys.from_stream(ctx, body, 0)
+    ct = np.stack([_rand_ct(rng, kmods[:k], 3, n, 1)[0] for _ in range(2)])
+    a, b = ctx.upload(ct), ctx.upload(ct)
+    ev.relinearize_inplace(a, 3, k, 2, [rk_seeded])
+    ev.relinearize_inplace(b, 3, k, 2, [sealhip.KSwitchKeys(ctx, full)])
+    assert np.array_equal(a.download(), b.download())
+
+
+def struct_pack_kswitch_seeded(W, key_id, digits0, seeds, n, n_key):
+    """a KSwitchKeys stream (kswitchkeys.cpp:43-85) whose PublicKeys are seeded ciphertexts"""
+    import struct
+
+    body = struct.pack("<4Q", *key_id) + struct.pack("<Q", 1) + struct.pack("<Q", len(digits0))
+    for c0, sd in zip(digits0, seeds):
+        body += W.save_ciphertext(key_id, True, 2, n, n_key, 1.0, c0.reshape(-1), seed=np.array(sd, dtype="<u8").tobytes())
+    return W.header(16 + len(body)) + body
+
+
 def test_f1_multiply_many_exponentiate_add_many_resize(sealhip):
     """Evaluator::multiply_many / exponentiate / add_many (evaluator.cpp:153-172, 1180-1288) and Ciphertext::resize on
     device-resident batches: the same queue order as the reference, every step bit-exact against the oracle's
@@ -1428,6 +1483,9 @@ def test_f3_kswitch_keys_stream_to_hbm(sealhip):
         ev.relinearize_inplace(a, 3, k, count, [loaded])
         ev.relinearize_inplace(b, 3, k, count, [sealhip.KSwitchKeys(ctx, host)])
         assert np.array_equal(a.download(), b.download())
+    # KSwitchKeys::save: the engine writes the same bytes the oracle's restatement of kswitchkeys.cpp:43-85 does
+    assert sealhip.save_kswitch_keys(ctx, [rk, None, rk2]) == raw
+    assert sealhip.save_kswitch_keys(ctx, [sealhip.KSwitchKeys(ctx, key)]) == W.save_kswitch_keys(key_id, [list(key)], n, n_key)
     with pytest.raises(ValueError, match="out of range"):
         sealhip.KSwitchKeys.from_stream(ctx, raw, 3)
     with pytest.raises(sealhip.LogicError, match="not valid"):

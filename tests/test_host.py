@@ -243,3 +243,38 @@ def test_f3_peek_matches_the_oracle_and_reports_errors_like_the_reference():
         S.ciphertext_peek(raw[:-8])
     with pytest.raises(RuntimeError, match="I/O error"):
         S.ciphertext_peek(raw[:10])
+
+
+def test_f3_seed_expansion_blake2xb_known_answers_and_oracle():
+    """Ciphertext::expand_seed (ciphertext.cpp:126-133) without the host library: the engine's BLAKE2Xb
+    (csrc/blake2xb.cpp, written from the BLAKE2 specifications) and the oracle's (oracle/sealref.c) both reproduce
+    tests/golden/prng_vectors.json -- outputs of the REFERENCE's own blake2b.c / blake2xb.c compiled from /root/reference
+    (tests/golden/make_prng_vectors.py) -- and the engine's BlakePRNG + sample_poly_uniform equal the oracle's word for
+    word, across buffer refills and rejections."""
+    import json
+    import struct
+
+    import sealhip as S
+
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "prng_vectors.json")))
+    for impl in (S.blake2xb, O.blake2xb):
+        for t in vec["blake2xb"]:
+            out = impl(t["outlen"], bytes.fromhex(t["data"]), bytes.fromhex(t["key"]))
+            assert len(out) == t["outlen"] and out[:64].hex() == t["head"] and out[-16:].hex() == t["tail"]
+        for t in vec["prng"]:
+            key = struct.pack("<8Q", *[int(x) for x in t["seed"]])
+            b0, b1 = impl(4096, struct.pack("<Q", 0), key), impl(4096, struct.pack("<Q", 1), key)
+            assert b0[:32].hex() == t["buffer0_head"] and b0[-32:].hex() == t["buffer0_tail"]
+            assert b1[:32].hex() == t["buffer1_head"]
+    # 60-bit primes reject about one candidate in eight, small ones almost never: both ends, several buffers deep
+    for logn, bits in ((10, [60, 59, 30]), (12, [36, 36, 37]), (13, [55] * 3)):
+        n = 1 << logn
+        mods = O.coeff_modulus_create(n, bits)
+        ctx = S.Context(S.SCHEME_CKKS, logn, mods, 1, 0, device=-1)
+        for seed in ([0] * 8, list(range(11, 19)), [2**64 - 1 - i for i in range(8)]):
+            for rows in (1, len(mods)):
+                got = ctx.expand_seed(rows, seed)
+                assert np.array_equal(got, O.expand_seed(seed, mods[:rows], n))
+                assert all((got[j] < mods[j]).all() for j in range(rows))
+    with pytest.raises(ValueError):
+        S.blake2xb(0, b"")

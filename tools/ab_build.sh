@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../gemini-seal_amd"
 name=$1; shift
 mkdir -p build_$name lib
-for f in hostmath.cpp engine.cpp pipeline.cpp api.cpp wire.cpp hostbatch.cpp ntt.hip poly.hip rns.hip keyswitch.hip rlwe.hip ckks_encoder.hip; do
+for f in hostmath.cpp engine.cpp pipeline.cpp api.cpp wire.cpp blake2xb.cpp hostbatch.cpp ntt.hip poly.hip rns.hip keyswitch.hip rlwe.hip ckks_encoder.hip; do
   ( /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../include "$@" -c csrc/$f -o build_$name/$f.o ) &
 done
 wait
