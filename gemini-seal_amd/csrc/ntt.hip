@@ -611,6 +611,30 @@ namespace sealhip
                     u64x2 Wv;
                     if (UNIFORM)
                         Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
+#ifdef SEALHIP_NTT_TW_SHUFFLE
+                    // Measurement-only variant ("wavefront-shuffle twiddle propagation"): in round 2 the twiddle index only
+                    // depends on the lane bits above Arr::low_len, so one lane per group of 2^low_len loads the pair and the
+                    // others take it through the LDS crossbar (ds_bpermute, four dwords). Result (profiles/r02): slower --
+                    // the wave issues the same number of memory instructions (a load whose lanes share an address is one
+                    // request anyway) plus four cross-lane moves per twiddle, in a kernel bound by instruction issue.
+                    else if (R == 2 && Arr<T, R>::low_len >= 1)
+                    {
+                        const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+                        const int leader = lane & ~((1 << (Arr<T, R>::low_len < 6 ? Arr<T, R>::low_len : 6)) - 1);
+                        u64x2 mine;
+                        mine.x = 0;
+                        mine.y = 0;
+                        if (lane == leader)
+                            mine = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                        const int a = leader << 2;
+                        const unsigned x0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x));
+                        const unsigned x1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x >> 32));
+                        const unsigned y0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y));
+                        const unsigned y1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y >> 32));
+                        Wv.x = static_cast<u64>(x0) | (static_cast<u64>(x1) << 32);
+                        Wv.y = static_cast<u64>(y0) | (static_cast<u64>(y1) << 32);
+                    }
+#endif
                     else
                         Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
                     w[j] = Wv.x;
@@ -967,6 +991,30 @@ namespace sealhip
                     u64x2 Wv;
                     if (UNIFORM)
                         Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
+#ifdef SEALHIP_NTT_TW_SHUFFLE
+                    // Measurement-only variant ("wavefront-shuffle twiddle propagation"): in round 2 the twiddle index only
+                    // depends on the lane bits above Arr::low_len, so one lane per group of 2^low_len loads the pair and the
+                    // others take it through the LDS crossbar (ds_bpermute, four dwords). Result (profiles/r02): slower --
+                    // the wave issues the same number of memory instructions (a load whose lanes share an address is one
+                    // request anyway) plus four cross-lane moves per twiddle, in a kernel bound by instruction issue.
+                    else if (R == 2 && Arr<T, R>::low_len >= 1)
+                    {
+                        const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+                        const int leader = lane & ~((1 << (Arr<T, R>::low_len < 6 ? Arr<T, R>::low_len : 6)) - 1);
+                        u64x2 mine;
+                        mine.x = 0;
+                        mine.y = 0;
+                        if (lane == leader)
+                            mine = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                        const int a = leader << 2;
+                        const unsigned x0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x));
+                        const unsigned x1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x >> 32));
+                        const unsigned y0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y));
+                        const unsigned y1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y >> 32));
+                        Wv.x = static_cast<u64>(x0) | (static_cast<u64>(x1) << 32);
+                        Wv.y = static_cast<u64>(y0) | (static_cast<u64>(y1) << 32);
+                    }
+#endif
                     else
                         Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
                     w[j] = Wv.x;

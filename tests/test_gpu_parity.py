@@ -1830,6 +1830,47 @@ def test_cfg4_rotate_large_batch_vs_golden_and_oracle(sealhip):
             assert h(got[i]) == row["digests"]["rotate"], i
 
 
+def test_cfg4_variant_with_16_decomposition_digits(sealhip):
+    """BASELINE.json words config 4 as "12 primes ... 16 decomposition digits"; with n_special_primes = 1 the digit count
+    is the number of ciphertext primes (keygenerator.cpp:334-336), so 16 digits means 17 key primes (SURVEY section 8
+    header). That variant -- CKKS N = 2^15, {50} x 17, k = 16, ks_mac_items_kernel<16> and 17-row key-level polynomials --
+    against the oracle: rotate_vector, multiply + relinearize, rescale."""
+    logn, n, nsp = 15, 1 << 15, 1
+    kmods = O.coeff_modulus_create(n, [50] * 17)
+    k, d, count = 16, 16, 17
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, nsp, 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(2, logn, kmods, nsp=nsp, t=0)
+    rng = np.random.default_rng(16)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(d)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    elt = ctx.galois_elt_from_step(1)
+    g = ctx.upload(a)
+    ev.rotate_vector_inplace(g, k, count, 1, {elt: dkey})
+    rot = g.download(a.shape)
+    o = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, o)
+    ev.relinearize_inplace(o, 3, k, count, [dkey])
+    rel = o.download((count, 3, k, n))[:, :2].copy()
+    low = ctx.alloc(count * 2 * (k - 1) * n)
+    ev.rescale_to_next(ctx.upload(rel), 2, k, count, low)
+    res = low.download((count, 2, k - 1, n))
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    for i in (0, 7, count - 1):
+        exp = a[i].copy()
+        assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(exp), elt, O.ptr(key)) == 0
+        assert np.array_equal(rot[i], exp), i
+        wide = np.zeros((3, k, n), dtype=np.uint64)
+        assert L.ref_ckks_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(wide)) == 0
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(wide), 3, keys) == 0
+        assert np.array_equal(rel[i], wide[:2]), i
+        lo = np.zeros((2, k - 1, n), dtype=np.uint64)
+        assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(np.ascontiguousarray(wide[:2])), 2, O.ptr(lo)) == 0
+        assert np.array_equal(res[i], lo), i
+
+
 def test_bench_shapes_with_a_small_arena():
     """SEALHIP_WORKSPACE_MB is read once per process: a child process with a 64 MB arena runs the two tests above with
     a smaller batch, so that every operation walks its batch in chunks of two or three ciphertexts (config 3 needs 27 MB
