@@ -491,7 +491,7 @@ def main(argv=None):
 
     # ---- NTT-only section: forward-NTT/s (the other half of the BASELINE metric), same primes, same device
     ntt = None
-    if not args.stub:
+    if not args.stub and args.ntt_polys > 0:
         P = args.ntt_polys
         with torch.cuda.stream(w.stream):
             x = torch.empty((P, k, n), dtype=torch.int64, device=w.dev)
@@ -591,12 +591,14 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
-    per_kernel = {}
+    totals = {}  # tag -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "rows": rows, "launches": n}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="sealhip_pmc_", dir="/tmp")
+        # the multiply+relinearize step only (no NTT-only section): the same mix of forward / inverse launches that
+        # roofline.achieved is measured over
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-               os.path.abspath(__file__), "--batch", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-               "--no-verify", "--ntt-polys", "1024"]
+               os.path.abspath(__file__), "--batch", "256", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
+               "--no-verify", "--ntt-polys", "0"]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -610,21 +612,22 @@ def measure_traffic(args):
                 tag = "ntt_inv_half"
             else:
                 continue
-            rows = int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # two workgroups per row
-            per_kernel.setdefault((tag, rows), {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+            t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "rows": 0.0, "launches": 0})
+            t[counter] += float(row["Counter_Value"])
+            if counter == "FETCH_SIZE":
+                t["rows"] += int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # two workgroups per row
+                t["launches"] += 1
         shutil.rmtree(d, ignore_errors=True)
     rec = {"kernels_sha": kernels_sha(), "measured": time.strftime("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %Y-%m-%d"),
-           "command": "bench.py --batch 256 --steps 1 --warmup 1"}
-    for tag in ("ntt_fwd_half", "ntt_inv_half"):
-        # launches that skip rows would dilute the per-row figure: take the largest launch, where every row is live
-        cands = [(rows, v) for (t, rows), v in per_kernel.items() if t == tag and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-        if not cands:
+           "command": "bench.py --batch 256 --steps 2 --warmup 0 --ntt-polys 0 (every launch of the kernel in the step)"}
+    for tag, t in totals.items():
+        if not t["rows"]:
             continue
-        rows, v = max(cands, key=lambda c: c[0])
-        f = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
-        wr = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-        rec[tag] = {"hbm_bytes_per_row_per_launch": (2 * f + wr) * 1024 / rows, "rows_in_that_launch": rows,
-                    "fetch_size_kb_raw": f, "write_size_kb": wr}
+        # summed over every launch of the kernel in the step (the variants differ: gathered / in place, with or without
+        # the fused tensor product), divided by the rows they transform
+        rec[tag] = {"hbm_bytes_per_row_per_launch": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / t["rows"],
+                    "rows_total": t["rows"], "launches": t["launches"], "fetch_size_kb_raw_total": t["FETCH_SIZE"],
+                    "write_size_kb_total": t["WRITE_SIZE"]}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     return rec
 

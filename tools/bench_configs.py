@@ -248,15 +248,18 @@ def main():
         logn, n = 15, 1 << 15
         pr = bench.CFG3_PRIMES
         ctx = S.Context(S.SCHEME_BFV, logn, pr, 1, 786433)
-        ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
+        s_lat = torch.cuda.Stream()  # graphs cannot be captured from the legacy default stream: an explicit one
+        ctx.set_stream(s_lat.cuda_stream)
         ev = S.Evaluator(ctx)
         k = 7
         key = mk(ctx, (k, 2, 8, n), pr, dev)
+        torch.cuda.synchronize()
         rk = S.KSwitchKeys(ctx, key, n_digits=k, from_host=False)
         res = {}
         for B in (1, 2, 4, 8, 16, 64, 256):
             x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
             o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
 
             def step():
                 ev.multiply(x, 2, y, 2, k, B, o)
