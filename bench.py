@@ -344,7 +344,9 @@ class EngineWorkload:
 
     def result_slice(self, count):
         with torch.cuda.stream(self.stream):
-            return self.out[:count, :2].contiguous()  # the size-2 results, compacted (what a caller gets back)
+            res = self.out[:count, :2].contiguous()  # the size-2 results, compacted (what a caller gets back)
+        self.stream.synchronize()  # the callers (digests, RCCL gather) work on other streams
+        return res
 
     def key_digest(self):
         with torch.cuda.stream(self.stream):

@@ -42,8 +42,10 @@ namespace sealhip
         // launch-wide treatment of the loaded words (single-prime mod-up, multi_special_primes.cpp:99-108): 0 none,
         // 1 barrett_reduce_63 w.r.t. the row's prime, 2 one conditional subtraction (every source prime is below twice
         // every destination prime, so the canonical residue is x or x - p). Both are no-ops on rows whose source prime
-        // does not exceed their own.
+        // does not exceed their own. 4: the CKKS mod-down with one special prime (multi_special_primes.cpp:262-273): the
+        // word becomes -(x mod aux_p) as the integer aux_p - (x mod aux_p) (0 stays 0), aux_p = the special prime.
         int reduce_mode;
+        u64 aux_p, aux_cr1;
     };
     constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
 

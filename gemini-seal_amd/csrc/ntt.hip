@@ -685,7 +685,8 @@ namespace sealhip
         constexpr int kLoadBatch = SEALHIP_NTT_LOAD_BATCH; // (lo, hi) 16-byte pairs per lane in flight during the load phase
         template <int T, int STRICT, int HALF, int REDUCE>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
-                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1)
+                                                   const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1,
+                                                   u64 aux_p = 0, u64 aux_cr1 = 0)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
             const u64x2 W1 = ((tw_const_t)tw)[1];
@@ -700,6 +701,25 @@ namespace sealhip
                     const int idx = jb + Arr<T, 1>::slot_index(s);
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
+                }
+                if constexpr (REDUCE == 4)
+                {
+                    // CKKS mod-down with one special prime P (multi_special_primes.cpp:262-273): the word is a lazy value of
+                    // the special row; the row being transformed holds (-(s mod P)) mod q. -(s mod P) is formed here as the
+                    // integer P - r (0 for r = 0), which is below P < 2q: the lazy transform takes it as it is, so the
+                    // separate pass that wrote these k rows and the read of them are gone.
+#pragma unroll
+                    for (int i = 0; i < kLoadBatch; i++)
+                    {
+                        const auto red = [&](u64 v) {
+                            const u64 r = barrett_reduce_63(v, aux_p, aux_cr1);
+                            return r ? aux_p - r : 0;
+                        };
+                        lo[i].x = red(lo[i].x);
+                        lo[i].y = red(lo[i].y);
+                        hi[i].x = red(hi[i].x);
+                        hi[i].y = red(hi[i].y);
+                    }
                 }
                 if constexpr (REDUCE == 1 || REDUCE == 2) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
                 {
@@ -859,9 +879,9 @@ namespace sealhip
                     x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
             }
             else if (half)
-                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1);
+                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1);
             else
-                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1);
+                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -1660,7 +1680,8 @@ namespace sealhip
             // the consumer reduces whatever representative it reads, nothing expects the [0, 4p) range (no canonicalising
             // wrapper, no kNttReduceOut) and 50p cannot wrap: every live prime below 2^58.
             static const bool no_apx = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
-            bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0;
+            bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0 &&
+                       red != 4;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
             if (apx)
@@ -1674,7 +1695,9 @@ namespace sealhip
             }
             else if (flags & kNttStrict)
             {
-                if (red == 3)
+                if (red == 4)
+                    SEALHIP_FWD_HALF(1, 4);
+                else if (red == 3)
                     SEALHIP_FWD_HALF(1, 3);
                 else if (red == 2)
                     SEALHIP_FWD_HALF(1, 2);
@@ -1685,7 +1708,9 @@ namespace sealhip
             }
             else
             {
-                if (red == 3)
+                if (red == 4)
+                    SEALHIP_FWD_HALF(0, 4);
+                else if (red == 3)
                     SEALHIP_FWD_HALF(0, 3);
                 else if (red == 2)
                     SEALHIP_FWD_HALF(0, 2);
@@ -1703,7 +1728,9 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[11] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 3>),
+            const void *fwd[13] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 4>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 4>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 3>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 3>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 0>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 1>),

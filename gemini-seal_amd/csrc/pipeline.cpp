@@ -232,12 +232,39 @@ namespace sealhip
             // (the mod-down reduces the special rows with barrett_reduce_63 / a Shoup product: canonical either way)
             check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, kNttAnyRep), "intt(special)");
             // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
-            check(launch_ks_moddown_pre(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, 2 * m),
-                  "moddown_pre");
-            if (ckks)
-                check(launch_ntt(e, temp, m * 2 * k, map_q, false, 0), "ntt(temp)");
+            // Step 5 for CKKS with one special prime P: temp_i = (-(special mod P)) mod q_i, then its forward transform
+            // (multi_special_primes.cpp:262-289). With the single-pass kernel the transform gathers the special row and forms
+            // temp_i while it loads (reduce mode 4): no pass that writes the k rows of temp, none that reads them back.
+            u64 p_special = 0, p_min = ~u64(0);
+            if (ckks && e.nsp == 1)
+            {
+                p_special = e.key_moduli[h.row_prime[k]];
+                for (int r = 0; r < k; r++)
+                    p_min = std::min(p_min, e.key_moduli[h.row_prime[r]]);
+            }
+            const bool fold_pre = ckks && e.nsp == 1 && ntt_can_gather(e) && p_special < 2 * p_min &&
+                                  p_special < (u64(1) << 58) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
+            if (fold_pre)
+            {
+                NttSource ns{};
+                ns.base[0] = prod;
+                ns.poly_stride[0] = ext_item;
+                ns.reduce_mode = 4;
+                ns.aux_p = p_special;
+                ns.aux_cr1 = HostModulus(p_special).cr1;
+                for (int r = 0; r < k; r++)
+                    ns.code[r] = static_cast<unsigned short>(k); // every row of temp reads the special row of its polynomial
+                check(launch_ntt_gather(e, temp, m * 2 * k, map_q, ns, 0), "ntt(temp, gathered from the special row)");
+            }
             else
-                check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, 0), "intt(prod)");
+            {
+                check(launch_ks_moddown_pre(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, 2 * m),
+                      "moddown_pre");
+                if (ckks)
+                    check(launch_ntt(e, temp, m * 2 * k, map_q, false, 0), "ntt(temp)");
+                else
+                    check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, 0), "intt(prod)");
+            }
             check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
                                          ct_stride, 2 * m, 1),
                   "moddown_post");
