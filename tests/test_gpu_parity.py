@@ -1934,6 +1934,8 @@ def test_ntt_handoff_failure_surfaces_at_every_host_visible_point(sealhip):
     sticky flag is raised. sealhip_debug_ntt_handoff withholds the hand-off signal and cuts the wait to one poll, which
     drives exactly that path: every entry point that makes results host-visible must then fail (E_UNEXPECTED ->
     RuntimeError) instead of returning the rows with S_OK, once per failure, and the engine must work again afterwards."""
+    if os.environ.get("SEALHIP_NTT_TWO_PASS"):
+        pytest.skip("the two-pass tiled kernels have no cross-workgroup hand-off")
     logn, n = 15, 1 << 15
     kmods = O.coeff_modulus_create(n, [55] * 3)
     ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433)
