@@ -26,7 +26,72 @@ namespace sealhip
         u64 ninv;                   // -p^{-1} mod 2^64 (Montgomery reduction of 128-bit dot products)
         const u64 *fwd;  // N {w, w'} pairs, bit-reversed exponent order
         const u64 *inv;  // N {w, w'} pairs for psi^{-1}
+        // primes below 2^50 only (else null): the same twiddles as doubles, for the floating-point transform
+        const double *fwd_d; // N entries w
+        const double *inv_d; // N entries
+        double p_d, pinv_d;  // p and the correctly rounded 1/p
     };
+
+    // ---- residues as doubles (primes below 2^50). A product y*w with |y| < 2^53 and 0 <= w < p is formed exactly as
+    // h + l (h = the rounded product, l = fma(y, w, -h) its rounding error, both exact), the quotient estimate
+    // q = rint(h / p) is off by at most two, and r = (h - q*p) + l is exact again (|h - q*p| < 2.5p fits 53 bits and is a
+    // multiple of ulp(h) because q*p is formed inside the fma): r == y*w (mod p), |r| < 2.5p. Every operation is an
+    // exact integer computation as long as magnitudes stay below 2^53 = 8 * 2^50, which the callers' reduction
+    // schedules guarantee -- the transform is bit-for-bit the integer one after the final canonicalisation.
+    // (v_fma_f64 issues at the rate of v_mad_u64_u32; the modular product takes 6 of them against 14.)
+    constexpr double kTwo52 = 4503599627370496.0;
+    __device__ __forceinline__ double fp_of(u64 bits)
+    {
+        return __longlong_as_double(static_cast<long long>(bits));
+    }
+    __device__ __forceinline__ u64 fp_bits(double v)
+    {
+        return static_cast<u64>(__double_as_longlong(v));
+    }
+    // integer below 2^52 -> double (two instructions: or the exponent of 2^52 in, subtract 2^52)
+    __device__ __forceinline__ double fp_from_u64(u64 x)
+    {
+        return fp_of(x | 0x4330000000000000ull) - kTwo52;
+    }
+    // double holding an integer in [0, 2^52) -> integer
+    __device__ __forceinline__ u64 fp_to_u64(double r)
+    {
+        return fp_bits(r + kTwo52) & 0x000FFFFFFFFFFFFFull;
+    }
+    // |x| < 2^53 -> the representative in [-p/2, p/2]
+    __device__ __forceinline__ double fp_reduce(double x, double p, double pinv)
+    {
+#pragma clang fp contract(off)
+        return __builtin_fma(-__builtin_rint(x * pinv), p, x);
+    }
+    // -> the canonical residue in [0, p)
+    __device__ __forceinline__ double fp_canonical(double x, double p, double pinv)
+    {
+        const double r = fp_reduce(x, p, pinv);
+        return r < 0.0 ? r + p : r;
+    }
+    __device__ __forceinline__ double fp_mulmod(double y, double w, double p, double pinv)
+    {
+#pragma clang fp contract(off)
+        const double h = y * w;
+        const double l = __builtin_fma(y, w, -h);
+        const double q = __builtin_rint(h * pinv);
+        return __builtin_fma(-q, p, h) + l;
+    }
+    // Cooley-Tukey butterfly (u, y) -> (u + y*w, u - y*w)
+    __device__ __forceinline__ void fp_butterfly_fwd(u64 &ub, u64 &yb, u64 wb, double p, double pinv)
+    {
+        const double u = fp_of(ub), r = fp_mulmod(fp_of(yb), fp_of(wb), p, pinv);
+        ub = fp_bits(u + r);
+        yb = fp_bits(u - r);
+    }
+    // Gentleman-Sande butterfly (u, y) -> (u + y, (u - y)*w)
+    __device__ __forceinline__ void fp_butterfly_inv(u64 &ub, u64 &yb, u64 wb, double p, double pinv)
+    {
+        const double u = fp_of(ub), y = fp_of(yb);
+        ub = fp_bits(u + y);
+        yb = fp_bits(fp_mulmod(u - y, fp_of(wb), p, pinv));
+    }
 
     // streaming stores (nontemporal hint): outputs that the producing kernel does not read again should not push the
     // constant tables (twiddles, key slices) out of L2

@@ -129,6 +129,20 @@ namespace sealhip
             }
             d.fwd = tb.fwd.empty() ? nullptr : upload<u64>(*e, e->owned, tb.fwd.data(), tb.fwd.size());
             d.inv = tb.inv.empty() ? nullptr : upload<u64>(*e, e->owned, tb.inv.data(), tb.inv.size());
+            d.fwd_d = d.inv_d = nullptr;
+            d.p_d = static_cast<double>(tb.p);
+            d.pinv_d = 1.0 / d.p_d;
+            if (tb.p < kFpPrimeBound && tb.logn >= 14 && !tb.fwd.empty())
+            {
+                // the single-pass kernels' floating-point variant (ntt.hip): the twiddles w, without the Shoup quotients
+                std::vector<double> f(tb.fwd.size() / 2), v(tb.inv.size() / 2);
+                for (std::size_t j = 0; j < f.size(); j++)
+                    f[j] = static_cast<double>(tb.fwd[2 * j]);
+                for (std::size_t j = 0; j < v.size(); j++)
+                    v[j] = static_cast<double>(tb.inv[2 * j]);
+                d.fwd_d = upload<double>(*e, e->owned, f.data(), f.size());
+                d.inv_d = upload<double>(*e, e->owned, v.data(), v.size());
+            }
         }
         e->d_primes = upload<PrimeDev>(*e, e->owned, pd.data(), pd.size());
         return e;

@@ -56,6 +56,10 @@ namespace sealhip
     constexpr int kNttApprox = 0x20;   // forward, with kNttAnyRep or a consumer that takes outputs below 5p: approximate quotient
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
+    // Primes below this bound have double-precision twiddle tables: the single-pass kernels then run their butterflies
+    // on the FP64 pipe (exact, devmath.hpp) whenever the launch promises nothing about representatives that only the
+    // integer sequence would deliver (canonical outputs, or kNttAnyRep). SEALHIP_NTT_NO_FP64=1 switches it off.
+    constexpr u64 kFpPrimeBound = u64(1) << 50;
 
     struct NttRound
     {

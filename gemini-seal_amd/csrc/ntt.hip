@@ -370,6 +370,21 @@ namespace sealhip
         typedef u64 u64x2 __attribute__((ext_vector_type(2)));
         typedef const __attribute__((address_space(1))) u64x2 *tw_global_t;
         typedef const __attribute__((address_space(4))) u64x2 *tw_const_t;
+        // the floating-point variant's tables hold one double per twiddle (PrimeDev::fwd_d / inv_d), moved as 64-bit words
+        typedef const __attribute__((address_space(1))) u64 *twd_global_t;
+        typedef const __attribute__((address_space(4))) u64 *twd_const_t;
+        // In the floating-point instances (STRICT == 3 forward, MODE == 2 inverse) the registers x[] hold the bit patterns
+        // of doubles, the parameters named two_p / neg_p carry the bits of p and 1/p as doubles, and tw points to the
+        // double table. Reduction schedule of the forward transform: every value is brought to [-p/2, p/2] at the start
+        // of each round; a round's (at most four) layers then grow magnitudes to 0.5p -> 1.76p -> 3.02p -> 4.78p -> 6.73p
+        // (each layer adds |y*w mod p| < (0.5 + 2^-52 |y| 2^50 + 0.25) p), below 8p <= 2^53: all operations are exact.
+        __device__ __forceinline__ void fp_reduce_all(u64 (&x)[32], u64 p_bits, u64 pinv_bits)
+        {
+            const double p = fp_of(p_bits), pinv = fp_of(pinv_bits);
+#pragma unroll
+            for (int i = 0; i < 32; i++)
+                x[i] = fp_bits(fp_reduce(fp_of(x[i]), p, pinv));
+        }
 
 #ifndef SEALHIP_NTT_IL
 #define SEALHIP_NTT_IL 4
@@ -385,6 +400,23 @@ namespace sealhip
 #else
 #define NTT_EXP(flags, bit) false
 #endif
+
+        // Final-round stores. A lane finishes runs of 2^f consecutive coefficients; for f >= 2 storing them from there
+        // means 16-byte pieces at a 2^f * 8-byte stride per instruction -- every 128-byte line is written by 2^(f-1)
+        // different instructions, and a kernel that does nothing but these stores reaches 2.0 TB/s at f = 2 (3.0 at
+        // f = 3) against 5.3 TB/s for the contiguous stores of f = 1 (profiles/r02/ntt_store_pattern.txt). So for
+        // f >= 2 the finished values take one more trip through the LDS, back to arrangement 1 (a lane holds pairs, the
+        // lanes of a wave are consecutive pairs), and every store instruction writes one contiguous kilobyte.
+        // Which instances take the trip (bit mask): 1 the floating-point ones, 2 the integer ones at f = 2, 4 the integer
+        // ones at f = 3. Inside the pipelines the integer instances are bound by instruction issue, not by their stores:
+        // at f = 2 the extra exchange costs them 2 % (config 3: 18.8 vs 18.4 ms of forward transforms per 1024 pairs)
+        // although the transform alone gains 6 %; the floating-point instances gain 10 % in the config-4 key switch.
+#ifndef SEALHIP_NTT_STORE_EXCHANGE
+#define SEALHIP_NTT_STORE_EXCHANGE 5
+#endif
+        template <int T, int STRICT>
+        constexpr bool kStoreExchange =
+            (T - 12) >= 2 && ((SEALHIP_NTT_STORE_EXCHANGE) & (STRICT == 3 ? 1 : ((T - 12) == 2 ? 2 : 4))) != 0;
 
         template <int T, int STRICT, int G, bool ROUT>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
@@ -405,6 +437,12 @@ namespace sealhip
                     if (e & bit)
                         continue;
                     const int s = (G << f) | e;
+                    if constexpr (STRICT == 3)
+                    {
+                        fp_butterfly_fwd(x[s], x[s | bit], ((twd_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)], fp_of(two_p),
+                                         fp_of(neg_p));
+                        continue;
+                    }
                     const u64x2 Wv = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
                     if (STRICT == 1)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
@@ -420,7 +458,13 @@ namespace sealhip
                 ulonglong2 v;
                 v.x = x[s];
                 v.y = x[s + 1];
-                if (fin & 1)
+                if constexpr (STRICT == 3)
+                {
+                    // canonical residues always: they serve kNttCanonical and every any-representative consumer alike
+                    v.x = fp_to_u64(fp_canonical(fp_of(v.x), fp_of(two_p), fp_of(neg_p)));
+                    v.y = fp_to_u64(fp_canonical(fp_of(v.y), fp_of(two_p), fp_of(neg_p)));
+                }
+                else if (fin & 1)
                 {
                     v.x = v.x >= two_p ? v.x - two_p : v.x;
                     v.y = v.y >= two_p ? v.y - two_p : v.y;
@@ -437,9 +481,15 @@ namespace sealhip
                 }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
-                // (plain store: this path serves f = 3, where a lane's 64-byte run is written by four instructions and
-                //  the L2 has to merge them; streaming stores cost 12 % there)
-                *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
+                if constexpr (kStoreExchange<T, STRICT>)
+                {
+                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1
+                    x[s + 1] = v.y;
+                }
+                else
+                    // (plain store: a lane's 64-byte run is written by four instructions and the L2 has to merge them;
+                    //  streaming stores cost 12 % there)
+                    *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
             }
         }
 
@@ -476,7 +526,7 @@ namespace sealhip
             static constexpr bool PIPE = f <= 2; // f = 3: two stages of 28 twiddle registers do not fit
         };
 
-        template <int T, int G>
+        template <int T, int G, bool FP = false>
         __device__ __forceinline__ void h_final_tw(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
         {
             constexpr int f = T - 12;
@@ -488,7 +538,10 @@ namespace sealhip
                 for (int o = 0; o < (1 << (f - 1 - W)); o++)
                 {
                     const int s = (G << f) | (o << (W + 1));
-                    tg[(1 << (f - 1 - W)) - 1 + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    if constexpr (FP)
+                        tg[(1 << (f - 1 - W)) - 1 + o].x = ((twd_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    else
+                        tg[(1 << (f - 1 - W)) - 1 + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
                 }
             }
         }
@@ -512,6 +565,11 @@ namespace sealhip
                         continue;
                     const int s = (G << f) | e;
                     const u64x2 Wv = tg[(1 << (f - 1 - W)) - 1 + (e >> (W + 1))];
+                    if constexpr (STRICT == 3)
+                    {
+                        fp_butterfly_fwd(x[s], x[s | bit], Wv.x, fp_of(two_p), fp_of(neg_p));
+                        continue;
+                    }
                     if (STRICT == 1)
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
@@ -526,7 +584,13 @@ namespace sealhip
                 ulonglong2 v;
                 v.x = x[s];
                 v.y = x[s + 1];
-                if (fin & 1)
+                if constexpr (STRICT == 3)
+                {
+                    // canonical residues always: they serve kNttCanonical and every any-representative consumer alike
+                    v.x = fp_to_u64(fp_canonical(fp_of(v.x), fp_of(two_p), fp_of(neg_p)));
+                    v.y = fp_to_u64(fp_canonical(fp_of(v.y), fp_of(two_p), fp_of(neg_p)));
+                }
+                else if (fin & 1)
                 {
                     v.x = v.x >= two_p ? v.x - two_p : v.x;
                     v.y = v.y >= two_p ? v.y - two_p : v.y;
@@ -543,18 +607,24 @@ namespace sealhip
                 }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
-                store_nt(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s), v.x, v.y);
+                if constexpr (kStoreExchange<T, STRICT>)
+                {
+                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1
+                    x[s + 1] = v.y;
+                }
+                else
+                    store_nt(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s), v.x, v.y);
             }
         }
 
-        template <int T, int ST, int I = 0>
+        template <int T, int ST, int I = 0, bool FP = false>
         struct StageTw // twiddle loads of stage ST
         {
             __device__ static __forceinline__ void load(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
             {
-                h_final_tw<T, ST * FinalStage<T>::SG + I>(tg + I * FinalStage<T>::NTW, tw, jb, N);
+                h_final_tw<T, ST * FinalStage<T>::SG + I, FP>(tg + I * FinalStage<T>::NTW, tw, jb, N);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    StageTw<T, ST, I + 1>::load(tg, tw, jb, N);
+                    StageTw<T, ST, I + 1, FP>::load(tg, tw, jb, N);
             }
         };
         template <int T, int STRICT, bool ROUT, int ST, int I = 0>
@@ -578,7 +648,7 @@ namespace sealhip
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    StageTw<T, ST + 1>::load(next, tw, jb, N);
+                    StageTw<T, ST + 1, 0, STRICT == 3>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
                 StageRun<T, STRICT, ROUT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 __builtin_amdgcn_sched_barrier(0);
@@ -609,32 +679,14 @@ namespace sealhip
                 for (int j = 0; j < kIL; j++)
                 {
                     u64x2 Wv;
-                    if (UNIFORM)
-                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
-#ifdef SEALHIP_NTT_TW_SHUFFLE
-                    // Measurement-only variant ("wavefront-shuffle twiddle propagation"): in round 2 the twiddle index only
-                    // depends on the lane bits above Arr::low_len, so one lane per group of 2^low_len loads the pair and the
-                    // others take it through the LDS crossbar (ds_bpermute, four dwords). Result (profiles/r02): slower --
-                    // the wave issues the same number of memory instructions (a load whose lanes share an address is one
-                    // request anyway) plus four cross-lane moves per twiddle, in a kernel bound by instruction issue.
-                    else if (R == 2 && Arr<T, R>::low_len >= 1)
+                    if constexpr (STRICT == 3)
                     {
-                        const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-                        const int leader = lane & ~((1 << (Arr<T, R>::low_len < 6 ? Arr<T, R>::low_len : 6)) - 1);
-                        u64x2 mine;
-                        mine.x = 0;
-                        mine.y = 0;
-                        if (lane == leader)
-                            mine = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
-                        const int a = leader << 2;
-                        const unsigned x0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x));
-                        const unsigned x1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x >> 32));
-                        const unsigned y0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y));
-                        const unsigned y1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y >> 32));
-                        Wv.x = static_cast<u64>(x0) | (static_cast<u64>(x1) << 32);
-                        Wv.y = static_cast<u64>(y0) | (static_cast<u64>(y1) << 32);
+                        Wv.x = UNIFORM ? ((twd_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)]
+                                       : ((twd_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                        Wv.y = 0;
                     }
-#endif
+                    else if (UNIFORM)
+                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
                     else
                         Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
                     w[j] = Wv.x;
@@ -644,6 +696,13 @@ namespace sealhip
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
                                                        u64 neg_p)
             {
+                if constexpr (STRICT == 3)
+                {
+#pragma unroll
+                    for (int j = 0; j < kIL; j++)
+                        fp_butterfly_fwd(x[slot(j)], x[slot(j) | bit], w[j], fp_of(two_p), fp_of(neg_p));
+                    return;
+                }
                 u64 u[kIL], y[kIL];
 #pragma unroll
                 for (int j = 0; j < kIL; j++)
@@ -689,7 +748,11 @@ namespace sealhip
                                                    u64 aux_p = 0, u64 aux_cr1 = 0)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
-            const u64x2 W1 = ((tw_const_t)tw)[1];
+            u64x2 W1;
+            if constexpr (STRICT == 3)
+                W1.x = ((twd_const_t)tw)[1];
+            else
+                W1 = ((tw_const_t)tw)[1];
 #pragma unroll
             for (int batch = 0; batch < 16 / kLoadBatch; batch++)
             {
@@ -723,7 +786,7 @@ namespace sealhip
                 }
                 if constexpr (REDUCE == 1 || REDUCE == 2) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
                 {
-                    const u64 p = 0 - neg_p;
+                    const u64 p = STRICT == 3 ? static_cast<u64>(fp_of(two_p)) : 0 - neg_p;
                     const auto red = [&](u64 v) {
                         if constexpr (REDUCE == 2)
                             return v >= p ? v - p : v; // source prime < 2p: the canonical residue is v or v - p
@@ -747,6 +810,19 @@ namespace sealhip
                     const int s = (batch * kLoadBatch + i) * 2;
                     u64 u[4] = {lo[i].x, lo[i].y, lo[i + 1].x, lo[i + 1].y};
                     u64 y[4] = {hi[i].x, hi[i].y, hi[i + 1].x, hi[i + 1].y};
+                    if constexpr (STRICT == 3)
+                    {
+                        // inputs below 2^52 (launch_half: residues, lazy gathered values, or the treatments above)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            u[j] = fp_bits(fp_from_u64(u[j]));
+                            y[j] = fp_bits(fp_from_u64(y[j]));
+                            fp_butterfly_fwd(u[j], y[j], W1.x, fp_of(two_p), fp_of(neg_p));
+                            x[s + j] = HALF ? y[j] : u[j];
+                        }
+                        continue;
+                    }
                     const u64 w[4] = {W1.x, W1.x, W1.x, W1.x}, ws[4] = {W1.y, W1.y, W1.y, W1.y};
                     if (STRICT == 1)
                     {
@@ -827,6 +903,16 @@ namespace sealhip
             return v;
         }
 
+        // arrangement 1 -> memory: pairs, consecutive lanes 16 bytes apart
+        template <int T>
+        __device__ __forceinline__ void h_store_rows(const u64 (&x)[32], u64 *__restrict__ halfp, int tid)
+        {
+            const int jb = Arr<T, 1>::tid_index(tid);
+#pragma unroll
+            for (int s = 0; s < 32; s += 2)
+                store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
+        }
+
         template <int LOGN, int STRICT, int REDUCE>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_fwd_half_kernel(
             u64 *__restrict__ data, const PrimeDev *__restrict__ primes, RowMap map, std::size_t nrows, int flags,
@@ -844,13 +930,14 @@ namespace sealhip
             const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
             const PrimeDev P = primes[pid];
-            const u64 p = P.p, two_p = P.two_p, rdp = P.rdp;
-            const u64 *tw = P.fwd;
+            constexpr bool FP = STRICT == 3; // butterflies on the FP64 pipe (primes below 2^50, see fp_reduce_all)
+            const u64 p = P.p, two_p = FP ? fp_bits(P.p_d) : P.two_p, rdp = P.rdp;
+            const u64 *tw = FP ? reinterpret_cast<const u64 *>(P.fwd_d) : P.fwd;
             u64 *rowp = data + (row << LOGN);
             u64 x[32];
 
             // ---- load both halves, top layer on the fly, arrangement 1 (block-uniform branch on the half)
-            const u64 neg_p = 0 - p;
+            const u64 neg_p = FP ? fp_bits(P.pinv_d) : 0 - p;
             const u64 *srcp = rowp;
             if (src.base[0])
             {
@@ -894,6 +981,8 @@ namespace sealhip
             // round 1: every lane index bit lies below the processed bits -> block-uniform twiddles
             u64 w0[kIL], ws0[kIL];
             RoundStage<T, 1, STRICT, true, 0>::load(w0, ws0, tw, gbase, N);
+            if constexpr (FP)
+                fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
@@ -903,6 +992,8 @@ namespace sealhip
                 h_exchange<T, 1, 2>(x, lds, fresh(tid));
             if (tid == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (FP)
+                fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
@@ -910,36 +1001,44 @@ namespace sealhip
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 2, 3>(x, lds, fresh(tid));
+            if constexpr (FP)
+                fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
             const int jb4 = gbase + Arr<T, 4>::tid_index(fresh(tid));
             u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
             if constexpr (FinalStage<T>::PIPE)
             {
-                StageTw<T, 0>::load(tg0, tw, jb4, N); // lands while the last exchange runs
+                StageTw<T, 0, 0, STRICT == 3>::load(tg0, tw, jb4, N); // lands while the last exchange runs
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 3, 4>(x, lds, fresh(tid));
+            if constexpr (FP)
+                fp_reduce_all(x, two_p, neg_p);
             NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
-            if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
-            {
-                unsigned spins = 0;
-                while (__hip_atomic_load(&tickets[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
+            const auto wait_for_sibling = [&] {
+                if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
                 {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > spin_limit)
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&tickets[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
                     {
-                        // never observed outside the tests that force it; do not hang the device: flag the launch as
-                        // failed (host-mapped word, read by every host-visible synchronisation point) and fall through
-                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > spin_limit)
+                        {
+                            // never observed outside the tests that force it; do not hang the device: flag the launch as
+                            // failed (host-mapped word, read by every host-visible synchronisation point) and fall through
+                            __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
                     }
                 }
-            }
-            // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
-            //  that both workgroups of the row have finished reading)
+                // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
+                //  that both workgroups of the row have finished reading)
+            };
+            if constexpr (!kStoreExchange<T, STRICT>)
+                wait_for_sibling(); // the final round stores as it goes
             NTT_STAMP(3);
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
             const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
@@ -950,6 +1049,13 @@ namespace sealhip
                 FinalPipe<T, STRICT, ROUT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             else
                 FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+            if constexpr (kStoreExchange<T, STRICT>)
+            {
+                if (!NTT_EXP(flags, 0x200))
+                    h_exchange<T, 4, 1>(x, lds, fresh(tid));
+                wait_for_sibling();
+                h_store_rows<T>(x, rowp + gbase, fresh(tid));
+            }
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
             if ((flags & 0x2000) && tid == 0 && g_ntt_trace)
@@ -990,7 +1096,16 @@ namespace sealhip
             }
             static constexpr int max_shift = 1 + (r1 > T - 2 - r1 ? r1 : T - 2 - r1);
         };
-        template <int T, int R, bool UNIFORM, int K, bool LZ = false>
+        // Floating-point schedule of the inverse (LZ == 2, primes below 2^50, inputs below 2p): sums double the bound per
+        // layer, so both outputs of layers 0, 3, 6, ... are brought back to [-p/2, p/2]: 2p -> 4p | 0.5p -> p -> 2p -> 4p |
+        // ..., products of differences stay below 1.5p. Everything below 8p <= 2^53 is exact (devmath.hpp). The last layer's
+        // outputs are canonicalised by the store instead.
+        template <int T>
+        constexpr bool fp_inv_reduce_after(int layer)
+        {
+            return layer % 3 == 0 && layer != T - 1;
+        }
+        template <int T, int R, bool UNIFORM, int K, int LZ = 0>
         struct RoundStageInv
         {
             static constexpr int PER = 16 / kIL;
@@ -1009,32 +1124,14 @@ namespace sealhip
                 for (int j = 0; j < kIL; j++)
                 {
                     u64x2 Wv;
-                    if (UNIFORM)
-                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
-#ifdef SEALHIP_NTT_TW_SHUFFLE
-                    // Measurement-only variant ("wavefront-shuffle twiddle propagation"): in round 2 the twiddle index only
-                    // depends on the lane bits above Arr::low_len, so one lane per group of 2^low_len loads the pair and the
-                    // others take it through the LDS crossbar (ds_bpermute, four dwords). Result (profiles/r02): slower --
-                    // the wave issues the same number of memory instructions (a load whose lanes share an address is one
-                    // request anyway) plus four cross-lane moves per twiddle, in a kernel bound by instruction issue.
-                    else if (R == 2 && Arr<T, R>::low_len >= 1)
+                    if constexpr (LZ == 2)
                     {
-                        const int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-                        const int leader = lane & ~((1 << (Arr<T, R>::low_len < 6 ? Arr<T, R>::low_len : 6)) - 1);
-                        u64x2 mine;
-                        mine.x = 0;
-                        mine.y = 0;
-                        if (lane == leader)
-                            mine = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
-                        const int a = leader << 2;
-                        const unsigned x0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x));
-                        const unsigned x1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.x >> 32));
-                        const unsigned y0 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y));
-                        const unsigned y1 = __builtin_amdgcn_ds_bpermute(a, static_cast<int>(mine.y >> 32));
-                        Wv.x = static_cast<u64>(x0) | (static_cast<u64>(x1) << 32);
-                        Wv.y = static_cast<u64>(y0) | (static_cast<u64>(y1) << 32);
+                        Wv.x = UNIFORM ? ((twd_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)]
+                                       : ((twd_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
+                        Wv.y = 0;
                     }
-#endif
+                    else if (UNIFORM)
+                        Wv = ((tw_const_t)tw)[__builtin_amdgcn_readfirstlane(tb) + Arr<T, R>::tw_offset(slot(j), W)];
                     else
                         Wv = ((tw_global_t)tw)[tb + Arr<T, R>::tw_offset(slot(j), W)];
                     w[j] = Wv.x;
@@ -1045,6 +1142,21 @@ namespace sealhip
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
                                                        u64 neg_p, u64 rdp)
             {
+                if constexpr (LZ == 2)
+                {
+                    const double pd = fp_of(two_p), pinv = fp_of(neg_p);
+#pragma unroll
+                    for (int j = 0; j < kIL; j++)
+                    {
+                        fp_butterfly_inv(x[slot(j)], x[slot(j) | bit], w[j], pd, pinv);
+                        if constexpr (fp_inv_reduce_after<T>(layer))
+                        {
+                            x[slot(j)] = fp_bits(fp_reduce(fp_of(x[slot(j)]), pd, pinv));
+                            x[slot(j) | bit] = fp_bits(fp_reduce(fp_of(x[slot(j) | bit]), pd, pinv));
+                        }
+                    }
+                    return;
+                }
                 u64 u[kIL], y[kIL];
 #pragma unroll
                 for (int j = 0; j < kIL; j++)
@@ -1052,7 +1164,7 @@ namespace sealhip
                     u[j] = x[slot(j)];
                     y[j] = x[slot(j) | bit];
                 }
-                if constexpr (LZ)
+                if constexpr (LZ == 1)
                     butterflies_inv_hs<UNIFORM, kIL, InvLazy<T>::mode(layer)>(u, y, w, ws, neg_p,
                                                                              (0 - neg_p) << InvLazy<T>::shift(layer), rdp);
                 else
@@ -1065,7 +1177,7 @@ namespace sealhip
                 }
             }
         };
-        template <int T, int R, bool UNIFORM, bool LZ, int K = 0>
+        template <int T, int R, bool UNIFORM, int LZ, int K = 0>
         struct RoundPipeInv
         {
             static constexpr int NST = 4 * (16 / kIL);
@@ -1087,7 +1199,7 @@ namespace sealhip
         // layers (index bits 0 .. f-1, ascending); group twiddles in the order used: layer W = 0 (2^(f-1) entries),
         // W = 1, ..., W = f-1 (1 entry). All coefficients are loaded before (one exposed latency), twiddles are
         // requested one stage (FinalStage<T>::SG groups) ahead.
-        template <int T, int G>
+        template <int T, int G, bool FP = false>
         __device__ __forceinline__ void h_first_tw(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
         {
             constexpr int f = T - 12;
@@ -1100,12 +1212,15 @@ namespace sealhip
                 for (int o = 0; o < (1 << (f - 1 - W)); o++)
                 {
                     const int s = (G << f) | (o << (W + 1));
-                    tg[base + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    if constexpr (FP)
+                        tg[base + o].x = ((twd_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
+                    else
+                        tg[base + o] = ((tw_global_t)tw)[tb + Arr<T, 4>::tw_offset(s, W)];
                 }
                 base += 1 << (f - 1 - W);
             }
         }
-        template <int T, int G, bool LZ>
+        template <int T, int G, int LZ>
         __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
         {
             constexpr int f = T - 12;
@@ -1115,7 +1230,7 @@ namespace sealhip
             for (int W = 0; W < f; W++)
             {
                 const int bit = 1 << W;
-                const u64 addend = LZ ? (0 - neg_p) << InvLazy<T>::shift(W) : two_p; // layer index = W
+                const u64 addend = LZ == 1 ? (0 - neg_p) << InvLazy<T>::shift(W) : two_p; // layer index = W
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
                 {
@@ -1123,6 +1238,17 @@ namespace sealhip
                         continue;
                     const int s = (G << f) | e;
                     const u64x2 Wv = tg[base + (e >> (W + 1))];
+                    if constexpr (LZ == 2)
+                    {
+                        const double pd = fp_of(two_p), pinv = fp_of(neg_p);
+                        fp_butterfly_inv(x[s], x[s | bit], Wv.x, pd, pinv);
+                        if (fp_inv_reduce_after<T>(W))
+                        {
+                            x[s] = fp_bits(fp_reduce(fp_of(x[s]), pd, pinv));
+                            x[s | bit] = fp_bits(fp_reduce(fp_of(x[s | bit]), pd, pinv));
+                        }
+                        continue;
+                    }
                     const u64 u = x[s], v = x[s | bit];
                     u64 tt = u + v;
                     if (!LZ)
@@ -1133,12 +1259,12 @@ namespace sealhip
                 base += 1 << (f - 1 - W);
             }
         }
-        template <int T, int ST, bool LZ, int I = 0>
+        template <int T, int ST, int LZ, int I = 0>
         struct FirstStage
         {
             __device__ static __forceinline__ void load(u64x2 *tg, const u64 *__restrict__ tw, int jb, int N)
             {
-                h_first_tw<T, ST * FinalStage<T>::SG + I>(tg + I * FinalStage<T>::NTW, tw, jb, N);
+                h_first_tw<T, ST * FinalStage<T>::SG + I, LZ == 2>(tg + I * FinalStage<T>::NTW, tw, jb, N);
                 if constexpr (I + 1 < FinalStage<T>::SG)
                     FirstStage<T, ST, LZ, I + 1>::load(tg, tw, jb, N);
             }
@@ -1149,7 +1275,7 @@ namespace sealhip
                     FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p);
             }
         };
-        template <int T, int ST, bool LZ>
+        template <int T, int ST, int LZ>
         struct FirstPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
@@ -1244,8 +1370,21 @@ namespace sealhip
             for (int j = 0; j < IL; j++)
                 t[j] = hi[j] + mh[j] + (lo[j] != 0); // lo + m p is a multiple of 2^64: its low word carries iff lo != 0
         }
-        // the half row's 32 words per lane, arrangement 4, as products of two (c_0, c_2) or four (c_1) input rows
+        // The inverse starts in arrangement 4 (runs of 2^f consecutive coefficients per lane). Loading the rows that way
+        // means 16-byte pieces at a 2^f * 8-byte stride per instruction for f >= 2 -- the mirror image of the store pattern
+        // described at kStoreExchange. With SEALHIP_NTT_LOAD_EXCHANGE=1 the rows are loaded in arrangement 1 for f >= 2
+        // (contiguous kilobytes per instruction; the tensor products are position-independent and are formed there) and
+        // moved to arrangement 4 through the LDS. Measured (profiles/r02/ntt_store_pattern.txt): no gain -- unlike the
+        // stores, the second load instruction of a line hits in the CU's L1 (plain inverse 3.85 vs 4.01 M rows/s at
+        // N = 2^15, tensor inverse 14.1 vs 14.0 ms per 1024 pairs) -- so it stays off.
+#ifndef SEALHIP_NTT_LOAD_EXCHANGE
+#define SEALHIP_NTT_LOAD_EXCHANGE 0
+#endif
         template <int T>
+        constexpr int kInvLoadArr = (SEALHIP_NTT_LOAD_EXCHANGE != 0 && (T - 12) >= 2) ? 1 : 4;
+
+        // the half row's 32 words per lane, arrangement A, as products of two (c_0, c_2) or four (c_1) input rows
+        template <int T, int A>
         __device__ __forceinline__ void h_load_dyadic2(u64 (&x)[32], const u64 *__restrict__ a, const u64 *__restrict__ b,
                                                        int jloc, u64 p, u64 ninv)
         {
@@ -1256,7 +1395,7 @@ namespace sealhip
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                 {
-                    const int idx = jloc + Arr<T, 4>::slot_index((batch * 4 + i) * 2);
+                    const int idx = jloc + Arr<T, A>::slot_index((batch * 4 + i) * 2);
                     va[i] = *reinterpret_cast<const ulonglong2 *>(a + idx);
                     vb[i] = *reinterpret_cast<const ulonglong2 *>(b + idx);
                 }
@@ -1274,7 +1413,7 @@ namespace sealhip
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        template <int T>
+        template <int T, int A>
         __device__ __forceinline__ void h_load_dyadic4(u64 (&x)[32], const u64 *__restrict__ a0, const u64 *__restrict__ b1,
                                                        const u64 *__restrict__ a1, const u64 *__restrict__ b0, int jloc, u64 p,
                                                        u64 ninv)
@@ -1286,7 +1425,7 @@ namespace sealhip
 #pragma unroll
                 for (int i = 0; i < 2; i++)
                 {
-                    const int idx = jloc + Arr<T, 4>::slot_index((batch * 2 + i) * 2);
+                    const int idx = jloc + Arr<T, A>::slot_index((batch * 2 + i) * 2);
                     v0[i] = *reinterpret_cast<const ulonglong2 *>(a0 + idx);
                     v1[i] = *reinterpret_cast<const ulonglong2 *>(b1 + idx);
                     v2[i] = *reinterpret_cast<const ulonglong2 *>(a1 + idx);
@@ -1308,7 +1447,7 @@ namespace sealhip
         // -- it still holds its own half in registers -- reads the sibling's half back, applies the layer to both halves and
         // stores the whole row. Nobody waits for anybody: the first finisher just leaves. Saves the separate streaming
         // kernel (read N + write N from HBM) of the standalone inverse transforms.
-        template <int LOGN, bool LZ, bool DY, bool TOPF = false>
+        template <int LOGN, int LZ, bool DY, bool TOPF = false>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
@@ -1330,20 +1469,23 @@ namespace sealhip
             const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
             const PrimeDev P = primes[pid];
-            const u64 p = P.p, two_p = P.two_p;
-            const u64 *tw = P.inv;
+            constexpr bool FP = LZ == 2; // two_p / neg_p then carry the bits of p and 1/p as doubles (see fp_reduce_all)
+            static_assert(!FP || (!DY && !TOPF), "the floating-point instance serves plain half transforms only");
+            const u64 p = P.p, two_p = FP ? fp_bits(P.p_d) : P.two_p;
+            const u64 *tw = FP ? reinterpret_cast<const u64 *>(P.inv_d) : P.inv;
             const int gbase = half << T;
             u64 *halfp = data + (row << LOGN) + gbase;
             // optional out-of-place input (polynomial-strided rows of another buffer): saves a copy kernel
             const u64 *inp = src ? src + (row / map.rows) * src_poly_stride + ((row % map.rows) << LOGN) + gbase : halfp;
             u64 x[32];
-            const u64 neg_p = 0 - p;
+            const u64 neg_p = FP ? fp_bits(P.pinv_d) : 0 - p;
             {
                 // every coefficient of the half row first (16 x 16 bytes per lane in flight at once), the twiddles of
                 // the first stage with them
-                const int jloc = Arr<T, 4>::tid_index(fresh(tid));
+                constexpr int LA = kInvLoadArr<T>;
+                const int jloc = Arr<T, 4>::tid_index(fresh(tid)), jl = Arr<T, LA>::tid_index(fresh(tid));
                 u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
-                if constexpr (!DY)
+                if constexpr (!DY && LA == 4)
                     FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
                 if constexpr (DY)
                 {
@@ -1352,40 +1494,47 @@ namespace sealhip
                     const u64 *xr = dy.x + poly * dy.item_stride + (static_cast<std::size_t>(r) << LOGN) + gbase;
                     const std::size_t ps = dy.poly_stride;
                     if (I == 1) // block-uniform
-                        h_load_dyadic4<T>(x, xr, xr + 3 * ps, xr + ps, xr + 2 * ps, jloc, p, P.ninv);
+                        h_load_dyadic4<T, LA>(x, xr, xr + 3 * ps, xr + ps, xr + 2 * ps, jl, p, P.ninv);
                     else if (I == 0)
-                        h_load_dyadic2<T>(x, xr, xr + 2 * ps, jloc, p, P.ninv);
+                        h_load_dyadic2<T, LA>(x, xr, xr + 2 * ps, jl, p, P.ninv);
                     else
-                        h_load_dyadic2<T>(x, xr + ps, xr + 3 * ps, jloc, p, P.ninv);
+                        h_load_dyadic2<T, LA>(x, xr + ps, xr + 3 * ps, jl, p, P.ninv);
                     // (the first stage's twiddles only now: held across the products they cost 24 registers of scratch)
-                    FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
+                    if constexpr (LA == 4)
+                        FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
                 }
                 else
                 {
 #pragma unroll
                     for (int s = 0; s < 32; s += 2)
                     {
-                        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(inp + jloc + Arr<T, 4>::slot_index(s));
-                        x[s] = v.x;
-                        x[s + 1] = v.y;
+                        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(inp + jl + Arr<T, LA>::slot_index(s));
+                        x[s] = FP ? fp_bits(fp_from_u64(v.x)) : v.x; // (inputs below 2p < 2^52)
+                        x[s + 1] = FP ? fp_bits(fp_from_u64(v.y)) : v.y;
                     }
+                }
+                if constexpr (LA != 4)
+                {
+                    FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N); // lands while the exchange runs
+                    __builtin_amdgcn_sched_barrier(0);
+                    h_exchange<T, LA, 4>(x, lds, fresh(tid));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 FirstPipe<T, 0, LZ>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
             }
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
             u64 w0[kIL], ws0[kIL];
-            const u64 rdp = LZ ? P.rdp : 0; // only the reducing layers of the lazy schedule read it
-            RoundStageInv<T, 3, false, 0>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
+            const u64 rdp = LZ == 1 ? P.rdp : 0; // only the reducing layers of the lazy schedule read it
+            RoundStageInv<T, 3, false, 0, LZ>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 4, 3>(x, lds, fresh(tid));
             RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
-            RoundStageInv<T, 2, false, 0>::load(w0, ws0, tw, jb2, N);
+            RoundStageInv<T, 2, false, 0, LZ>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 3, 2>(x, lds, fresh(tid));
             RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp);
-            RoundStageInv<T, 1, true, 0>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
+            RoundStageInv<T, 1, true, 0, LZ>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh(tid));
             RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
             if constexpr (!TOPF)
@@ -1394,7 +1543,11 @@ namespace sealhip
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
-                    store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
+                    if constexpr (FP) // canonical residues: below 2p as the consumers of the lazy form expect, and exact
+                        store_nt(halfp + jb + Arr<T, 1>::slot_index(s), fp_to_u64(fp_canonical(fp_of(x[s]), fp_of(two_p), fp_of(neg_p))),
+                                 fp_to_u64(fp_canonical(fp_of(x[s + 1]), fp_of(two_p), fp_of(neg_p))));
+                    else
+                        store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
                 }
             }
             else
@@ -1536,13 +1689,18 @@ namespace sealhip
                 bool lazy = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !exact_only;
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
+                // floating-point instance: same contract (inputs below 2p, any representative out), every live prime below 2^50
+                static const bool no_fp = std::getenv("SEALHIP_NTT_NO_FP64") != nullptr;
+                bool fp = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !no_fp && !dyadic;
+                for (int i = 0; fp && i < live.n; i++)
+                    fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
                 const DyadicSrc dy = dyadic ? *dyadic : DyadicSrc{};
                 // standalone transforms (top layer not left to a consumer): SEALHIP_NTT_INV_ONE_LAUNCH=1 lets the second
                 // finisher of every row apply the top layer instead of the streaming top-layer kernel. Bit-exact, measured
                 // (profiles/r02): 6.7 vs 7.4 M NTT/s at N = 2^14, 3.29 vs 3.26 at 2^15, 1.43 vs 1.41 at 2^16 -- what the
                 // second launch costs, the longer-lived workgroups cost too; so the two-launch form stays the default.
                 static const bool one_launch = std::getenv("SEALHIP_NTT_INV_ONE_LAUNCH") != nullptr;
-                const bool topf = !(flags & kNttDeferTop) && !dyadic && one_launch;
+                const bool topf = !(flags & kNttDeferTop) && !dyadic && one_launch && !fp;
                 unsigned *tickets = topf ? e.ntt_tickets(nrows) : nullptr;
                 if (topf && !tickets)
                     return hipErrorOutOfMemory;
@@ -1555,22 +1713,24 @@ namespace sealhip
                 if (topf)
                 {
                     if (lazy)
-                        SEALHIP_INV_HALF_TOP(true);
+                        SEALHIP_INV_HALF_TOP(1);
                     else
-                        SEALHIP_INV_HALF_TOP(false);
+                        SEALHIP_INV_HALF_TOP(0);
                     return hipGetLastError();
                 }
                 if (dyadic)
                 {
                     if (lazy)
-                        SEALHIP_INV_HALF(true, true);
+                        SEALHIP_INV_HALF(1, true);
                     else
-                        SEALHIP_INV_HALF(false, true);
+                        SEALHIP_INV_HALF(0, true);
                 }
+                else if (fp)
+                    SEALHIP_INV_HALF(2, false);
                 else if (lazy)
-                    SEALHIP_INV_HALF(true, false);
+                    SEALHIP_INV_HALF(1, false);
                 else
-                    SEALHIP_INV_HALF(false, false);
+                    SEALHIP_INV_HALF(0, false);
 #undef SEALHIP_INV_HALF
 #undef SEALHIP_INV_HALF_TOP
                 hipError_t err = hipGetLastError();
@@ -1653,6 +1813,22 @@ namespace sealhip
                 }
             } trace_dump{trace, trace_path, blocks, e.lane().stream};
 #endif
+            // Floating-point instance (devmath.hpp): every live prime below 2^50, inputs below 2^52 (residues, or gathered
+            // words of another key prime, or the output of a load treatment), and a launch that does not ask for the
+            // integer sequence's own representatives (canonical output, or a consumer that reduces whatever it reads).
+            // The result is the canonical residue, so the integer instances' flags play no further role.
+            static const bool no_fp = std::getenv("SEALHIP_NTT_NO_FP64") != nullptr;
+            bool fp = !no_fp && (flags & (kNttAnyRep | kNttCanonical)) != 0 && (flags & kNttReduceOut) == 0;
+            for (int i = 0; fp && i < live.n; i++)
+                fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
+            if (fp && src.base[0])
+            {
+                if (src.reduce_mode == 4)
+                    fp = src.aux_p < (u64(1) << 52);
+                else
+                    for (std::size_t i = 0; fp && i < e.key_moduli.size(); i++)
+                        fp = e.key_moduli[i] < (u64(1) << 52);
+            }
             if (flags & kNttAnyRep)
             {
                 // the last layer may keep its first operand unreduced only if the grown values cannot wrap
@@ -1684,7 +1860,18 @@ namespace sealhip
                        red != 4;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
-            if (apx)
+            if (fp)
+            {
+                if (red == 4)
+                    SEALHIP_FWD_HALF(3, 4);
+                else if (red == 2)
+                    SEALHIP_FWD_HALF(3, 2);
+                else if (red == 1)
+                    SEALHIP_FWD_HALF(3, 1);
+                else
+                    SEALHIP_FWD_HALF(3, 0);
+            }
+            else if (apx)
             {
                 if (red == 2)
                     SEALHIP_FWD_HALF(2, 2);
@@ -1728,7 +1915,11 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[13] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 4>),
+            const void *fwd[17] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 0>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 1>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 2>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 4>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 4>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 4>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 3>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 3>),
@@ -1747,12 +1938,13 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            const void *inv[6] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false, true>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, false, true>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, false>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, false>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, true, true>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, false, true>) };
+            const void *inv[7] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, true>) };
             for (const void *f : inv)
             {
                 err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -77,6 +77,60 @@ def test_ntt_all_variants_vs_oracle(sealhip, logn, bits):
     assert np.array_equal(buf.download(x.shape), x)
 
 
+@pytest.mark.parametrize("logn", [14, 15, 16])
+def test_ntt_fp64_instances_extreme_inputs(sealhip, logn):
+    """Primes below 2^50 take the floating-point single-pass kernels whenever the output's representative is free
+    (canonical transforms, kNttAnyRep consumers). Their exactness argument is a bound (magnitudes below 2^53); drive it
+    with the largest admissible primes and the inputs that maximise growth -- all p-1, alternating 0 / p-1, one spike,
+    random -- for the forward transform, and values in [0, 2p) (what the lazy inverse accepts) for the inverse. Bit-exact
+    against the oracle's integer transforms (ntt.cpp:210-281)."""
+    n = 1 << logn
+    mods = O.get_primes(n, 50, 3) + O.get_primes(n, 49, 1) + O.get_primes(n, 30, 1) + O.get_primes(n, 57, 1)
+    k = len(mods) - 1
+    assert max(mods[:k]) < (1 << 50) and max(mods[:3]) > (1 << 50) - (1 << 40)
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    tabs = [O.Tables(logn, p) for p in mods[:k]]
+    rng = np.random.default_rng(50 + logn)
+    pats = []
+    for kind in range(5):
+        x = np.zeros((k, n), dtype=np.uint64)
+        for i, p in enumerate(mods[:k]):
+            if kind == 0:
+                x[i, :] = p - 1
+            elif kind == 1:
+                x[i, ::2] = p - 1
+            elif kind == 2:
+                x[i, n // 2:] = p - 1
+            elif kind == 3:
+                x[i, rng.integers(0, n)] = p - 1
+            else:
+                x[i] = rng.integers(0, p, n, dtype=np.uint64)
+        pats.append(x)
+    x = np.stack(pats)
+    buf = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey(buf, len(pats), k)
+    got = buf.download(x.shape)
+    exp = x.copy()
+    for c in range(len(pats)):
+        for i in range(k):
+            L.ref_ntt_forward(O.ptr(exp[c, i]), C.byref(tabs[i].t), 0)
+    assert np.array_equal(got, exp), "forward"
+    # inverse: canonical inputs, and the lazy range [0, 2p) (same residues, the canonical output must not change)
+    for lazy_in in (False, True):
+        y = x.copy()
+        if lazy_in:
+            for i, p in enumerate(mods[:k]):
+                y[:, i, 1::3] += np.uint64(p)
+        buf = ctx.upload(y)
+        ctx.inverse_ntt_negacyclic_harvey(buf, len(pats), k)
+        got = buf.download(x.shape)
+        exp = x.copy()
+        for c in range(len(pats)):
+            for i in range(k):
+                L.ref_ntt_inverse(O.ptr(exp[c, i]), C.byref(tabs[i].t))
+        assert np.array_equal(got, exp), "inverse lazy_in=%s" % lazy_in
+
+
 @pytest.mark.parametrize("row", DIG["ntt_digests"], ids=lambda r: "logn%d_k%d" % (r["logn"], len(r["bits"])))
 def test_ntt_golden_digests(sealhip, row):
     """The survey's digests of util::ntt_negacyclic_harvey & co. from the compiled reference."""

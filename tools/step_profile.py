@@ -1,24 +1,35 @@
-"""Absolute kernel times (HIP events) of one multiply+relinearize step at config 3 size: tools/step_profile.py [batch]"""
+"""Absolute kernel times (HIP events) of one step: tools/step_profile.py [batch] [cfg3|cfg4|cfg4mul]
+cfg3: BFV multiply+relinearize at config 3; cfg4: CKKS rotate_vector at config 4; cfg4mul: CKKS multiply+relinearize."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gemini-seal_amd")); sys.path.insert(0, ROOT)
 import torch, bench, sealhip as S
-from tools.bench_configs import mk
+from tools.bench_configs import mk, P15_12
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-n, k, pr = 1 << 15, 7, bench.CFG3_PRIMES
-ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433)
+which = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
+n = 1 << 15
+if which == "cfg3":
+    k, pr = 7, bench.CFG3_PRIMES
+    ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433)
+else:
+    k, pr = 11, P15_12
+    ctx = S.Context(S.SCHEME_CKKS, 15, pr, 1, 0)
 ctx.use_default_stream()  # torch fills run on the legacy default stream: same stream, ordered
 ev = S.Evaluator(ctx)
 x, y = mk(ctx, (B, 2, k, n), pr[:k], dev), mk(ctx, (B, 2, k, n), pr[:k], dev)
 o = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
-rk = S.KSwitchKeys(ctx, mk(ctx, (k, 2, 8, n), pr, dev), n_digits=k, from_host=False)
+rk = S.KSwitchKeys(ctx, mk(ctx, (k, 2, k + 1, n), pr, dev), n_digits=k, from_host=False)
+elt = ctx.galois_elt_from_step(1) if which == "cfg4" else None
 def step():
-    ev.multiply(x, 2, y, 2, k, B, o); ev.relinearize_inplace(o, 3, k, B, [rk])
+    if which == "cfg4":
+        ev.rotate_vector_inplace(x, k, B, 1, {elt: rk})
+    else:
+        ev.multiply(x, 2, y, 2, k, B, o); ev.relinearize_inplace(o, 3, k, B, [rk])
 step(); ctx.synchronize()
 ctx.profile_enable(True)
 for _ in range(3):
     step()
 ctx.synchronize()
 prof = ctx.profile_fetch()
-print({t: round(v["ms"] / 3, 3) for t, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}, "total", round(sum(v["ms"] for v in prof.values()) / 3, 2))
+print(which, {t: round(v["ms"] / 3, 3) for t, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}, "total", round(sum(v["ms"] for v in prof.values()) / 3, 2))
