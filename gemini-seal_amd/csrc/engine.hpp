@@ -420,13 +420,16 @@ namespace sealhip
     hipError_t launch_ks_moddown_pre(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
                                      std::size_t prod_stride, u64 *temp, std::size_t temp_stride, std::size_t npolys);
     // BFV only: steps 1-4 of the rescale + the add into the ciphertext in one kernel; top_deferred = the rows of prod
-    // come from an inverse NTT launched with kNttDeferTop
+    // come from an inverse NTT launched with kNttDeferTop. c0_src (both mod-down launchers): when set, the ciphertext is
+    // not read: component 0 becomes c0_src + result, component 1 the result (apply_galois: the ciphertext the key switch
+    // adds into is (galois(c0), 0), evaluator.cpp:1903-1935 -- no copy of c0, no zero fill of c1).
     hipError_t launch_ks_moddown_bfv(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
                                      std::size_t prod_stride, u64 *ct, std::size_t ct_item_stride, std::size_t npolys,
-                                     bool top_deferred);
+                                     bool top_deferred, const u64 *c0_src = nullptr, std::size_t c0_stride = 0);
     hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
                                       std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
-                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct);
+                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct,
+                                      const u64 *c0_src = nullptr, std::size_t c0_stride = 0);
 
     // ---- batches of separately allocated host ciphertexts (hostbatch.cpp) ----
     struct HostBatchIO
@@ -451,8 +454,9 @@ namespace sealhip
     void run_host_batch(Engine &e, const HostBatchIO &io, std::size_t count, const HostChunkFn &fn);
 
     // ---- composed operations (pipeline.cpp) ----
+    // c0_src: see launch_ks_moddown_bfv -- the ciphertext is then write-only: (c0_src + result_0, result_1)
     void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
-                       std::size_t count, const KSwitchKey &key);
+                       std::size_t count, const KSwitchKey &key, const u64 *c0_src = nullptr, std::size_t c0_stride = 0);
     void op_modup(Engine &e, int k, int bundle, u64 *ext, std::size_t count);
     void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
     void op_ckks_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);

@@ -268,7 +268,8 @@ namespace sealhip
                                                                            u64 *__restrict__ ct,
                                                                            std::size_t ct_item_stride,
                                                                            std::size_t npolys, int logn,
-                                                                           int add_into_ct)
+                                                                           int add_into_ct, const u64 *__restrict__ c0_src,
+                                                                           std::size_t c0_stride)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const int k = d->k;
@@ -287,7 +288,10 @@ namespace sealhip
             {
                 // polynomial `poly` is component (poly & 1) of ciphertext (poly >> 1)
                 u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
-                *pc = add_mod(v, *pc, Q.p);
+                if (!c0_src)
+                    *pc = add_mod(v, *pc, Q.p);
+                else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
+                    *pc = (poly & 1) ? v : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c], Q.p);
             }
             else
                 *pp = v;
@@ -326,7 +330,8 @@ namespace sealhip
                                                                           const u64 *__restrict__ prod,
                                                                           std::size_t prod_stride, u64 *__restrict__ ct,
                                                                           std::size_t ct_item_stride, std::size_t npolys,
-                                                                          int logn)
+                                                                          int logn, const u64 *__restrict__ c0_src,
+                                                                          std::size_t c0_stride)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn, half = N >> 1;
             const int k = d->k, nsp = d->nsp;
@@ -379,7 +384,12 @@ namespace sealhip
             for (int h = 0; h < 2; h++)
             {
                 const u64 v = mulmod_shoup(pv[h] + temp[h], d->invP[q], d->invP_shoup[q], Q.p);
-                pc[h * half] = add_mod(v, pc[h * half], Q.p);
+                if (!c0_src)
+                    pc[h * half] = add_mod(v, pc[h * half], Q.p);
+                else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
+                    pc[h * half] = (poly & 1) ? v
+                                              : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c + h * half],
+                                                        Q.p);
             }
         }
 
@@ -459,31 +469,32 @@ namespace sealhip
 
     hipError_t launch_ks_moddown_bfv(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
                                      std::size_t prod_stride, u64 *ct, std::size_t ct_item_stride, std::size_t npolys,
-                                     bool top_deferred)
+                                     bool top_deferred, const u64 *c0_src, std::size_t c0_stride)
     {
         if (!npolys)
             return hipSuccess;
         const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << (e.logn - 1); // one lane per coefficient pair
         ProfScope prof(e, "ks_moddown_bfv", 0);
         if (top_deferred)
-            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, prod, prod_stride, ct,
-                                                                                     ct_item_stride, npolys, e.logn);
+            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
+                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride);
         else
-            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, prod, prod_stride, ct,
-                                                                                      ct_item_stride, npolys, e.logn);
+            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
+                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride);
         return hipGetLastError();
     }
 
     hipError_t launch_ks_moddown_post(const Engine &e, const KsDev *d, const KsDev &h, u64 *prod,
                                       std::size_t prod_stride, const u64 *temp, std::size_t temp_stride, u64 *ct,
-                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct)
+                                      std::size_t ct_item_stride, std::size_t npolys, int add_into_ct, const u64 *c0_src,
+                                      std::size_t c0_stride)
     {
         if (!npolys)
             return hipSuccess;
         const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
         ProfScope prof(e, "ks_moddown_post", 0);
         ks_moddown_post_kernel<<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-            d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct);
+            d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct, c0_src, c0_stride);
         return hipGetLastError();
     }
 } // namespace sealhip

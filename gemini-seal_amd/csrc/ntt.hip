@@ -21,6 +21,7 @@
 //
 // LDS image: index l is stored at l + (l >> 4) (one pad word per 16), which makes both the
 // stride-1 and the stride-16 access patterns of the rounds bank-conflict free for ds_read_b64.
+#include <cstring>
 #include <cstdlib>
 
 #include "engine.hpp"
@@ -775,6 +776,13 @@ namespace sealhip
                     for (int i = 0; i < kLoadBatch; i++)
                     {
                         const auto red = [&](u64 v) {
+                            if constexpr (STRICT == 3)
+                            {
+                                // floating-point instance: aux_p / aux_cr1 carry P and 1/P as doubles, v < 2^52; the word
+                                // stays a double (the top layer below does not convert it again)
+                                const double P = fp_of(aux_p), r = fp_canonical(fp_from_u64(v), P, fp_of(aux_cr1));
+                                return fp_bits(r != 0.0 ? P - r : 0.0);
+                            }
                             const u64 r = barrett_reduce_63(v, aux_p, aux_cr1);
                             return r ? aux_p - r : 0;
                         };
@@ -816,8 +824,11 @@ namespace sealhip
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                         {
-                            u[j] = fp_bits(fp_from_u64(u[j]));
-                            y[j] = fp_bits(fp_from_u64(y[j]));
+                            if constexpr (REDUCE != 4)
+                            {
+                                u[j] = fp_bits(fp_from_u64(u[j]));
+                                y[j] = fp_bits(fp_from_u64(y[j]));
+                            }
                             fp_butterfly_fwd(u[j], y[j], W1.x, fp_of(two_p), fp_of(neg_p));
                             x[s + j] = HALF ? y[j] : u[j];
                         }
@@ -1860,11 +1871,18 @@ namespace sealhip
                        red != 4;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
-            if (fp)
+            if (fp && red == 4)
             {
-                if (red == 4)
-                    SEALHIP_FWD_HALF(3, 4);
-                else if (red == 2)
+                NttSource fsrc = src; // the special prime as doubles (h_load_top)
+                const double P = static_cast<double>(src.aux_p), Pinv = 1.0 / P;
+                std::memcpy(&fsrc.aux_p, &P, 8);
+                std::memcpy(&fsrc.aux_cr1, &Pinv, 8);
+                ntt_fwd_half_kernel<LOGN, 3, 4><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
+                    data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+            }
+            else if (fp)
+            {
+                if (red == 2)
                     SEALHIP_FWD_HALF(3, 2);
                 else if (red == 1)
                     SEALHIP_FWD_HALF(3, 1);

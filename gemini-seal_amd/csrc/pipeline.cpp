@@ -89,7 +89,7 @@ namespace sealhip
     // switch_key_inplace (evaluator.cpp:2259-2368)
     // ------------------------------------------------------------------------------------------
     void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
-                       std::size_t count, const KSwitchKey &key)
+                       std::size_t count, const KSwitchKey &key, const u64 *c0_src, std::size_t c0_stride)
     {
         if (k > e.k_first)
             throw std::invalid_argument("key switching needs a ciphertext level");
@@ -122,6 +122,7 @@ namespace sealhip
             u64 *temp = e.ws_alloc(w_temp * m);
             const u64 *tg = target + off * target_stride;
             u64 *ctp = ct + off * ct_stride;
+            const u64 *c0p = c0_src ? c0_src + off * c0_stride : nullptr;
             const std::size_t ext_item = static_cast<std::size_t>(rows) * N;
             const std::size_t ext_digit = ext_item * m; // digit-major
 
@@ -225,7 +226,8 @@ namespace sealhip
                 const bool defer = ntt_can_defer_top(e, k);
                 // (ks_moddown_bfv reduces what it reads canonically: any representative below 2p will do)
                 check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, defer ? (kNttDeferTop | kNttAnyRep) : 0), "intt(prod)");
-                check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer), "moddown_bfv");
+                check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer, c0p, c0_stride),
+                      "moddown_bfv");
                 continue;
             }
             // (:2351-2355) special rows back to coefficient form (lazy)
@@ -254,7 +256,8 @@ namespace sealhip
                 ns.aux_cr1 = HostModulus(p_special).cr1;
                 for (int r = 0; r < k; r++)
                     ns.code[r] = static_cast<unsigned short>(k); // every row of temp reads the special row of its polynomial
-                check(launch_ntt_gather(e, temp, m * 2 * k, map_q, ns, 0), "ntt(temp, gathered from the special row)");
+                // (ks_moddown_post adds these rows to the q rows and reduces the sum canonically: any representative will do)
+                check(launch_ntt_gather(e, temp, m * 2 * k, map_q, ns, kNttAnyRep), "ntt(temp, gathered from the special row)");
             }
             else
             {
@@ -266,7 +269,7 @@ namespace sealhip
                     check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, 0), "intt(prod)");
             }
             check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
-                                         ct_stride, 2 * m, 1),
+                                         ct_stride, 2 * m, 1, c0p, c0_stride),
                   "moddown_post");
         }
     }
@@ -550,10 +553,10 @@ namespace sealhip
             }
             u64 *scratch = reinterpret_cast<u64 *>(static_cast<char *>(e.lane().ws) + guard.saved);
             check(launch_galois(e, c, scratch, m * 2 * k, lt.map_q, elt, table), "galois");
-            check(launch_copy_rows(e, scratch, 2 * poly, c, 2 * poly, m, k), "copy(c0)"); // :1903 / :1917
-            SEALHIP_CHECK(hipMemset2DAsync(c + poly, 2 * poly * sizeof(u64), 0, poly * sizeof(u64), m,
-                                           e.lane().stream)); // :1928
-            op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key); // :1934-1935
+            // The reference copies galois(c0) back (:1903 / :1917), zeroes c1 (:1928) and lets the key switch add its two
+            // polynomials into that ciphertext (:1934-1935). Here the key switch's last kernel writes (galois(c0) + r0, r1)
+            // directly: same sums, no copy pass and no fill pass over the ciphertext.
+            op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key, scratch, 2 * poly);
         }
     }
     // multiply_plain_normal (evaluator.cpp:1475-1603) for parameters with fast plain lift (every q_i > t): lift the
