@@ -44,8 +44,12 @@ namespace sealhip
         // every destination prime, so the canonical residue is x or x - p). Both are no-ops on rows whose source prime
         // does not exceed their own. 4: the CKKS mod-down with one special prime (multi_special_primes.cpp:262-273): the
         // word becomes -(x mod aux_p) as the integer aux_p - (x mod aux_p) (0 stays 0), aux_p = the special prime.
+        // 5: the same, on a source row whose inverse transform left its top layer to the consumer (kNttDeferTop): the
+        // transform reads the pairs (c, c + N/2) anyway and applies BackwardLazyLast (ntt.cpp:274-281) to them first;
+        // aux_top = the special prime's {n^-1, its Shoup quotient, w n^-1, its Shoup quotient}.
         int reduce_mode;
         u64 aux_p, aux_cr1;
+        u64 aux_top[4];
     };
     constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
 

@@ -746,7 +746,7 @@ namespace sealhip
         template <int T, int STRICT, int HALF, int REDUCE>
         __device__ __forceinline__ void h_load_top(u64 (&x)[32], const u64 *__restrict__ rowp,
                                                    const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1,
-                                                   u64 aux_p = 0, u64 aux_cr1 = 0)
+                                                   u64 aux_p = 0, u64 aux_cr1 = 0, const u64 *aux_top = nullptr)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
             u64x2 W1;
@@ -765,6 +765,40 @@ namespace sealhip
                     const int idx = jb + Arr<T, 1>::slot_index(s);
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
+                }
+                if constexpr (REDUCE == 5)
+                {
+                    // mode 4 on a source row whose top inverse layer was left to us: the pair (lo, hi) = (c, c + N/2) first
+                    // goes through BackwardLazyLast w.r.t. the special prime P (inputs below 2P), then -(. mod P)
+#pragma unroll
+                    for (int i = 0; i < kLoadBatch; i++)
+                    {
+                        const auto top = [&](u64 &u, u64 &v) {
+                            if constexpr (STRICT == 3)
+                            {
+                                // aux_p / aux_cr1: P and 1/P as doubles; aux_top[0], [2]: n^-1 and w n^-1 as doubles
+                                const double P = fp_of(aux_p), Pinv = fp_of(aux_cr1), ud = fp_from_u64(u), vd = fp_from_u64(v);
+                                const double a0 = fp_canonical(fp_mulmod(ud + vd, fp_of(aux_top[0]), P, Pinv), P, Pinv);
+                                const double a1 = fp_canonical(fp_mulmod(ud - vd, fp_of(aux_top[2]), P, Pinv), P, Pinv);
+                                u = fp_bits(a0 != 0.0 ? P - a0 : 0.0);
+                                v = fp_bits(a1 != 0.0 ? P - a1 : 0.0);
+                            }
+                            else
+                            {
+                                const u64 two_P = aux_p << 1;
+                                u64 tt = u + v;
+                                tt = tt >= two_P ? tt - two_P : tt;
+                                u64 a0 = mulmod_lazy(tt, aux_top[0], aux_top[1], aux_p); // below 2P
+                                u64 a1 = mulmod_lazy(u - v + two_P, aux_top[2], aux_top[3], aux_p);
+                                a0 = a0 >= aux_p ? a0 - aux_p : a0;
+                                a1 = a1 >= aux_p ? a1 - aux_p : a1;
+                                u = a0 ? aux_p - a0 : 0;
+                                v = a1 ? aux_p - a1 : 0;
+                            }
+                        };
+                        top(lo[i].x, hi[i].x);
+                        top(lo[i].y, hi[i].y);
+                    }
                 }
                 if constexpr (REDUCE == 4)
                 {
@@ -824,7 +858,7 @@ namespace sealhip
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                         {
-                            if constexpr (REDUCE != 4)
+                            if constexpr (REDUCE != 4 && REDUCE != 5)
                             {
                                 u[j] = fp_bits(fp_from_u64(u[j]));
                                 y[j] = fp_bits(fp_from_u64(y[j]));
@@ -977,9 +1011,9 @@ namespace sealhip
                     x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
             }
             else if (half)
-                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1);
+                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             else
-                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1);
+                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -1834,8 +1868,8 @@ namespace sealhip
                 fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
             if (fp && src.base[0])
             {
-                if (src.reduce_mode == 4)
-                    fp = src.aux_p < (u64(1) << 52);
+                if (src.reduce_mode == 4 || src.reduce_mode == 5)
+                    fp = src.aux_p < (src.reduce_mode == 5 ? kFpPrimeBound : u64(1) << 52); // (5: sums of two words below 2P)
                 else
                     for (std::size_t i = 0; fp && i < e.key_moduli.size(); i++)
                         fp = e.key_moduli[i] < (u64(1) << 52);
@@ -1868,17 +1902,24 @@ namespace sealhip
             // wrapper, no kNttReduceOut) and 50p cannot wrap: every live prime below 2^58.
             static const bool no_apx = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
             bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0 &&
-                       red != 4;
+                       red != 4 && red != 5;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
-            if (fp && red == 4)
+            if (fp && (red == 4 || red == 5))
             {
-                NttSource fsrc = src; // the special prime as doubles (h_load_top)
+                NttSource fsrc = src; // the special prime's constants as doubles (h_load_top)
                 const double P = static_cast<double>(src.aux_p), Pinv = 1.0 / P;
+                const double c0 = static_cast<double>(src.aux_top[0]), c2 = static_cast<double>(src.aux_top[2]);
                 std::memcpy(&fsrc.aux_p, &P, 8);
                 std::memcpy(&fsrc.aux_cr1, &Pinv, 8);
-                ntt_fwd_half_kernel<LOGN, 3, 4><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                    data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                std::memcpy(&fsrc.aux_top[0], &c0, 8);
+                std::memcpy(&fsrc.aux_top[2], &c2, 8);
+                if (red == 5)
+                    ntt_fwd_half_kernel<LOGN, 3, 5><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
+                        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                else
+                    ntt_fwd_half_kernel<LOGN, 3, 4><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
+                        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
             }
             else if (fp)
             {
@@ -1900,7 +1941,9 @@ namespace sealhip
             }
             else if (flags & kNttStrict)
             {
-                if (red == 4)
+                if (red == 5)
+                    SEALHIP_FWD_HALF(1, 5);
+                else if (red == 4)
                     SEALHIP_FWD_HALF(1, 4);
                 else if (red == 3)
                     SEALHIP_FWD_HALF(1, 3);
@@ -1913,7 +1956,9 @@ namespace sealhip
             }
             else
             {
-                if (red == 4)
+                if (red == 5)
+                    SEALHIP_FWD_HALF(0, 5);
+                else if (red == 4)
                     SEALHIP_FWD_HALF(0, 4);
                 else if (red == 3)
                     SEALHIP_FWD_HALF(0, 3);
@@ -1933,7 +1978,10 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[17] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 0>),
+            const void *fwd[20] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 5>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 5>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 5>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 0>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 1>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 2>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 4>),

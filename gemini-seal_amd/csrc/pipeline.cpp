@@ -230,13 +230,6 @@ namespace sealhip
                       "moddown_bfv");
                 continue;
             }
-            // (:2351-2355) special rows back to coefficient form (lazy)
-            // (the mod-down reduces the special rows with barrett_reduce_63 / a Shoup product: canonical either way)
-            check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, kNttAnyRep), "intt(special)");
-            // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
-            // Step 5 for CKKS with one special prime P: temp_i = (-(special mod P)) mod q_i, then its forward transform
-            // (multi_special_primes.cpp:262-289). With the single-pass kernel the transform gathers the special row and forms
-            // temp_i while it loads (reduce mode 4): no pass that writes the k rows of temp, none that reads them back.
             u64 p_special = 0, p_min = ~u64(0);
             if (ckks && e.nsp == 1)
             {
@@ -246,14 +239,31 @@ namespace sealhip
             }
             const bool fold_pre = ckks && e.nsp == 1 && ntt_can_gather(e) && p_special < 2 * p_min &&
                                   p_special < (u64(1) << 58) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
+            // the gathered transform below reads the special row as pairs (c, c + N/2): it can apply the top inverse layer
+            const bool fold_top = fold_pre && ntt_can_defer_top(e, k);
+            // (:2351-2355) special rows back to coefficient form (lazy)
+            // (the mod-down reduces the special rows with barrett_reduce_63 / a Shoup product: canonical either way)
+            check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, kNttAnyRep | (fold_top ? kNttDeferTop : 0)),
+                  "intt(special)");
+            // Step 5 (:2361): rescale_special_rns_inplace, then add into the ciphertext (:2363-2366)
+            // Step 5 for CKKS with one special prime P: temp_i = (-(special mod P)) mod q_i, then its forward transform
+            // (multi_special_primes.cpp:262-289). With the single-pass kernel the transform gathers the special row and forms
+            // temp_i while it loads (reduce mode 4): no pass that writes the k rows of temp, none that reads them back.
             if (fold_pre)
             {
                 NttSource ns{};
                 ns.base[0] = prod;
                 ns.poly_stride[0] = ext_item;
-                ns.reduce_mode = 4;
+                ns.reduce_mode = fold_top ? 5 : 4;
                 ns.aux_p = p_special;
                 ns.aux_cr1 = HostModulus(p_special).cr1;
+                {
+                    const HostNttTables &tb = e.tables[h.row_prime[k]];
+                    ns.aux_top[0] = tb.inv_n;
+                    ns.aux_top[1] = tb.inv_n_shoup;
+                    ns.aux_top[2] = tb.inv_n_w;
+                    ns.aux_top[3] = tb.inv_n_w_shoup;
+                }
                 for (int r = 0; r < k; r++)
                     ns.code[r] = static_cast<unsigned short>(k); // every row of temp reads the special row of its polynomial
                 // (ks_moddown_post adds these rows to the q rows and reduces the sum canonically: any representative will do)
