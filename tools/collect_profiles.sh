@@ -25,5 +25,19 @@ python3 tools/ntt_only.py --logn 14 --polys 1024 --inverse >> $out/ntt_only.txt 
 python3 tools/ntt_only.py --logn 16 --polys 512 >> $out/ntt_only.txt 2>&1
 python3 tools/ntt_only.py --logn 16 --polys 512 --inverse >> $out/ntt_only.txt 2>&1
 python3 tools/step_profile.py 1024 > $out/step_profile_b1024.txt 2>&1
+python3 tools/step_profile.py 1024 cfg4 2>&1 | grep "^cfg" > $out/step_profile_side_configs.txt
+python3 tools/step_profile.py 1024 cfg4mul 2>&1 | grep "^cfg" >> $out/step_profile_side_configs.txt
+python3 tools/step_profile.py 256 cfg5 2>&1 | grep "^cfg" >> $out/step_profile_side_configs.txt
+python3 tools/step_profile.py 4096 cfg1 2>&1 | grep "^cfg" >> $out/step_profile_side_configs.txt
+# 5. FP64 against integer NTT instances on 50-bit primes (same box, back to back)
+for l in 14 15 16; do
+  python3 tools/ntt_ab.py $l $((672*32768/(1<<l))) 2>&1 | grep logn | sed 's/^/fp64 /' >> $out/ntt_fp64_ab.txt
+  SEALHIP_NTT_NO_FP64=1 python3 tools/ntt_ab.py $l $((672*32768/(1<<l))) 2>&1 | grep logn | sed 's/^/int  /' >> $out/ntt_fp64_ab.txt
+done
+# 6. kernel trace of the config-4 rotate step (what the per-tag profile does not cover shows up here)
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -o cfg4 -- python3 $root/tools/step_profile.py 1024 cfg4 > /dev/null 2>&1
+find $out/stats4 -name "*kernel_stats.csv" -exec cp {} $out/cfg4_rotate_kernel_stats.csv \;
+rm -rf $out/stats4
+cd $root
 rm -rf $out/stats
 ls -la $out

@@ -1,21 +1,37 @@
-"""Batched in-place NTT throughput (canonical outputs) at one size: tools/ntt_only.py logn [polys] -> rows/s, HBM fraction.
-Primes: cfg2's (2^14), cfg4's (2^15) or cfg5's first 12 (2^16) -- all 50-bit, so the FP64 instances serve them
-(SEALHIP_NTT_NO_FP64=1 selects the integer ones for an A/B)."""
-import os, sys
+#!/usr/bin/env python3
+"""NTT-only driver for profiling: forward (and optionally inverse) NTT over a batch at N=2^logn."""
+import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "gemini-seal_amd")); sys.path.insert(0, ROOT)
-import torch, sealhip as S
-from tools.bench_configs import mk, timed, P14, P15_12, P16
-logn = int(sys.argv[1]); n = 1 << logn
-pr = {14: P14, 15: P15_12, 16: P16[:12]}[logn]
-P = int(sys.argv[2]) if len(sys.argv) > 2 else (1 << 24) // (n * len(pr)) * 4
-dev = torch.device("cuda", 0)
-ctx = S.Context(S.SCHEME_CKKS, logn, pr, 1, 0)
-ctx.use_default_stream()
-k = len(pr) - 1
-x = mk(ctx, (P, len(pr), n), pr, dev)
-fwd = timed(lambda: ctx.ntt_negacyclic_harvey(x, P, k, S.BASE_KEY), 10)
-inv = timed(lambda: ctx.inverse_ntt_negacyclic_harvey(x, P, k, S.BASE_KEY), 10)
-rows = P * len(pr)
-print({"logn": logn, "rows": rows, "fwd_rows_per_s": round(rows / fwd), "inv_rows_per_s": round(rows / inv),
-       "fwd_hbm_frac": round(rows * 16 * n / fwd / 8e12, 4), "inv_hbm_frac": round(rows * 16 * n / inv / 8e12, 4)})
+sys.path.insert(0, os.path.join(ROOT, "gemini-seal_amd"))
+import numpy as np
+import sealhip as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--logn", type=int, default=15)
+ap.add_argument("--polys", type=int, default=1024)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--inverse", action="store_true")
+a = ap.parse_args()
+PR = {15: [36028797010444289, 36028797012606977, 36028797013000193, 36028797013327873, 36028797014376449,
+           36028797014573057, 36028797014704129, 36028797017456641],
+      14: [1125899903107073, 1125899903500289, 1125899903795201, 1125899903827969, 1125899903991809, 1125899904679937],
+      16: [1125899864506369, 1125899865948161, 1125899870011393, 1125899870404609, 1125899877875713]}[a.logn]
+ctx = S.Context(S.SCHEME_CKKS, a.logn, PR, 1, 0)
+k, n = len(PR) - 1, 1 << a.logn
+rng = np.random.default_rng(0)
+x = np.stack([rng.integers(0, p, size=(a.polys, n), dtype=np.uint64) for p in PR[:k]], axis=1)
+d = ctx.upload(x)
+fn = ctx.inverse_ntt_negacyclic_harvey if a.inverse else ctx.ntt_negacyclic_harvey
+fn(d, a.polys, k); ctx.synchronize()
+ctx.profile_enable(True)
+t0 = time.perf_counter()
+for _ in range(a.reps):
+    fn(d, a.polys, k)
+ctx.synchronize()
+dt = time.perf_counter() - t0
+prof = ctx.profile_fetch()
+rows = a.polys * k * a.reps
+ms = sum(v["ms"] for v in prof.values())
+print("logn %d %s: %.3f M NTT/s wall, %.3f M NTT/s kernel, %.1f%% of HBM roofline (16N B/row)  %s" % (
+    a.logn, "inv" if a.inverse else "fwd", rows / dt / 1e6, rows / (ms / 1e3) / 1e6,
+    rows * 16 * n / (ms / 1e3) / 8e12 * 100, prof))
