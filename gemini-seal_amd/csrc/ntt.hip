@@ -1707,12 +1707,51 @@ namespace sealhip
             return static_cast<double>(nrows / map.rows) * live;
         }
 
+        // A launch whose live rows mix primes below 2^50 with larger ones (the usual CKKS chain: 60-bit ends, 40-bit middle)
+        // is issued as two: the rows that can take the floating-point instance, then the others. -> true when both kinds
+        // are live; `fp_rows` / `rest` are the map with the other kind masked out.
+        inline bool split_by_fp(const Engine &e, const RowMap &map, RowMap &fp_rows, RowMap &rest)
+        {
+            fp_rows = rest = map;
+            int n_fp = 0, n_rest = 0;
+            for (int r = 0; r < map.rows; r++)
+            {
+                if (map.prime[r] == kSkipRow)
+                    continue;
+                if (e.tables[map.prime[r]].p < kFpPrimeBound)
+                {
+                    rest.prime[r] = kSkipRow;
+                    n_fp++;
+                }
+                else
+                {
+                    fp_rows.prime[r] = kSkipRow;
+                    n_rest++;
+                }
+            }
+            return n_fp > 0 && n_rest > 0;
+        }
+        inline bool fp64_enabled()
+        {
+            static const bool off = std::getenv("SEALHIP_NTT_NO_FP64") != nullptr;
+            return !off;
+        }
+
         template <int LOGN>
         hipError_t launch_half_inv(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, int flags,
                                    const u64 *src = nullptr, std::size_t src_poly_stride = 0,
                                    const DyadicSrc *dyadic = nullptr)
         {
             constexpr int T = LOGN - 1;
+            if (fp64_enabled() && (flags & (kNttAnyRep | kNttCanonical)) != 0 && !dyadic)
+            {
+                RowMap a, b;
+                if (split_by_fp(e, map, a, b))
+                {
+                    const hipError_t err = launch_half_inv<LOGN>(e, data, nrows, a, flags, src, src_poly_stride);
+                    return err != hipSuccess ? err : launch_half_inv<LOGN>(e, data, nrows, b, flags, src, src_poly_stride);
+                }
+            }
             const std::size_t lds_bytes = static_cast<std::size_t>(hpad(1 << (T - 1))) * 8;
             if (nrows % map.rows != 0)
                 return hipErrorInvalidValue;
@@ -1735,8 +1774,7 @@ namespace sealhip
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
                 // floating-point instance: same contract (inputs below 2p, any representative out), every live prime below 2^50
-                static const bool no_fp = std::getenv("SEALHIP_NTT_NO_FP64") != nullptr;
-                bool fp = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !no_fp && !dyadic;
+                bool fp = (flags & (kNttAnyRep | kNttCanonical)) != 0 && fp64_enabled() && !dyadic;
                 for (int i = 0; fp && i < live.n; i++)
                     fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
                 const DyadicSrc dy = dyadic ? *dyadic : DyadicSrc{};
@@ -1810,6 +1848,15 @@ namespace sealhip
 #endif
             if (nrows % map.rows != 0)
                 return hipErrorInvalidValue;
+            if (fp64_enabled() && (flags & (kNttAnyRep | kNttCanonical)) != 0 && (flags & kNttReduceOut) == 0 && !src.base[0])
+            {
+                RowMap a, b; // (in-place launches only: a gathered launch's sources are not known per row here)
+                if (split_by_fp(e, map, a, b))
+                {
+                    const hipError_t err = launch_half<LOGN>(e, data, nrows, a, flags, src);
+                    return err != hipSuccess ? err : launch_half<LOGN>(e, data, nrows, b, flags, src);
+                }
+            }
             const LiveSlots live = live_slots(map);
             if (live.n == 0)
                 return hipSuccess;
@@ -1862,8 +1909,7 @@ namespace sealhip
             // words of another key prime, or the output of a load treatment), and a launch that does not ask for the
             // integer sequence's own representatives (canonical output, or a consumer that reduces whatever it reads).
             // The result is the canonical residue, so the integer instances' flags play no further role.
-            static const bool no_fp = std::getenv("SEALHIP_NTT_NO_FP64") != nullptr;
-            bool fp = !no_fp && (flags & (kNttAnyRep | kNttCanonical)) != 0 && (flags & kNttReduceOut) == 0;
+            bool fp = fp64_enabled() && (flags & (kNttAnyRep | kNttCanonical)) != 0 && (flags & kNttReduceOut) == 0;
             for (int i = 0; fp && i < live.n; i++)
                 fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
             if (fp && src.base[0])
@@ -2054,10 +2100,10 @@ namespace sealhip
         NttPlan plan{};
         plan.logn = logn;
         plan.serial = logn < 4;
+        plan.flags = flags;
         if (plan.serial)
         {
             plan.npass = 0;
-            plan.flags = flags;
             return plan;
         }
         auto init = [&](NttPass &ps, int t, int c, int b_lo, int lo, int hi) {

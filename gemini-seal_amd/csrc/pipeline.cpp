@@ -202,7 +202,7 @@ namespace sealhip
                     check(launch_ntt_gather(e, ext + j * ext_digit, m * rows, mj, ns, kNttAnyRep | kNttApprox), "ntt(ext, gathered)");
                 }
                 else
-                    check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, 0), "ntt(ext)");
+                    check(launch_ntt(e, ext + j * ext_digit, m * rows, mj, false, kNttAnyRep), "ntt(ext)"); // (as above)
             }
             // in-bundle rows: the reference multiplies the target rows as they are (:2319-2320);
             // STRICT transforms the coefficient-form BFV rows first
@@ -225,7 +225,7 @@ namespace sealhip
                 // order of independent row transforms does not matter), then one fused mod-down kernel
                 const bool defer = ntt_can_defer_top(e, k);
                 // (ks_moddown_bfv reduces what it reads canonically: any representative below 2p will do)
-                check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, defer ? (kNttDeferTop | kNttAnyRep) : 0), "intt(prod)");
+                check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, (defer ? kNttDeferTop : 0) | kNttAnyRep), "intt(prod)");
                 check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer, c0p, c0_stride),
                       "moddown_bfv");
                 continue;
@@ -274,9 +274,9 @@ namespace sealhip
                 check(launch_ks_moddown_pre(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, 2 * m),
                       "moddown_pre");
                 if (ckks)
-                    check(launch_ntt(e, temp, m * 2 * k, map_q, false, 0), "ntt(temp)");
+                    check(launch_ntt(e, temp, m * 2 * k, map_q, false, kNttAnyRep), "ntt(temp)"); // (moddown_post reduces the sum)
                 else
-                    check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, 0), "intt(prod)");
+                    check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, kNttAnyRep), "intt(prod)");
             }
             check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
                                          ct_stride, 2 * m, 1, c0p, c0_stride),
@@ -398,7 +398,9 @@ namespace sealhip
                 check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? kNttReduceOut : 0), "ntt(X, Bsk rows)");
             }
             else
-                check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, 0), "ntt(X)");
+                // (the tensor product reduces whatever it reads, polyarithsmallmod.cpp:63-117; the 60-bit Bsk rows keep the
+                //  reference's wrapped words either way: launch_half / the pass kernels only use the freedom on small primes)
+                check(launch_ntt(e, X, m * sin * kb, lt.map_qbsk, false, kNttAnyRep), "ntt(X)");
             if (fused_tensor)
             {
                 // steps (4) + (5) (:376-424): D[I] = inverse NTT of sum_{i1+i2=I} X[i1] (.) X[2+i2], top layer deferred, every
@@ -590,7 +592,7 @@ namespace sealhip
         u64 *temp = e.ws_alloc(nplains * k * N);
         check(launch_plain_lift(e, plain, plain_stride, temp, nplains, map_q, e.t), "plain_lift");
         check(launch_ntt(e, temp, nplains * k, map_q, false, kNttCanonical), "ntt(plain)");
-        check(launch_ntt(e, ct, count * size * k, map_q, false, 0), "ntt(ct)");
+        check(launch_ntt(e, ct, count * size * k, map_q, false, kNttAnyRep), "ntt(ct)"); // (the dyadic product reduces)
         check(launch_ct_linear(e, CtLinearOp::MulPlain, ct, size, temp, 0, plain_stride ? static_cast<std::size_t>(k) * N : 0,
                                ct, count, map_q),
               "dyadic(plain)");
@@ -620,7 +622,7 @@ namespace sealhip
             e.ws_reset();
             u64 *copy = e.ws_alloc(tail * m);
             check(launch_copy_rows(e, ct + off * item + poly, item, copy, tail, m, (size - 1) * k), "copy(c1..)");
-            check(launch_ntt(e, copy, m * (size - 1) * k, map_q, false, 0), "ntt(c1..)");
+            check(launch_ntt(e, copy, m * (size - 1) * k, map_q, false, kNttAnyRep), "ntt(c1..)"); // (the dot product reduces)
             // the kernel indexes polynomials 1.. of an item: hand it a base one polynomial before the copies
             check(launch_dot_sk(e, copy - poly, size, tail, sk_powers, sk_stride, out + off * poly, m, map_q, 0), "dot_sk");
             check(launch_ntt(e, out + off * poly, m * k, map_q, true, kNttCanonical), "intt(dot)");
