@@ -512,6 +512,8 @@ namespace sealhip
                 rd.floor_G1m_top[2][j] = mont(rd.floor_G1m_top[0][j], b);
                 rd.floor_G1m_top[3][j] = mont(rd.floor_G1m_top[1][j], b);
                 rd.b_p[j] = b;
+                rd.b_w1[j] = tb.fwd.size() >= 4 ? tb.fwd[2] : 0; // pair 1 of the forward table: the top layer's twiddle
+                rd.b_w1s[j] = tb.fwd.size() >= 4 ? tb.fwd[3] : 0;
                 rd.b_rdp[j] = tb.rdp ? tb.rdp : shoup(1, b);
                 {
                     u64 inv = b;

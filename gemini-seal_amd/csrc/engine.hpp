@@ -59,6 +59,10 @@ namespace sealhip
     constexpr int kNttReduceOut = 0x10; // forward, single-pass kernel: one more conditional subtraction, outputs in [0, 2p)
     constexpr int kNttApprox = 0x20;   // forward, with kNttAnyRep or a consumer that takes outputs below 5p: approximate quotient
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
+    // forward, single-pass kernel, with kNttReduceOut, in place: the producer of the rows has already applied the top layer
+    // (gap N/2) -- bfv_lift2 does for the Bsk rows it writes. Each workgroup then loads its own half only: no second read of
+    // the row, no duplicated products (both workgroups of a row compute the top layer's products otherwise), no hand-off.
+    constexpr int kNttTopDone = 0x80;
     constexpr int kNttDeferTop = 4;  // inverse, single-pass kernels only: leave the top layer (gap N/2) to the consumer
     // Primes below this bound have double-precision twiddle tables: the single-pass kernels then run their butterflies
     // on the FP64 pipe (exact, devmath.hpp) whenever the launch promises nothing about representatives that only the
@@ -122,6 +126,7 @@ namespace sealhip
         // two dependent scalar loads
         u64 q_p[kMaxModuli], q_ninv[kMaxModuli], q_rdp[kMaxModuli];
         u64 b_p[kMaxModuli + 2], b_ninv[kMaxModuli + 2], b_rdp[kMaxModuli + 2];
+        u64 b_w1[kMaxModuli + 2], b_w1s[kMaxModuli + 2]; // top-layer forward twiddle of the Bsk rows and its Shoup quotient
         // Montgomery/Shoup companions of the folded constants (suffix m: times 2^64 mod the row's prime; s: Shoup)
         const u64 *lift_L1m, *floor_G2m, *B_to_qm; // [nB][k], [nB][k], [k][B]
         u64 lift_L2m[kMaxModuli + 2], floor_G1m[kMaxModuli + 2];
@@ -361,8 +366,11 @@ namespace sealhip
     hipError_t launch_sm_mrq(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
                              u64 *out, std::size_t out_stride, std::size_t count);
     // fused fastbconv_m_tilde + sm_mrq: in k rows -> out |Bsk| rows
+    // top_layer: also apply the forward NTT's top layer to the rows written (exact-k instances only; the caller then
+    // transforms them with kNttTopDone). -> bfv_lift_can_apply_top tells whether this level has such an instance.
+    bool bfv_lift_can_apply_top(const Engine &e, const RnsDev &h);
     hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
-                               u64 *out, std::size_t out_stride, std::size_t count);
+                               u64 *out, std::size_t out_stride, std::size_t count, bool top_layer = false);
     hipError_t launch_fast_floor(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                  std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                  int mul_t);

@@ -1010,6 +1010,18 @@ namespace sealhip
                 for (int i = 0; i < 32; i++)
                     x[i] = static_cast<u64>(tid) * 0x9E3779B97F4A7C15ull + i;
             }
+            else if constexpr (REDUCE == 6)
+            {
+                // kNttTopDone: the producer applied the top layer; this workgroup's half, arrangement 1, nothing else
+                const int jb1 = Arr<T, 1>::tid_index(fresh(tid));
+#pragma unroll
+                for (int s = 0; s < 32; s += 2)
+                {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(rowp + (half << T) + jb1 + Arr<T, 1>::slot_index(s));
+                    x[s] = v.x;
+                    x[s + 1] = v.y;
+                }
+            }
             else if (half)
                 h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             else
@@ -1089,7 +1101,7 @@ namespace sealhip
             const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
             // bit 0: canonicalising wrapper; bit 1: leave the last layer's first operand unreduced (kNttAnyRep)
             const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0);
-            constexpr bool ROUT = REDUCE == 3; // kNttReduceOut launches (never gathered: no load treatment to combine with)
+            constexpr bool ROUT = REDUCE == 3 || REDUCE == 6; // kNttReduceOut launches (never gathered: no load treatment to combine with)
             if constexpr (FinalStage<T>::PIPE)
                 FinalPipe<T, STRICT, ROUT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             else
@@ -1866,10 +1878,14 @@ namespace sealhip
                 return hipErrorInvalidValue;
             // SEALHIP_NTT_NO_TICKET=1 is a measurement-only switch (A/B of the hand-off cost); it re-opens the race
             static const bool no_ticket = std::getenv("SEALHIP_NTT_NO_TICKET") != nullptr;
-            unsigned *tickets = no_ticket ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
+            // (kNttTopDone: no workgroup reads the other's half, nothing to hand off)
+            const bool top_done = (flags & kNttTopDone) != 0;
+            if (top_done && ((flags & (kNttReduceOut | kNttStrict | kNttCanonical)) != kNttReduceOut || src.base[0]))
+                return hipErrorInvalidValue;
+            unsigned *tickets = (no_ticket || top_done) ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
             if (e.ntt_suppress_signal)
                 flags |= kNttDebugNoSignal; // sealhip_debug_ntt_handoff: drive the time-out path
-            if (!tickets && !no_ticket)
+            if (!tickets && !no_ticket && !top_done)
                 return hipErrorOutOfMemory;
 #ifdef SEALHIP_NTT_EXPERIMENT
             if (const char *sk = std::getenv("SEALHIP_NTT_SKIP"))
@@ -1940,7 +1956,7 @@ namespace sealhip
             {
                 if (red != 0 || (flags & kNttCanonical))
                     return hipErrorInvalidValue; // an in-place, non-canonical launch option
-                red = 3;
+                red = top_done ? 6 : 3;
             }
             // butterfly mode 2 (approximate Shoup quotient, one multiplier instruction less per butterfly): the product then
             // lies in [0, 3p), every layer adds 3p instead of 2p and the outputs are below 50p (kNttAnyRep) or 5p. Only where
@@ -2002,7 +2018,9 @@ namespace sealhip
             }
             else
             {
-                if (red == 5)
+                if (red == 6)
+                    SEALHIP_FWD_HALF(0, 6);
+                else if (red == 5)
                     SEALHIP_FWD_HALF(0, 5);
                 else if (red == 4)
                     SEALHIP_FWD_HALF(0, 4);
@@ -2024,7 +2042,8 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[20] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 5>),
+            const void *fwd[21] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 6>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 0>),

@@ -346,6 +346,15 @@ namespace sealhip
             // the q rows are gathered straight from the operands by the NTT kernel (no set_poly copy) when the
             // single-pass kernel is available
             const bool gather = ntt_can_gather(e) && sin * kb <= kMaxRows;
+            // With the single-pass kernels and two size-2 operands the tensor product (step 4) is formed by the inverse
+            // NTT while it loads its rows (no separate pass over 7 rows per prime; launch_intt_tensor)
+            const bool defer = ntt_can_defer_top(e, k);
+            bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
+                                std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
+            for (int r = 0; r < k; r++) // its Montgomery reduction lands below 2p for ciphertext primes under 2^59
+                fused_tensor = fused_tensor && e.key_moduli[r] < (u64(1) << 59);
+            // the lift applies the forward transform's top layer to the Bsk rows it writes (kNttTopDone below)
+            const bool lift_top = fused_tensor && bfv_lift_can_apply_top(e, h);
             for (int s = 0; s < sin; s++)
             {
                 const bool first = s < sa;
@@ -354,15 +363,8 @@ namespace sealhip
                 u64 *dst = X + s * poly_x;
                 if (!gather)
                     check(launch_copy_rows(e, src, src_stride, dst, w_x, m, k), "copy");
-                check(launch_bfv_lift(e, lt.d_rns, h, src, src_stride, dst + poly_q, w_x, m), "bfv_lift");
+                check(launch_bfv_lift(e, lt.d_rns, h, src, src_stride, dst + poly_q, w_x, m, lift_top), "bfv_lift");
             }
-            // With the single-pass kernels and two size-2 operands the tensor product (step 4) is formed by the inverse
-            // NTT while it loads its rows (no separate pass over 7 rows per prime; launch_intt_tensor)
-            const bool defer = ntt_can_defer_top(e, k);
-            bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
-                                std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
-            for (int r = 0; r < k; r++) // its Montgomery reduction lands below 2p for ciphertext primes under 2^59
-                fused_tensor = fused_tensor && e.key_moduli[r] < (u64(1) << 59);
             if (gather)
             {
                 // one "polynomial" of the launch = all sin*(k+|Bsk|) rows of an item
@@ -395,7 +397,8 @@ namespace sealhip
                       "ntt(X, gathered q rows)");
                 // (fused tensor product: the wrapped Bsk words are brought below 2p as they are stored -- the residue class
                 //  is all the dyadic product depends on)
-                check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? kNttReduceOut : 0), "ntt(X, Bsk rows)");
+                check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? (kNttReduceOut | (lift_top ? kNttTopDone : 0)) : 0),
+                      "ntt(X, Bsk rows)");
             }
             else
                 // (the tensor product reduces whatever it reads, polyarithsmallmod.cpp:63-117; the 60-bit Bsk rows keep the

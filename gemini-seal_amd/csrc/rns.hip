@@ -165,67 +165,96 @@ namespace sealhip
         // with ONE 128-bit accumulation and ONE Barrett reduction per output instead of three.
         // KMAX < 0 means "exactly K = -KMAX primes, known at compile time" (no per-iteration guards, constants
         // fetched with wide scalar loads); KMAX > 0 is the guarded form for any k <= KMAX
-        template <int KMAX>
+        // TOP (exact-K instances): one lane per column PAIR (c, c + N/2); after a row's two outputs are formed the lane
+        // applies the forward NTT's top layer to them (ForwardLazy, ntt.cpp:245-252, the very function the NTT kernel's load
+        // phase would run on these two words) and stores the results. The transform that follows is launched with
+        // kNttTopDone: its workgroups then read their own half only, and the layer's products are computed once per pair
+        // instead of once per workgroup.
+        template <int KMAX, bool TOP = false>
         __global__ __launch_bounds__(kThreads) void bfv_lift2_kernel(const RnsDev *__restrict__ d_,
                                                                      const PrimeDev *__restrict__ primes_,
                                                                      const u64 *__restrict__ in, std::size_t in_stride,
                                                                      u64 *__restrict__ out, std::size_t out_stride,
                                                                      std::size_t count, int logn)
         {
+            static_assert(!TOP || KMAX < 0, "the paired-column form exists for the exact-K instances");
             Cols cc;
-            if (!column(count, logn, cc))
+            if (!column(count, TOP ? logn - 1 : logn, cc))
                 return;
             constexpr int KA = KMAX < 0 ? -KMAX : KMAX; // array extent
+            constexpr int NC = TOP ? 2 : 1;             // columns per lane
             const auto *d = kc(d_);           // read-only for the lifetime of the context: constant address space
             const auto *primes = kc(primes_); // (scalar loads the compiler may merge and hoist)
             const int k = KMAX < 0 ? KA : d->k, nB = d->nB;
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const u64 *pin = in + cc.item * in_stride + cc.c;
             u64 *pout = out + cc.item * out_stride + cc.c;
-            u64 t[KA];
-            u64 acc = 0;
+            u64 t[NC][KA];
+            u64 acc[NC] = {};
             (void)primes;
 #pragma unroll
             for (int i = 0; i < KA; i++)
                 if (KMAX < 0 || i < k)
                 {
                     const u64 qp = d->q_p[i];
-                    t[i] = mulmod_shoup_hs(pin[i * N], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
-                    acc += t[i] * d->q_to_mt[i];
+#pragma unroll
+                    for (int h = 0; h < NC; h++)
+                    {
+                        t[h][i] = mulmod_shoup_hs(pin[i * N + h * (N >> 1)], d->q_mt_inv[i], d->q_mt_inv_s[i], qp); // exact canonical product
+                        acc[h] += t[h][i] * d->q_to_mt[i];
+                    }
                 }
-            const u64 r_mt = r_m_tilde(acc & 0xFFFFFFFFull, d);
+            u64 r_mt[NC];
+#pragma unroll
+            for (int h = 0; h < NC; h++)
+                r_mt[h] = r_m_tilde(acc[h] & 0xFFFFFFFFull, d);
             // exact-K instances are only launched when the host proved every REDC lands below 2p (RnsDev::redc_small):
             // a compile-time fact there, so the row loops carry no branch
             const bool small = KMAX < 0 ? true : d->redc_small != 0;
-            SplitT ts[KA];
+            SplitT ts[NC][KA];
             if constexpr (KMAX < 0)
-                static_for<KA>([&](auto I) { ts[I.value] = SplitT(t[I.value]); });
+                static_for<KA>([&](auto I) {
+#pragma unroll
+                    for (int h = 0; h < NC; h++)
+                        ts[h][I.value] = SplitT(t[h][I.value]);
+                });
             const auto *L1m = kc(d->lift_L1m);
             const auto *L2m = kc(d->lift_L2m);
             const auto row_out = [&](int j) {
                 const u64 bp = d->b_p[j];
-                u64 temp = r_mt;
-                if (temp >= (1ull << 31))
-                    temp += bp - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
                 const auto *row = L1m + j * k; // constants carry the factor 2^64: REDC removes it
-                u64 lo, hi;
-                if constexpr (KMAX < 0)
-                {
-                    DotAcc<KA + 1> acc2; // carry-free accumulation (devmath.hpp), same integer sum
-                    acc2.template add<0>(SplitT(temp), L2m[j]);
-                    static_for<KA>([&](auto I) { acc2.template add<I.value + 1>(ts[I.value], row[I.value]); });
-                    acc2.finish(lo, hi);
-                }
-                else
-                {
-                    lo = temp * L2m[j];
-                    hi = mulhi(temp, L2m[j]);
+                u64 v[NC];
 #pragma unroll
-                    for (int i = 0; i < KA; i++)
-                        if (i < k)
-                            mac128(lo, hi, t[i], row[i]);
+                for (int h = 0; h < NC; h++)
+                {
+                    u64 temp = r_mt[h];
+                    if (temp >= (1ull << 31))
+                        temp += bp - (1ull << 32); // centred reduction of r_m_tilde, rns.cpp:969-973
+                    u64 lo, hi;
+                    if constexpr (KMAX < 0)
+                    {
+                        DotAcc<KA + 1> acc2; // carry-free accumulation (devmath.hpp), same integer sum
+                        acc2.template add<0>(SplitT(temp), L2m[j]);
+                        static_for<KA>([&](auto I) { acc2.template add<I.value + 1>(ts[h][I.value], row[I.value]); });
+                        acc2.finish(lo, hi);
+                    }
+                    else
+                    {
+                        lo = temp * L2m[j];
+                        hi = mulhi(temp, L2m[j]);
+#pragma unroll
+                        for (int i = 0; i < KA; i++)
+                            if (i < k)
+                                mac128(lo, hi, t[h][i], row[i]);
+                    }
+                    v[h] = redc_finish(redc128(lo, hi, bp, d->b_ninv[j]), bp, d->b_rdp[j], small);
                 }
-                pout[j * N] = redc_finish(redc128(lo, hi, bp, d->b_ninv[j]), bp, d->b_rdp[j], small);
+                if constexpr (TOP)
+                {
+                    butterfly_fwd_hs<true>(v[0], v[1], d->b_w1[j], d->b_w1s[j], 0 - bp, bp << 1);
+                    pout[j * N + (N >> 1)] = v[1];
+                }
+                pout[j * N] = v[0];
             };
             if constexpr (KMAX < 0)
             {
@@ -800,16 +829,43 @@ namespace sealhip
         return hipGetLastError();
     }
 
+    namespace
+    {
+        template <int KM>
+        void lift2_launch(const Engine &e, const RnsDev *d, const u64 *in, std::size_t in_stride, u64 *out, std::size_t out_stride,
+                          std::size_t count, unsigned grid, bool top_layer)
+        {
+            if constexpr (KM < 0)
+            {
+                if (top_layer)
+                {
+                    bfv_lift2_kernel<KM, true><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out, out_stride,
+                                                                                       count, e.logn);
+                    return;
+                }
+            }
+            bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
+        }
+    } // namespace
+
+    bool bfv_lift_can_apply_top(const Engine &e, const RnsDev &h)
+    {
+        static const bool off = std::getenv("SEALHIP_LIFT_TOP_OFF") != nullptr;
+        return !off && !e.unfused_rns && !e.mode_strict && h.redc_small && h.k >= 1 && h.k <= 16 && e.logn >= 14;
+    }
+
     hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
-                               u64 *out, std::size_t out_stride, std::size_t count)
+                               u64 *out, std::size_t out_stride, std::size_t count, bool top_layer)
     {
         if (!count)
             return hipSuccess;
-        const unsigned grid = blocks_for(count, e.logn);
+        if (top_layer && !bfv_lift_can_apply_top(e, h))
+            return hipErrorInvalidValue;
+        const unsigned grid = blocks_for(count, top_layer ? e.logn - 1 : e.logn);
         ProfScope prof(e, "bfv_lift", 0);
         if (h.k <= 32 && !e.unfused_rns)
         {
-#define SEALHIP_LIFT2(KM) bfv_lift2_kernel<KM><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out, out_stride, count, e.logn)
+#define SEALHIP_LIFT2(KM) lift2_launch<KM>(e, d, in, in_stride, out, out_stride, count, grid, top_layer)
             switch (h.redc_small ? h.k : 0)
             {
             case 1: SEALHIP_LIFT2(-1); break;

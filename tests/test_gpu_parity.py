@@ -2047,3 +2047,21 @@ def test_exact_ntt_variants_still_match_the_golden_digests():
                        env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode("utf-8", "replace")[-400:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+def test_round2_fast_paths_off_still_match_the_golden_digests():
+    """Round 2's fast paths each have a switch that restores the form they replaced: the FP64 NTT instances
+    (SEALHIP_NTT_NO_FP64), the top layer applied by bfv_lift2 (SEALHIP_LIFT_TOP_OFF), the CKKS mod-down folded into the
+    gathered transform (SEALHIP_KS_MODDOWN_UNFUSED) and the tensor product formed by the inverse transform
+    (SEALHIP_TENSOR_UNFUSED). With all of them off (child process: the switches are read once) the golden digests of the
+    compiled reference must come out as they do in this process with all of them on."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, SEALHIP_NTT_NO_FP64="1", SEALHIP_LIFT_TOP_OFF="1", SEALHIP_KS_MODDOWN_UNFUSED="1",
+               SEALHIP_TENSOR_UNFUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "end_to_end_golden_digests or ntt_golden_digests or bench_launch_shapes or cfg4_rotate_large_batch"],
+                       env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode("utf-8", "replace")[-400:]
+    assert r.returncode == 0 and " passed" in tail, tail
