@@ -127,7 +127,13 @@ long sealhip_debug_rns_constants(sealhip_context *ctx, uint32_t k, uint32_t whic
 
 /* ---------------------------------------------------------------- L2: NTT (util/ntt.h:189-368)
    data: count polynomials x rows x N, in place. `base` selects the primes of the `rows` rows of one
-   polynomial: BASE_Q -> rows = k; BASE_BSK -> rows = |Bsk|(k); BASE_KEY -> rows = k + nsp. */
+   polynomial: BASE_Q -> rows = k; BASE_BSK -> rows = |Bsk|(k); BASE_KEY -> rows = k + nsp.
+   Operand ranges are what the reference's butterflies are written for (ntt.cpp:245-281, :341): forward inputs below 4p, inverse inputs below 2p.
+   The `_lazy` entries reproduce the reference's representatives word for word (including the wrapped words of the
+   60-bit Bsk rows). The canonicalising entries return the residues those words reduce to; on rows whose prime
+   is below 2^50 they are computed with exact double-precision butterflies, which for operands
+   inside the ranges above is the same function -- for words outside them (>= 2^52) both the reference's output and this
+   one are meaningless, and they differ. */
 long sealhip_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
                                         uint32_t base);
 long sealhip_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base);

@@ -1949,6 +1949,65 @@ def test_cfg4_variant_with_16_decomposition_digits(sealhip):
         assert np.array_equal(res[i], lo), i
 
 
+def test_ckks_mixed_prime_chain_single_pass_kernels(sealhip):
+    """The usual CKKS chain -- 60-bit first and special primes, 40-bit primes in between -- at N = 2^14, where the
+    single-pass kernels run: launches whose live rows mix primes below 2^50 with larger ones are split into a
+    floating-point and an integer launch, the mod-down transform gathers a 60-bit special row (integer instance of
+    reduce mode 5: top inverse layer + negation on load), and apply_galois writes (galois(c0) + r0, r1) without the copy /
+    fill. rotate_vector, conjugate, multiply + relinearize + rescale and the canonical transforms against the oracle."""
+    logn, n, nsp = 14, 1 << 14, 1
+    kmods = O.coeff_modulus_create(n, [60, 40, 40, 40, 60])
+    k, count = 4, 3
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, nsp, 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(2, logn, kmods, nsp=nsp, t=0)
+    rng = np.random.default_rng(6040)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    for elt in (ctx.galois_elt_from_step(1), 2 * n - 1):  # a rotation and the conjugation
+        g = ctx.upload(a)
+        ev.apply_galois_inplace(g, k, count, elt, dkey)
+        rot = g.download(a.shape)
+        for i in range(count):
+            exp = a[i].copy()
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(exp), elt, O.ptr(key)) == 0
+            assert np.array_equal(rot[i], exp), (elt, i)
+    o = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, o)
+    ev.relinearize_inplace(o, 3, k, count, [dkey])
+    rel = o.download((count, 3, k, n))[:, :2].copy()
+    low = ctx.alloc(count * 2 * (k - 1) * n)
+    ev.rescale_to_next(ctx.upload(rel), 2, k, count, low)
+    res = low.download((count, 2, k - 1, n))
+    for i in range(count):
+        wide = np.zeros((3, k, n), dtype=np.uint64)
+        assert L.ref_ckks_multiply(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(wide)) == 0
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(wide), 3, keys) == 0
+        assert np.array_equal(rel[i], wide[:2]), i
+        lo = np.zeros((2, k - 1, n), dtype=np.uint64)
+        assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(np.ascontiguousarray(wide[:2])), 2, O.ptr(lo)) == 0
+        assert np.array_equal(res[i], lo), i
+    # canonical transforms over the mixed rows (split launches), both directions
+    tabs = [O.Tables(logn, p) for p in kmods[:k]]
+    x = a[:, 0].copy()
+    buf = ctx.upload(x)
+    ctx.inverse_ntt_negacyclic_harvey(buf, count, k)
+    inv = buf.download(x.shape)
+    ctx.ntt_negacyclic_harvey(buf, count, k)
+    fwd = buf.download(x.shape)
+    for c in range(count):
+        for i in range(k):
+            e = x[c, i].copy()
+            L.ref_ntt_inverse(O.ptr(e), C.byref(tabs[i].t))
+            assert np.array_equal(inv[c, i], e), (c, i)
+            # (no round-trip identity on the 60-bit row: the reference's forward butterflies wrap there, SURVEY F2)
+            L.ref_ntt_forward(O.ptr(e), C.byref(tabs[i].t), 0)
+            assert np.array_equal(fwd[c, i], e), (c, i)
+
+
 def test_bench_shapes_with_a_small_arena():
     """SEALHIP_WORKSPACE_MB is read once per process: a child process with a 64 MB arena runs the two tests above with
     a smaller batch, so that every operation walks its batch in chunks of two or three ciphertexts (config 3 needs 27 MB
