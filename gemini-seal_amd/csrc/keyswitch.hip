@@ -8,6 +8,7 @@
 // The reference also keeps two (k+nsp) x N arrays of 128-bit accumulators in memory across the digit
 // loop; here one lane owns one (row, coefficient) and keeps both accumulators in registers across
 // all digits, streaming the key slices.
+#include <cstdlib>
 #include "engine.hpp"
 
 namespace sealhip
@@ -147,10 +148,11 @@ namespace sealhip
         }
 
         // The same inner product with the key words of a lane's (row, coefficient) kept in registers across
-        // kItems consecutive ciphertexts: the key slice (2 * nd words per lane, 29 MB per pass at cfg3) is read once
-        // per kItems ciphertexts instead of once per ciphertext (it made up two thirds of this kernel's read traffic).
-        // The digit words of the next ciphertext are requested before the current one is accumulated.
-        constexpr int kMacItems = 8;
+        // `group` consecutive ciphertexts: the key slice (2 * nd words per lane, 29 MB per pass at cfg3) is read once
+        // per group instead of once per ciphertext (it made up two thirds of this kernel's read traffic at group 1, and
+        // still 17 % at group 8: config 4 reads 132 digit rows, writes 24 and re-reads 264 / group key rows per
+        // ciphertext). The digit words of the next ciphertext are requested before the current one is accumulated, so the
+        // group size costs no registers; the launcher picks it from the batch (mac_group).
         template <int ND>
         __global__ __launch_bounds__(kThreads) void ks_mac_items_kernel(const KsDev *__restrict__ d,
                                                                         const PrimeDev *__restrict__ primes,
@@ -161,7 +163,7 @@ namespace sealhip
                                                                         std::size_t ext_digit_stride,
                                                                         const u64 *__restrict__ key,
                                                                         u64 *__restrict__ prod, std::size_t prod_stride,
-                                                                        std::size_t count, int logn)
+                                                                        std::size_t count, int logn, std::size_t group)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const int k = d->k, nsp = d->nsp, rows = k + nsp, n_total = d->n_total;
@@ -169,10 +171,10 @@ namespace sealhip
             const std::size_t c = i & (N - 1);
             const std::size_t rr = i >> logn;
             const int r = static_cast<int>(rr % rows);
-            const std::size_t item0 = (rr / rows) * kMacItems;
+            const std::size_t item0 = (rr / rows) * group;
             if (item0 >= count)
                 return;
-            const std::size_t item1 = item0 + kMacItems < count ? item0 + kMacItems : count;
+            const std::size_t item1 = item0 + group < count ? item0 + group : count;
             const int rns_idx = d->row_prime[r];
             const int my_digit = r < k ? r / nsp : -1;
             const std::size_t row_off = static_cast<std::size_t>(r) * N + c;
@@ -421,15 +423,35 @@ namespace sealhip
         const u64 *tg = target;
         const std::size_t lanes = (count * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
         ProfScope prof(e, "ks_mac", 0);
-        const std::size_t groups = (count + kMacItems - 1) / kMacItems;
+        // ciphertexts per key load: 8 for small batches (enough workgroups to fill the chip), else 16 -- or 64 when the key
+        // slices this kernel reads (2 * nd * rows rows) are too large to stay in the memory-side cache between groups
+        // (profiles/r02/ks_mac_group.txt: config 4, 69 MB of key: 9.15 -> 7.96 ms per step; config 5, 251 MB: 9.38 -> 7.66;
+        // config 3, 29 MB: 3.68 -> 3.60 at 16, but 3.9-4.1 at 32)
+        static const std::size_t forced = [] {
+            const char *env = std::getenv("SEALHIP_KS_MAC_GROUP");
+            return env ? static_cast<std::size_t>(std::strtoull(env, nullptr, 10)) : std::size_t(0);
+        }();
+        const std::size_t key_bytes = (2ull * h.nd * (h.k + h.nsp)) << (e.logn + 3);
+        // (the largest candidate that still leaves 4096 workgroups -- two full rounds of the chip's resident set)
+        const std::size_t cap = key_bytes > (std::size_t(48) << 20) ? 64 : 16;
+        std::size_t mac_group = 8;
+        for (std::size_t g = cap; g > 8; g >>= 1)
+            if ((((count + g - 1) / g * static_cast<std::size_t>(h.k + h.nsp)) << e.logn) / kThreads >= 4096)
+            {
+                mac_group = g;
+                break;
+            }
+        if (forced)
+            mac_group = forced;
+        const std::size_t groups = (count + mac_group - 1) / mac_group;
         const std::size_t glanes = (groups * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
 #define SEALHIP_KS_MAC(ND)                                                                                          \
     case ND:                                                                                                        \
         ks_mac_items_kernel<ND><<<blocks_for(glanes), kThreads, 0, e.lane().stream>>>(                                     \
             d, e.d_primes, tg, target_stride, ext, ext_stride, ext_digit_stride, key, prod, prod_stride, count,    \
-            e.logn);                                                                                                \
+            e.logn, mac_group);                                                                                     \
         break;
-        switch (count >= 2 * kMacItems ? h.nd : 0)
+        switch (count >= 16 ? h.nd : 0)
         {
             SEALHIP_KS_MAC(1)
             SEALHIP_KS_MAC(2)
