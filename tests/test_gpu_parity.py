@@ -1852,11 +1852,12 @@ def _bench_shape_batch(row, count, n_random, seed):
     return inp, a, b, where
 
 
-@pytest.mark.parametrize("count", [33])
+@pytest.mark.parametrize("count", [33, 65])
 def test_cfg3_bench_launch_shapes_vs_golden_and_oracle(sealhip, count):
     """BASELINE config 3 (what bench.py times) at a batch that takes the same kernels as the bench: count >= 16 selects
-    ks_mac_items_kernel<7> at N = 2^15 (key words kept in registers across eight ciphertexts; 33 leaves a ragged last
-    group), the single-pass NTT kernels see multi-polynomial launches, and -- when SEALHIP_WORKSPACE_MB shrinks the arena
+    ks_mac_items_kernel<7> at N = 2^15 (key words kept in registers across a group of ciphertexts: groups of eight at
+    33, with a ragged last group; groups of sixteen -- the bench's -- at 65, again ragged), the single-pass NTT kernels
+    see multi-polynomial launches, and -- when SEALHIP_WORKSPACE_MB shrinks the arena
     (test_bench_shapes_with_a_small_arena re-runs this test so) -- the batch spans many arena chunks. Golden items must
     reproduce the compiled reference's digests, random items the oracle's words."""
     row = [r for r in DIG["end_to_end"] if r["cfg"] == 3][0]
