@@ -47,9 +47,23 @@ namespace sealhip
         // 5: the same, on a source row whose inverse transform left its top layer to the consumer (kNttDeferTop): the
         // transform reads the pairs (c, c + N/2) anyway and applies BackwardLazyLast (ntt.cpp:274-281) to them first;
         // aux_top = the special prime's {n^-1, its Shoup quotient, w n^-1, its Shoup quotient}.
+        // 7: mode 5 plus the rest of the CKKS mod-down as the transform's store phase (multi_special_primes.cpp:291-302 and the
+        // final add, evaluator.cpp:2363-2366): the transformed word t of row (polynomial pl, prime q) is not stored; instead
+        // v = (prod[pl][q] + t) * P^-1 mod q goes into the ciphertext -- added to what is there, or, with c0_src set,
+        // written as (c0_src + v, v) for components (0, 1). Floating-point instance at log n >= 15 only (ntt_can_fuse_moddown).
         int reduce_mode;
         u64 aux_p, aux_cr1;
         u64 aux_top[4];
+        struct ModDownStore
+        {
+            const u64 *inv_p, *inv_p_shoup; // [k] P^-1 mod q_i and its Shoup quotient (KsDev::invP on the device)
+            const u64 *prod;                // [2m polynomials][prod_stride]: rows q of the key-switch products
+            std::size_t prod_stride;
+            u64 *ct;                        // [m][ct_stride]: component c at c * k rows
+            std::size_t ct_stride;
+            const u64 *c0_src;              // optional, [m][c0_stride]
+            std::size_t c0_stride;
+        } md;
     };
     constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
 
@@ -384,6 +398,8 @@ namespace sealhip
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int deferred_top = 0);
     bool ntt_can_defer_top(const Engine &e, int k);
+    // reduce mode 7 available for a gathered launch over the first k ciphertext primes with this special prime?
+    bool ntt_can_fuse_moddown(const Engine &e, int k, u64 p_special);
     // inverse NTT whose input rows come from another buffer (single-pass kernels only: ntt_can_gather(e))
     hipError_t launch_intt_from(const Engine &e, u64 *data, const u64 *src, std::size_t src_poly_stride, std::size_t nrows,
                                 const RowMap &map, int flags);

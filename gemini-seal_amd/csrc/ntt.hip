@@ -766,7 +766,7 @@ namespace sealhip
                     lo[i] = *reinterpret_cast<const ulonglong2 *>(rowp + idx);
                     hi[i] = *reinterpret_cast<const ulonglong2 *>(rowp + (1 << T) + idx);
                 }
-                if constexpr (REDUCE == 5)
+                if constexpr (REDUCE == 5 || REDUCE == 7)
                 {
                     // mode 4 on a source row whose top inverse layer was left to us: the pair (lo, hi) = (c, c + N/2) first
                     // goes through BackwardLazyLast w.r.t. the special prime P (inputs below 2P), then -(. mod P)
@@ -858,7 +858,7 @@ namespace sealhip
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                         {
-                            if constexpr (REDUCE != 4 && REDUCE != 5)
+                            if constexpr (REDUCE != 4 && REDUCE != 5 && REDUCE != 7)
                             {
                                 u[j] = fp_bits(fp_from_u64(u[j]));
                                 y[j] = fp_bits(fp_from_u64(y[j]));
@@ -956,6 +956,44 @@ namespace sealhip
 #pragma unroll
             for (int s = 0; s < 32; s += 2)
                 store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
+        }
+
+        // reduce mode 7: the words of arrangement 1 are canonical residues t of temp_q (NTT form); what is stored is the rest of
+        // the CKKS mod-down (NttSource::ModDownStore): v = (prod + t) * P^-1 mod q, into the ciphertext
+        template <int T>
+        __device__ __forceinline__ void h_store_moddown(const u64 (&x)[32], int tid, const u64 *__restrict__ prod_half,
+                                                        u64 *__restrict__ ct_half, const u64 *__restrict__ c0_half, bool add_ct,
+                                                        u64 inv_p, u64 inv_p_shoup, u64 p)
+        {
+            const int jb = Arr<T, 1>::tid_index(tid);
+#pragma unroll
+            for (int b = 0; b < 32; b += 8)
+            {
+                ulonglong2 pr[4], cc[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int off = jb + Arr<T, 1>::slot_index(b + 2 * i);
+                    pr[i] = *reinterpret_cast<const ulonglong2 *>(prod_half + off);
+                    if (c0_half)
+                        cc[i] = *reinterpret_cast<const ulonglong2 *>(c0_half + off);
+                    else if (add_ct)
+                        cc[i] = *reinterpret_cast<const ulonglong2 *>(ct_half + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int off = jb + Arr<T, 1>::slot_index(b + 2 * i);
+                    u64 v0 = mulmod_shoup(pr[i].x + x[b + 2 * i], inv_p, inv_p_shoup, p);
+                    u64 v1 = mulmod_shoup(pr[i].y + x[b + 2 * i + 1], inv_p, inv_p_shoup, p);
+                    if (c0_half || add_ct)
+                    {
+                        v0 = add_mod(v0, cc[i].x, p);
+                        v1 = add_mod(v1, cc[i].y, p);
+                    }
+                    store_nt(ct_half + off, v0, v1);
+                }
+            }
         }
 
         template <int LOGN, int STRICT, int REDUCE>
@@ -1111,7 +1149,20 @@ namespace sealhip
                 if (!NTT_EXP(flags, 0x200))
                     h_exchange<T, 4, 1>(x, lds, fresh(tid));
                 wait_for_sibling();
-                h_store_rows<T>(x, rowp + gbase, fresh(tid));
+                if constexpr (REDUCE == 7)
+                {
+                    // row = (polynomial pl of the launch, prime slot q): products at prod[pl][q], ciphertext component pl & 1
+                    const std::size_t pl = row / map.rows, q = row % map.rows;
+                    typedef const __attribute__((address_space(4))) u64 *kc_t;
+                    const u64 ip = ((kc_t)src.md.inv_p)[q], ips = ((kc_t)src.md.inv_p_shoup)[q];
+                    const u64 *prod_half = src.md.prod + pl * src.md.prod_stride + (q << LOGN) + gbase;
+                    u64 *ct_half = src.md.ct + (pl >> 1) * src.md.ct_stride + (((pl & 1) * map.rows + q) << LOGN) + gbase;
+                    const u64 *c0_half =
+                        (src.md.c0_src && !(pl & 1)) ? src.md.c0_src + (pl >> 1) * src.md.c0_stride + (q << LOGN) + gbase : nullptr;
+                    h_store_moddown<T>(x, fresh(tid), prod_half, ct_half, c0_half, src.md.c0_src == nullptr, ip, ips, P.p);
+                }
+                else
+                    h_store_rows<T>(x, rowp + gbase, fresh(tid));
             }
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
@@ -1882,10 +1933,17 @@ namespace sealhip
             const bool top_done = (flags & kNttTopDone) != 0;
             if (top_done && ((flags & (kNttReduceOut | kNttStrict | kNttCanonical)) != kNttReduceOut || src.base[0]))
                 return hipErrorInvalidValue;
-            unsigned *tickets = (no_ticket || top_done) ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
+            // a launch whose live rows are all gathered from another buffer writes no row that anybody reads: nothing to
+            // hand off either (SEALHIP_NTT_GATHER_TICKET=1 keeps the hand-off, for A/B)
+            static const bool gather_ticket = std::getenv("SEALHIP_NTT_GATHER_TICKET") != nullptr;
+            bool all_gathered = src.base[0] != nullptr && !gather_ticket;
+            for (int i = 0; all_gathered && i < live.n; i++)
+                all_gathered = src.code[live.slot[i]] != kSkipRow;
+            const bool no_handoff = no_ticket || top_done || all_gathered;
+            unsigned *tickets = no_handoff ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
             if (e.ntt_suppress_signal)
                 flags |= kNttDebugNoSignal; // sealhip_debug_ntt_handoff: drive the time-out path
-            if (!tickets && !no_ticket && !top_done)
+            if (!tickets && !no_handoff)
                 return hipErrorOutOfMemory;
 #ifdef SEALHIP_NTT_EXPERIMENT
             if (const char *sk = std::getenv("SEALHIP_NTT_SKIP"))
@@ -1930,8 +1988,8 @@ namespace sealhip
                 fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
             if (fp && src.base[0])
             {
-                if (src.reduce_mode == 4 || src.reduce_mode == 5)
-                    fp = src.aux_p < (src.reduce_mode == 5 ? kFpPrimeBound : u64(1) << 52); // (5: sums of two words below 2P)
+                if (src.reduce_mode == 4 || src.reduce_mode == 5 || src.reduce_mode == 7)
+                    fp = src.aux_p < (src.reduce_mode == 4 ? u64(1) << 52 : kFpPrimeBound); // (5, 7: sums of two words below 2P)
                 else
                     for (std::size_t i = 0; fp && i < e.key_moduli.size(); i++)
                         fp = e.key_moduli[i] < (u64(1) << 52);
@@ -1964,10 +2022,12 @@ namespace sealhip
             // wrapper, no kNttReduceOut) and 50p cannot wrap: every live prime below 2^58.
             static const bool no_apx = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
             bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0 &&
-                       red != 4 && red != 5;
+                       red != 4 && red != 5 && red != 7;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
-            if (fp && (red == 4 || red == 5))
+            if (red == 7 && (!fp || !kStoreExchange<T, 3>))
+                return hipErrorInvalidValue; // ntt_can_fuse_moddown said no: the caller runs moddown_post itself
+            if (fp && (red == 4 || red == 5 || red == 7))
             {
                 NttSource fsrc = src; // the special prime's constants as doubles (h_load_top)
                 const double P = static_cast<double>(src.aux_p), Pinv = 1.0 / P;
@@ -1976,7 +2036,13 @@ namespace sealhip
                 std::memcpy(&fsrc.aux_cr1, &Pinv, 8);
                 std::memcpy(&fsrc.aux_top[0], &c0, 8);
                 std::memcpy(&fsrc.aux_top[2], &c2, 8);
-                if (red == 5)
+                if (red == 7)
+                {
+                    if constexpr (kStoreExchange<T, 3>)
+                        ntt_fwd_half_kernel<LOGN, 3, 7><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
+                            data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                }
+                else if (red == 5)
                     ntt_fwd_half_kernel<LOGN, 3, 5><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
                         data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
                 else
@@ -2066,6 +2132,13 @@ namespace sealhip
             for (const void *f : fwd)
             {
                 err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (err != hipSuccess)
+                    return err;
+            }
+            if constexpr (kStoreExchange<LOGN - 1, 3>)
+            {
+                err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 7>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (err != hipSuccess)
                     return err;
             }
@@ -2208,6 +2281,18 @@ namespace sealhip
     bool ntt_can_defer_top(const Engine &e, int k)
     {
         return e.use_half_kernel && e.logn >= 14 && e.logn <= 16 && k <= 32 && !e.unfused_rns;
+    }
+
+    bool ntt_can_fuse_moddown(const Engine &e, int k, u64 p_special)
+    {
+        static const bool off = std::getenv("SEALHIP_KS_MODDOWN_STORE_UNFUSED") != nullptr;
+        if (off || !fp64_enabled() || !ntt_can_gather(e) || e.logn < 15 || (SEALHIP_NTT_STORE_EXCHANGE & 1) == 0 ||
+            p_special >= kFpPrimeBound)
+            return false;
+        for (int r = 0; r < k; r++)
+            if (e.key_moduli[r] >= kFpPrimeBound)
+                return false;
+        return true;
     }
 
     bool ntt_can_gather(const Engine &e)

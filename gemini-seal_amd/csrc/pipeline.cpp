@@ -241,6 +241,8 @@ namespace sealhip
                                   p_special < (u64(1) << 58) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
             // the gathered transform below reads the special row as pairs (c, c + N/2): it can apply the top inverse layer
             const bool fold_top = fold_pre && ntt_can_defer_top(e, k);
+            // ... and, in its floating-point form, finish the mod-down as it stores (reduce mode 7): temp is never written
+            const bool fold_store = fold_top && ntt_can_fuse_moddown(e, k, p_special);
             // (:2351-2355) special rows back to coefficient form (lazy)
             // (the mod-down reduces the special rows with barrett_reduce_63 / a Shoup product: canonical either way)
             check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, k, rows), true, kNttAnyRep | (fold_top ? kNttDeferTop : 0)),
@@ -254,7 +256,18 @@ namespace sealhip
                 NttSource ns{};
                 ns.base[0] = prod;
                 ns.poly_stride[0] = ext_item;
-                ns.reduce_mode = fold_top ? 5 : 4;
+                ns.reduce_mode = fold_store ? 7 : (fold_top ? 5 : 4);
+                if (fold_store)
+                {
+                    ns.md.inv_p = lt.d_ks->invP; // (addresses inside the device copy of KsDev; not dereferenced here)
+                    ns.md.inv_p_shoup = lt.d_ks->invP_shoup;
+                    ns.md.prod = prod;
+                    ns.md.prod_stride = ext_item;
+                    ns.md.ct = ctp;
+                    ns.md.ct_stride = ct_stride;
+                    ns.md.c0_src = c0p;
+                    ns.md.c0_stride = c0_stride;
+                }
                 ns.aux_p = p_special;
                 ns.aux_cr1 = HostModulus(p_special).cr1;
                 {
@@ -278,9 +291,10 @@ namespace sealhip
                 else
                     check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, kNttAnyRep), "intt(prod)");
             }
-            check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
-                                         ct_stride, 2 * m, 1, c0p, c0_stride),
-                  "moddown_post");
+            if (!fold_store)
+                check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
+                                             ct_stride, 2 * m, 1, c0p, c0_stride),
+                      "moddown_post");
         }
     }
 
