@@ -2125,3 +2125,11 @@ def test_round2_fast_paths_off_still_match_the_golden_digests():
                        env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode("utf-8", "replace")[-400:]
     assert r.returncode == 0 and " passed" in tail, tail
+    # one level up: the gathered mod-down transform (floating-point reduce mode 5) with its last kernel separate, which
+    # the default path at config 4's size no longer takes (it stores the finished mod-down itself, mode 7)
+    env = dict(os.environ, SEALHIP_KS_MODDOWN_STORE_UNFUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "cfg4_rotate_large_batch or cfg4_variant or (end_to_end_golden_digests and cfg4)"],
+                       env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode("utf-8", "replace")[-400:]
+    assert r.returncode == 0 and " passed" in tail, tail
