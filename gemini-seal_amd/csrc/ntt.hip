@@ -376,9 +376,12 @@ namespace sealhip
         typedef const __attribute__((address_space(4))) u64 *twd_const_t;
         // In the floating-point instances (STRICT == 3 forward, MODE == 2 inverse) the registers x[] hold the bit patterns
         // of doubles, the parameters named two_p / neg_p carry the bits of p and 1/p as doubles, and tw points to the
-        // double table. Reduction schedule of the forward transform: every value is brought to [-p/2, p/2] at the start
-        // of each round; a round's (at most four) layers then grow magnitudes to 0.5p -> 1.76p -> 3.02p -> 4.78p -> 6.73p
-        // (each layer adds |y*w mod p| < (0.5 + 2^-52 |y| 2^50 + 0.25) p), below 8p <= 2^53: all operations are exact.
+        // double table. Reduction schedule of the forward transform. With U = 2^50 >= p and B a bound on the magnitudes, a
+        // layer gives |y*w mod p| <= (0.5 + |y| 2^-52) p (the quotient estimate is off by the rounding of rint plus the
+        // relative 2^-52 of h * (1/p), and |h / p| <= |y|), so B' <= 1.25 B + 0.5 U: from a reduction (B = 0.5 U) six layers
+        // stay below 8 U = 2^53 (1.13, 1.91, 2.88, 4.10, 5.63, 7.54), from raw inputs below 2^52 the top layer does (5.5 U).
+        // Hence: all values to [-p/2, p/2] after the top layer, after the second layer of round 2, and before the final round
+        // (whose <= 3 layers are followed by the canonicalisation): every operation is exact.
         __device__ __forceinline__ void fp_reduce_all(u64 (&x)[32], u64 p_bits, u64 pinv_bits)
         {
             const double p = fp_of(p_bits), pinv = fp_of(pinv_bits);
@@ -733,6 +736,8 @@ namespace sealhip
                 if constexpr (K + 1 < NST)
                     RoundStage<T, R, STRICT, UNIFORM, K + 1>::load(wn, wsn, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STRICT == 3 && R == 2 && K == 2 * (16 / kIL))
+                    fp_reduce_all(x, two_p, neg_p); // (after two of round 2's layers: see fp_reduce_all)
                 RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
                 if constexpr (K + 1 < NST)
                     RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
@@ -1087,8 +1092,6 @@ namespace sealhip
                 h_exchange<T, 1, 2>(x, lds, fresh(tid));
             if (tid == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if constexpr (FP)
-                fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
@@ -1096,8 +1099,6 @@ namespace sealhip
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 2, 3>(x, lds, fresh(tid));
-            if constexpr (FP)
-                fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
             const int jb4 = gbase + Arr<T, 4>::tid_index(fresh(tid));
@@ -1205,13 +1206,13 @@ namespace sealhip
             static constexpr int max_shift = 1 + (r1 > T - 2 - r1 ? r1 : T - 2 - r1);
         };
         // Floating-point schedule of the inverse (LZ == 2, primes below 2^50, inputs below 2p): sums double the bound per
-        // layer, so both outputs of layers 0, 3, 6, ... are brought back to [-p/2, p/2]: 2p -> 4p | 0.5p -> p -> 2p -> 4p |
-        // ..., products of differences stay below 1.5p. Everything below 8p <= 2^53 is exact (devmath.hpp). The last layer's
-        // outputs are canonicalised by the store instead.
+        // layer, so both outputs of layers 1, 5, 9, 13 are brought back to [-p/2, p/2]: 2p -> 4p -> 8p | 0.5p -> p -> 2p ->
+        // 4p -> 8p | ...; a difference is at most 8p too, its product below (0.5 + 8p 2^-52) p <= 2.5p. Every magnitude stays
+        // at or below 8p < 2^53: exact (devmath.hpp). The last layer's outputs are canonicalised by the store instead.
         template <int T>
         constexpr bool fp_inv_reduce_after(int layer)
         {
-            return layer % 3 == 0 && layer != T - 1;
+            return layer % 4 == 1 && layer != T - 1;
         }
         template <int T, int R, bool UNIFORM, int K, int LZ = 0>
         struct RoundStageInv
