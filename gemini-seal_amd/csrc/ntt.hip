@@ -1286,10 +1286,10 @@ namespace sealhip
                 }
             }
         };
-        template <int T, int R, bool UNIFORM, int LZ, int K = 0>
+        template <int T, int R, bool UNIFORM, int LZ, int K = 0, int NLAYERS = 4>
         struct RoundPipeInv
         {
-            static constexpr int NST = 4 * (16 / kIL);
+            static constexpr int NST = NLAYERS * (16 / kIL); // (NLAYERS = 3: the whole-row form applies the round's last layer itself)
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
                                                        const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p,
                                                        u64 rdp)
@@ -1300,7 +1300,7 @@ namespace sealhip
                 __builtin_amdgcn_sched_barrier(0);
                 RoundStageInv<T, R, UNIFORM, K, LZ>::run(x, w, ws, two_p, neg_p, rdp);
                 if constexpr (K + 1 < NST)
-                    RoundPipeInv<T, R, UNIFORM, LZ, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, rdp);
+                    RoundPipeInv<T, R, UNIFORM, LZ, K + 1, NLAYERS>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, rdp);
             }
         };
 
@@ -1556,7 +1556,11 @@ namespace sealhip
         // -- it still holds its own half in registers -- reads the sibling's half back, applies the layer to both halves and
         // stores the whole row. Nobody waits for anybody: the first finisher just leaves. Saves the separate streaming
         // kernel (read N + write N from HBM) of the standalone inverse transforms.
-        template <int LOGN, int LZ, bool DY, bool TOPF = false>
+        // WHOLE: the same workgroup shape (2^T coefficients, T = LOGN - 1) applied to a whole row of a ring of 2^T coefficients:
+        // one workgroup per row, all T layers on chip -- the last of them is the row's top layer (BackwardLazyLast with
+        // n^-1 folded in, ntt.cpp:274-281) -- so the standalone inverse is ONE launch that reads and writes the row once,
+        // instead of the half-row kernel plus the streaming top-layer pass. All three arithmetic forms, N = 2^14 and 2^15.
+        template <int LOGN, int LZ, bool DY, bool TOPF = false, bool WHOLE = false>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
@@ -1567,13 +1571,25 @@ namespace sealhip
                                                                                   unsigned *__restrict__ tickets = nullptr,
                                                                                   int canonical = 0)
         {
+            static_assert(!WHOLE || (!DY && !TOPF), "whole-row form: plain transforms");
             constexpr int T = LOGN - 1;
-            constexpr int N = 1 << LOGN;
+            constexpr int LOGR = WHOLE ? T : LOGN; // log2 of the row length
+            constexpr int N = 1 << LOGR;
             extern __shared__ u64 lds[];
             const int tid = threadIdx.x;
-            int half, position;
+            int half = 0, position;
             std::size_t poly;
-            if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
+            if constexpr (WHOLE)
+            {
+                // same XCD-aware enumeration as half_block_map, one workgroup per live row
+                const std::size_t slot = blockIdx.x >> 3, npolys = nrows / map.rows;
+                const std::size_t v = static_cast<std::size_t>(blockIdx.x & 7u) * chunk + slot;
+                if (slot >= chunk || v >= npolys * static_cast<std::size_t>(live.n))
+                    return;
+                poly = v % npolys;
+                position = static_cast<int>(v / npolys);
+            }
+            else if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
                 return;
             const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
@@ -1583,9 +1599,9 @@ namespace sealhip
             const u64 p = P.p, two_p = FP ? fp_bits(P.p_d) : P.two_p;
             const u64 *tw = FP ? reinterpret_cast<const u64 *>(P.inv_d) : P.inv;
             const int gbase = half << T;
-            u64 *halfp = data + (row << LOGN) + gbase;
+            u64 *halfp = data + (row << LOGR) + gbase;
             // optional out-of-place input (polynomial-strided rows of another buffer): saves a copy kernel
-            const u64 *inp = src ? src + (row / map.rows) * src_poly_stride + ((row % map.rows) << LOGN) + gbase : halfp;
+            const u64 *inp = src ? src + (row / map.rows) * src_poly_stride + ((row % map.rows) << LOGR) + gbase : halfp;
             u64 x[32];
             const u64 neg_p = FP ? fp_bits(P.pinv_d) : 0 - p;
             {
@@ -1645,7 +1661,49 @@ namespace sealhip
             RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp);
             RoundStageInv<T, 1, true, 0, LZ>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh(tid));
-            RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
+            if constexpr (WHOLE)
+            {
+                RoundPipeInv<T, 1, true, LZ, 0, 3>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
+                // the row's top layer: slot bit 4 of arrangement 1 is index bit T - 1
+                if constexpr (FP)
+                {
+                    // (inputs at most 4p in magnitude)
+                    const double pd = fp_of(two_p), pinv = fp_of(neg_p);
+                    const double c_sum = static_cast<double>(P.inv_n), c_diff = static_cast<double>(P.inv_n_w);
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; s2++)
+                    {
+                        const double u = fp_of(x[s2]), v = fp_of(x[s2 | 16]);
+                        x[s2] = fp_bits(fp_mulmod(u + v, c_sum, pd, pinv));
+                        x[s2 | 16] = fp_bits(fp_mulmod(u - v, c_diff, pd, pinv));
+                    }
+                }
+                else
+                {
+                    // BackwardLazyLast as ntt_inv_top_kernel applies it; with lazy sums the operands are below
+                    // 2^shift(T - 1) p, so that multiple of p keeps the difference non-negative
+                    const u64 addend = LZ == 1 ? (0 - neg_p) << InvLazy<T>::shift(T - 1) : two_p;
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; s2++)
+                    {
+                        const u64 u = x[s2], v = x[s2 | 16];
+                        u64 tt = u + v;
+                        if (LZ == 0)
+                            tt = tt >= two_p ? tt - two_p : tt;
+                        u64 a0 = mulmod_lazy_hs<true>(tt, P.inv_n, P.inv_n_shoup, neg_p);
+                        u64 a1 = mulmod_lazy_hs<true>(u - v + addend, P.inv_n_w, P.inv_n_w_shoup, neg_p);
+                        if (canonical)
+                        {
+                            a0 = a0 >= p ? a0 - p : a0;
+                            a1 = a1 >= p ? a1 - p : a1;
+                        }
+                        x[s2] = a0;
+                        x[s2 | 16] = a1;
+                    }
+                }
+            }
+            else
+                RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
             if constexpr (!TOPF)
             {
                 const int jb = Arr<T, 1>::tid_index(fresh(tid));
@@ -1851,6 +1909,32 @@ namespace sealhip
                 unsigned *tickets = topf ? e.ntt_tickets(nrows) : nullptr;
                 if (topf && !tickets)
                     return hipErrorOutOfMemory;
+                if constexpr (LOGN <= 15)
+                {
+                    // whole-row form (see the kernel): standalone floating-point transforms (the top layer is not left to a
+                    // consumer). Bit log n of SEALHIP_NTT_WHOLE_ROW (default: 2^14 and 2^15).
+                    static const unsigned long whole_mask = [] {
+                        const char *env = std::getenv("SEALHIP_NTT_WHOLE_ROW");
+                        return env ? std::strtoul(env, nullptr, 0) : ((1ul << 14) | (1ul << 15));
+                    }();
+                    if (!dyadic && !topf && !(flags & kNttDeferTop) && ((whole_mask >> LOGN) & 1))
+                    {
+                        const std::size_t wlds = static_cast<std::size_t>(hpad(1 << (LOGN - 1))) * 8;
+                        const int canon = (flags & kNttCanonical) ? 1 : 0;
+#define SEALHIP_INV_WHOLE(LZ_)                                                                                          \
+    ntt_inv_half_kernel<LOGN + 1, LZ_, false, false, true>                                                               \
+        <<<static_cast<unsigned>(chunk * 8), 1 << (LOGN - 5), wlds, e.lane().stream>>>(                                  \
+            data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, nullptr, canon)
+                        if (fp)
+                            SEALHIP_INV_WHOLE(2);
+                        else if (lazy)
+                            SEALHIP_INV_WHOLE(1);
+                        else
+                            SEALHIP_INV_WHOLE(0);
+#undef SEALHIP_INV_WHOLE
+                        return hipGetLastError();
+                    }
+                }
 #define SEALHIP_INV_HALF(LZ_, DY_)                                                                                    \
     ntt_inv_half_kernel<LOGN, LZ_, DY_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy)
@@ -2156,7 +2240,19 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            return hipSuccess;
+            if constexpr (LOGN <= 15)
+            {
+                const void *whole[3] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 2, false, false, true>),
+                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 1, false, false, true>),
+                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 0, false, false, true>) };
+                for (const void *f : whole)
+                {
+                    err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hpad(1 << (LOGN - 1)) * 8);
+                    if (err != hipSuccess)
+                        return err;
+                }
+            }
+            return err;
         }
 
         void make_rounds(NttPass &ps, int lo, int hi, bool inverse)
