@@ -1925,9 +1925,13 @@ namespace sealhip
     ntt_inv_half_kernel<LOGN + 1, LZ_, false, false, true>                                                               \
         <<<static_cast<unsigned>(chunk * 8), 1 << (LOGN - 5), wlds, e.lane().stream>>>(                                  \
             data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, nullptr, canon)
+                        // (the lazy-sum schedule of the larger shape has one more layer: its own bound on the primes)
+                        bool lazy_w = lazy;
+                        for (int i = 0; lazy_w && i < live.n; i++)
+                            lazy_w = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<LOGN>::max_shift));
                         if (fp)
                             SEALHIP_INV_WHOLE(2);
-                        else if (lazy)
+                        else if (lazy_w)
                             SEALHIP_INV_WHOLE(1);
                         else
                             SEALHIP_INV_WHOLE(0);

@@ -42,7 +42,9 @@ def rand_rows(rng, moduli, n, full_range=False):
 
 # ------------------------------------------------------------------ NTT
 NTT_CASES = [(3, [20]), (4, [30, 30]), (5, [25]), (6, [30] * 4), (8, [40, 41]), (10, [50] * 3), (12, [36, 36, 37]),
-             (13, [59, 58]), (14, [50] * 6), (15, [55] * 8), (16, [50] * 3)]
+             (13, [59, 58]), (14, [50] * 6), (15, [55] * 8), (16, [50] * 3),
+             # mixed sizes around the lazy-sum bounds of the half-row and whole-row shapes (2^55, 2^56) and the FP64 bound
+             (14, [58, 56, 55, 48]), (15, [56, 58, 55, 48]), (16, [56, 55, 49])]
 
 
 @pytest.mark.parametrize("logn,bits", NTT_CASES, ids=lambda x: str(x))
@@ -2113,13 +2115,13 @@ def test_round2_fast_paths_off_still_match_the_golden_digests():
     """Round 2's fast paths each have a switch that restores the form they replaced: the FP64 NTT instances
     (SEALHIP_NTT_NO_FP64), the top layer applied by bfv_lift2 (SEALHIP_LIFT_TOP_OFF), the CKKS mod-down folded into the
     gathered transform (SEALHIP_KS_MODDOWN_UNFUSED) and the tensor product formed by the inverse transform
-    (SEALHIP_TENSOR_UNFUSED). With all of them off (child process: the switches are read once) the golden digests of the
+    (SEALHIP_TENSOR_UNFUSED), the whole-row inverse (SEALHIP_NTT_WHOLE_ROW=0: half-row kernel + top-layer pass). With all of them off (child process: the switches are read once) the golden digests of the
     compiled reference must come out as they do in this process with all of them on."""
     import subprocess
     import sys
 
     env = dict(os.environ, SEALHIP_NTT_NO_FP64="1", SEALHIP_LIFT_TOP_OFF="1", SEALHIP_KS_MODDOWN_UNFUSED="1",
-               SEALHIP_TENSOR_UNFUSED="1")
+               SEALHIP_TENSOR_UNFUSED="1", SEALHIP_NTT_WHOLE_ROW="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "end_to_end_golden_digests or ntt_golden_digests or bench_launch_shapes or cfg4_rotate_large_batch"],
                        env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

@@ -37,6 +37,8 @@ def one(rng, it):
     t = 65537 if scheme == 1 else 0
     # (17 and 33 take the batched key-switch kernels: key words reused across a group of ciphertexts, ragged last group)
     count = int(rng.choice([1, 2, 5, 17, 33])) if logn <= 12 else (int(rng.choice([1, 3, 17])) if logn <= 14 else int(rng.choice([1, 2, 2, 17])))
+    print("case", it, "%s logn=%d k=%d nsp=%d count=%d bits=%s" % ("BFV" if scheme == 1 else "CKKS", logn, k, nsp, count, bits),
+          flush=True) if os.environ.get("FUZZ_VERBOSE") else None
     ctx = S.Context(scheme, logn, kmods, nsp, t)
     ev = S.Evaluator(ctx)
     ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t)
