@@ -418,11 +418,96 @@ namespace sealhip
 #ifndef SEALHIP_NTT_STORE_EXCHANGE
 #define SEALHIP_NTT_STORE_EXCHANGE 5
 #endif
-        template <int T, int STRICT>
+        // Round 3: the transposition in registers instead. What is slow about the f >= 2 pattern is not the 16-byte pieces
+        // as such but the *streaming* (nontemporal) stores of them: tools/ubench_store_pattern.hip writes the same half
+        // rows at 1.9 TB/s nontemporal against 5.7 TB/s with plain stores (the L2 merges the two instructions' pieces),
+        // and a nontemporal instruction is fast (5.5 TB/s) as soon as the wave as a whole covers contiguous memory --
+        // which lane writes which piece does not matter (profiles/r03/store_pattern_ubench.txt). v_permlane32_swap
+        // (lanes 32-63 of one register <-> lanes 0-31 of another) is exactly that transposition for f = 2: before,
+        // lane (l5, r) holds pairs h = 0, 1 of its run; after swap(pair 0, pair 1) register h of lane (l5, r) holds pair
+        // l5 of lane (h, r), so instruction h writes the 128 consecutive coefficients of half-wave h: one dword move per
+        // dword, no LDS, no barrier. For f = 3 a v_permlane16_swap step (rows of 16 lanes) transposes the second bit.
+        // Mask bits as in SEALHIP_NTT_STORE_EXCHANGE; the swap takes precedence (mode 7 keeps the trip: its store phase
+        // reads the product rows at the same addresses).
+#ifndef SEALHIP_NTT_STORE_SWAP
+#define SEALHIP_NTT_STORE_SWAP 7
+#endif
+#ifndef SEALHIP_NTT_STORE_NT
+#define SEALHIP_NTT_STORE_NT 1
+#endif
+        template <int T, int STRICT, int REDUCE = 0>
+        constexpr bool kStoreSwap = (T - 12) >= 2 && REDUCE != 7 &&
+                                    ((SEALHIP_NTT_STORE_SWAP) & (STRICT == 3 ? 1 : ((T - 12) == 2 ? 2 : 4))) != 0;
+        template <int T, int STRICT, int REDUCE = 0>
         constexpr bool kStoreExchange =
-            (T - 12) >= 2 && ((SEALHIP_NTT_STORE_EXCHANGE) & (STRICT == 3 ? 1 : ((T - 12) == 2 ? 2 : 4))) != 0;
+            (T - 12) >= 2 && !kStoreSwap<T, STRICT, REDUCE> &&
+            ((SEALHIP_NTT_STORE_EXCHANGE) & (STRICT == 3 ? 1 : ((T - 12) == 2 ? 2 : 4))) != 0;
 
-        template <int T, int STRICT, int G, bool ROUT>
+        __device__ __forceinline__ void swap_half_waves(u64 &a, u64 &b) // lanes 32-63 of a <-> lanes 0-31 of b
+        {
+            const auto lo = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(a), static_cast<unsigned>(b), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(a >> 32), static_cast<unsigned>(b >> 32), false, false);
+            a = lo[0] | (static_cast<u64>(hi[0]) << 32);
+            b = lo[1] | (static_cast<u64>(hi[1]) << 32);
+        }
+        __device__ __forceinline__ void swap_rows16(u64 &a, u64 &b) // odd 16-lane rows of a <-> even rows of b
+        {
+            const auto lo = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(a), static_cast<unsigned>(b), false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(a >> 32), static_cast<unsigned>(b >> 32), false, false);
+            a = lo[0] | (static_cast<u64>(hi[0]) << 32);
+            b = lo[1] | (static_cast<u64>(hi[1]) << 32);
+        }
+        // Final-round group G (2^f finished registers, runs of 2^f consecutive coefficients per lane) -> memory through the
+        // register transposition: afterwards pair register i of lane L holds pair (L >> 4 or 5 bits) of the lane whose
+        // those bits are i, so instruction i writes the i-th 128-coefficient piece of the wave's 2^(f+6) coefficients.
+        template <int T, int G>
+        __device__ __forceinline__ void h_store_group_swapped(u64 (&x)[32], u64 *__restrict__ rowp, int jb)
+        {
+            constexpr int f = T - 12;
+            static_assert(f == 2 || f == 3, "register transposition: runs of 4 or 8 coefficients");
+            constexpr int s = G << f;
+            const int j = jb & ((1 << T) | ((1 << T) - 1)); // (the experiment build keeps its hooks above)
+            const int tid = (j & ((1 << T) - 1)) >> f;
+            // lane part of the address: the wave's base, then r * 2^f + (the swapped lane bits) * 2
+            int base = (j & (1 << T)) + ((tid >> 6) << (6 + f));
+            if constexpr (f == 2)
+            {
+                base += ((tid & 31) << 2) + (((tid >> 5) & 1) << 1);
+                swap_half_waves(x[s], x[s + 2]);
+                swap_half_waves(x[s + 1], x[s + 3]);
+            }
+            else
+            {
+                base += ((tid & 15) << 3) + (((tid >> 5) & 1) << 2) + (((tid >> 4) & 1) << 1);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    swap_half_waves(x[s + e], x[s + 4 + e]);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                {
+                    swap_rows16(x[s + e], x[s + 2 + e]);
+                    swap_rows16(x[s + 4 + e], x[s + 6 + e]);
+                }
+            }
+            u64 *dst = rowp + base + Arr<T, 4>::slot_index(s);
+#pragma unroll
+            for (int i = 0; i < (1 << (f - 1)); i++)
+            {
+                if (SEALHIP_NTT_STORE_NT)
+                    store_nt(dst + i * 128, x[s + 2 * i], x[s + 2 * i + 1]);
+                else
+                {
+                    ulonglong2 v;
+                    v.x = x[s + 2 * i];
+                    v.y = x[s + 2 * i + 1];
+                    *reinterpret_cast<ulonglong2 *>(dst + i * 128) = v;
+                }
+            }
+        }
+
+        // SX: what happens to the finished words -- 0 stored from arrangement 4 as they are, 1 kept for the LDS trip
+        // (kStoreExchange), 2 transposed in registers and stored group by group (kStoreSwap)
+        template <int T, int STRICT, int G, bool ROUT, int SX>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -485,9 +570,9 @@ namespace sealhip
                 }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
-                if constexpr (kStoreExchange<T, STRICT>)
+                if constexpr (SX != 0)
                 {
-                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1
+                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1, or transposed below
                     x[s + 1] = v.y;
                 }
                 else
@@ -495,22 +580,25 @@ namespace sealhip
                     //  streaming stores cost 12 % there)
                     *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
             }
+            if constexpr (SX == 2)
+                if (!NTT_EXP(N, 0x800 << 20))
+                    h_store_group_swapped<T, G>(x, rowp, jb);
         }
 
-        template <int T, int STRICT, int G, int NG, bool ROUT>
+        template <int T, int STRICT, int G, int NG, bool ROUT, int SX>
         struct FinalGroups
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
                                                        int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
-                h_final_group<T, STRICT, G, ROUT>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                h_final_group<T, STRICT, G, ROUT, SX>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 if ((G & 1) == 1)
                     __builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting every group's twiddle loads
-                FinalGroups<T, STRICT, G + 1, NG, ROUT>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                FinalGroups<T, STRICT, G + 1, NG, ROUT, SX>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, int STRICT, int NG, bool ROUT>
-        struct FinalGroups<T, STRICT, NG, NG, ROUT>
+        template <int T, int STRICT, int NG, bool ROUT, int SX>
+        struct FinalGroups<T, STRICT, NG, NG, ROUT, SX>
         {
             __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
             {}
@@ -550,7 +638,7 @@ namespace sealhip
             }
         }
 
-        template <int T, int STRICT, int G, bool ROUT>
+        template <int T, int STRICT, int G, bool ROUT, int SX>
         __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
                                                            int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
         {
@@ -611,14 +699,19 @@ namespace sealhip
                 }
                 if (NTT_EXP(N, 0x800 << 20) && v.x != 0x1234567)
                     continue;
-                if constexpr (kStoreExchange<T, STRICT>)
+                if constexpr (SX != 0)
                 {
-                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1
+                    x[s] = v.x; // stored by h_store_rows after the trip back to arrangement 1, or transposed below
                     x[s + 1] = v.y;
                 }
-                else
+                else if (SEALHIP_NTT_STORE_NT)
                     store_nt(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s), v.x, v.y);
+                else
+                    *reinterpret_cast<ulonglong2 *>(rowp + (jb & ((1 << T) | ((1 << T) - 1))) + Arr<T, 4>::slot_index(s)) = v;
             }
+            if constexpr (SX == 2)
+                if (!NTT_EXP(N, 0x800 << 20))
+                    h_store_group_swapped<T, G>(x, rowp, jb);
         }
 
         template <int T, int ST, int I = 0, bool FP = false>
@@ -631,19 +724,19 @@ namespace sealhip
                     StageTw<T, ST, I + 1, FP>::load(tg, tw, jb, N);
             }
         };
-        template <int T, int STRICT, bool ROUT, int ST, int I = 0>
+        template <int T, int STRICT, bool ROUT, int SX, int ST, int I = 0>
         struct StageRun
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
                                                        u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
             {
-                h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I, ROUT>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
+                h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I, ROUT, SX>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
                                                                                two_p, neg_p, rdp, fin);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    StageRun<T, STRICT, ROUT, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    StageRun<T, STRICT, ROUT, SX, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
-        template <int T, int STRICT, bool ROUT, int ST>
+        template <int T, int STRICT, bool ROUT, int SX, int ST>
         struct FinalPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
@@ -654,10 +747,10 @@ namespace sealhip
                 if constexpr (ST + 1 < FinalStage<T>::NS)
                     StageTw<T, ST + 1, 0, STRICT == 3>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                StageRun<T, STRICT, ROUT, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                StageRun<T, STRICT, ROUT, SX, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FinalPipe<T, STRICT, ROUT, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    FinalPipe<T, STRICT, ROUT, SX, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
             }
         };
 
@@ -1133,7 +1226,9 @@ namespace sealhip
                 // (the other lanes of the wave wait for lane 0 through re-convergence; every wave checks for itself
                 //  that both workgroups of the row have finished reading)
             };
-            if constexpr (!kStoreExchange<T, STRICT>)
+            constexpr bool XCH = kStoreExchange<T, STRICT, REDUCE>;
+            constexpr int SX = XCH ? 1 : (kStoreSwap<T, STRICT, REDUCE> ? 2 : 0);
+            if constexpr (!XCH)
                 wait_for_sibling(); // the final round stores as it goes
             NTT_STAMP(3);
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
@@ -1142,10 +1237,10 @@ namespace sealhip
             const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0);
             constexpr bool ROUT = REDUCE == 3 || REDUCE == 6; // kNttReduceOut launches (never gathered: no load treatment to combine with)
             if constexpr (FinalStage<T>::PIPE)
-                FinalPipe<T, STRICT, ROUT, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+                FinalPipe<T, STRICT, ROUT, SX, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
             else
-                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
-            if constexpr (kStoreExchange<T, STRICT>)
+                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT, SX>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+            if constexpr (XCH)
             {
                 if (!NTT_EXP(flags, 0x200))
                     h_exchange<T, 4, 1>(x, lds, fresh(tid));
@@ -2114,7 +2209,7 @@ namespace sealhip
                        red != 4 && red != 5 && red != 7;
             for (int i = 0; apx && i < live.n; i++)
                 apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
-            if (red == 7 && (!fp || !kStoreExchange<T, 3>))
+            if (red == 7 && (!fp || !kStoreExchange<T, 3, 7>))
                 return hipErrorInvalidValue; // ntt_can_fuse_moddown said no: the caller runs moddown_post itself
             if (fp && (red == 4 || red == 5 || red == 7))
             {
@@ -2127,7 +2222,7 @@ namespace sealhip
                 std::memcpy(&fsrc.aux_top[2], &c2, 8);
                 if (red == 7)
                 {
-                    if constexpr (kStoreExchange<T, 3>)
+                    if constexpr (kStoreExchange<T, 3, 7>)
                         ntt_fwd_half_kernel<LOGN, 3, 7><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
                             data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
                 }
@@ -2224,7 +2319,7 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            if constexpr (kStoreExchange<LOGN - 1, 3>)
+            if constexpr (kStoreExchange<LOGN - 1, 3, 7>)
             {
                 err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 7>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
