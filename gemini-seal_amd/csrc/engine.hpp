@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "devmath.hpp"
+#include "ntt_bounds.hpp"
 #include "hostmath.hpp"
 
 namespace sealhip
@@ -81,7 +82,8 @@ namespace sealhip
     // Primes below this bound have double-precision twiddle tables: the single-pass kernels then run their butterflies
     // on the FP64 pipe (exact, devmath.hpp) whenever the launch promises nothing about representatives that only the
     // integer sequence would deliver (canonical outputs, or kNttAnyRep). SEALHIP_NTT_NO_FP64=1 switches it off.
-    constexpr u64 kFpPrimeBound = u64(1) << 50;
+    // (the bound is what the schedules' worst-case recurrences in ntt_bounds.hpp admit: 50 bits)
+    constexpr u64 kFpPrimeBound = u64(1) << bounds::kFpPrimeBits;
 
     struct NttRound
     {

@@ -376,12 +376,15 @@ namespace sealhip
         typedef const __attribute__((address_space(4))) u64 *twd_const_t;
         // In the floating-point instances (STRICT == 3 forward, MODE == 2 inverse) the registers x[] hold the bit patterns
         // of doubles, the parameters named two_p / neg_p carry the bits of p and 1/p as doubles, and tw points to the
-        // double table. Reduction schedule of the forward transform. With U = 2^50 >= p and B a bound on the magnitudes, a
-        // layer gives |y*w mod p| <= (0.5 + |y| 2^-52) p (the quotient estimate is off by the rounding of rint plus the
-        // relative 2^-52 of h * (1/p), and |h / p| <= |y|), so B' <= 1.25 B + 0.5 U: from a reduction (B = 0.5 U) six layers
-        // stay below 8 U = 2^53 (1.13, 1.91, 2.88, 4.10, 5.63, 7.54), from raw inputs below 2^52 the top layer does (5.5 U).
-        // Hence: all values to [-p/2, p/2] after the top layer, after the second layer of round 2, and before the final round
-        // (whose <= 3 layers are followed by the canonicalisation): every operation is exact.
+        // double table. Reduction schedule of the forward transform (ntt_bounds.hpp section 4 holds the derivation and the
+        // recurrence the CPU test runs). With U = 2^50 >= p and B a bound on the magnitudes, a layer gives
+        // |y*w mod p| <= (0.5 + 3 * 2^-53 |y|) p -- the quotient estimate's rounding, the relative 2^-52 of h * (1/p) AND the
+        // exact rounding error l of the product -- so B' <= 1.375 B + 0.5 U: from a reduction (B = 0.5 U) FIVE layers stay
+        // below 8 U = 2^53 (1.19, 2.13, 3.43, 5.22, 7.68), from raw inputs below 2^52 the top layer does (6 U). Hence: all
+        // values to [-p/2, p/2] after the top layer, after round 2's first layer and after round 3's second (spans of 5, 5 and
+        // at most 2 + 3 layers, the last followed by the canonicalisation): every operation is exact. (Round 2 reduced after
+        // round 2's second layer and before the final round -- two spans of six layers, sound only under the bound
+        // (0.5 + 2^-52 |y|) p, which ignores l: ADVICE r02.)
         __device__ __forceinline__ void fp_reduce_all(u64 (&x)[32], u64 p_bits, u64 pinv_bits)
         {
             const double p = fp_of(p_bits), pinv = fp_of(pinv_bits);
@@ -829,8 +832,9 @@ namespace sealhip
                 if constexpr (K + 1 < NST)
                     RoundStage<T, R, STRICT, UNIFORM, K + 1>::load(wn, wsn, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (STRICT == 3 && R == 2 && K == 2 * (16 / kIL))
-                    fp_reduce_all(x, two_p, neg_p); // (after two of round 2's layers: see fp_reduce_all)
+                // (before on-chip layers 5 and 10 -- after round 2's first and round 3's second layer: see fp_reduce_all)
+                if constexpr (STRICT == 3 && K % (16 / kIL) == 0 && bounds::fp_fwd_reduce_before_layer(4 * (R - 1) + K / (16 / kIL)))
+                    fp_reduce_all(x, two_p, neg_p);
                 RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
                 if constexpr (K + 1 < NST)
                     RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
@@ -1203,8 +1207,9 @@ namespace sealhip
             }
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 3, 4>(x, lds, fresh(tid));
-            if constexpr (FP)
-                fp_reduce_all(x, two_p, neg_p);
+            static_assert(!bounds::fp_fwd_reduce_before_layer(12) && !bounds::fp_fwd_reduce_before_layer(13) &&
+                              !bounds::fp_fwd_reduce_before_layer(14),
+                          "the final round runs without a reduction (the schedule reduces inside rounds 2 and 3)");
             NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             const auto wait_for_sibling = [&] {
@@ -1286,20 +1291,24 @@ namespace sealhip
         // prime of the launch is small enough, launch_half_inv): the conditional subtraction of the sum output is dropped
         // on all but two of the T on-chip layers; those two (the middle one and the last) reduce with barrett_lazy
         // instead. Values entering layer l are below 2^shift(l) * p; the difference operand gets that bound added.
+        // (the schedule, its worst-case recurrence and the admission predicate live in ntt_bounds.hpp)
         template <int T>
         struct InvLazy
         {
-            static constexpr int r1 = (T - 1) / 2;
+            static constexpr int r1 = bounds::inv_lazy_r1(T);
             static constexpr int mode(int l)
             {
-                return (l == r1 || l == T - 1) ? 2 : 1;
+                return bounds::inv_lazy_mode(T, l);
             }
             static constexpr int shift(int l)
             {
-                return 1 + (l <= r1 ? l : l - r1 - 1);
+                return bounds::inv_lazy_shift(T, l);
             }
-            static constexpr int max_shift = 1 + (r1 > T - 2 - r1 ? r1 : T - 2 - r1);
         };
+        // on-chip layers of the inverse kernel instance ntt_inv_half_kernel<KLOGN, ...> (half-row form of a ring of 2^KLOGN,
+        // or whole-row form of a ring of 2^(KLOGN-1)): what the launchers hand to bounds::inv_lazy_admits
+        template <int KLOGN>
+        constexpr int kInvLayers = KLOGN - 1;
         // Floating-point schedule of the inverse (LZ == 2, primes below 2^50, inputs below 2p): sums double the bound per
         // layer, so both outputs of layers 1, 5, 9, 13 are brought back to [-p/2, p/2]: 2p -> 4p -> 8p | 0.5p -> p -> 2p ->
         // 4p -> 8p | ...; a difference is at most 8p too, its product below (0.5 + 8p 2^-52) p <= 2.5p. Every magnitude stays
@@ -1307,7 +1316,7 @@ namespace sealhip
         template <int T>
         constexpr bool fp_inv_reduce_after(int layer)
         {
-            return layer % 4 == 1 && layer != T - 1;
+            return bounds::fp_inv_reduce_after_layer(T, layer);
         }
         template <int T, int R, bool UNIFORM, int K, int LZ = 0>
         struct RoundStageInv
@@ -1989,7 +1998,7 @@ namespace sealhip
                 static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_INV") != nullptr;
                 bool lazy = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !exact_only;
                 for (int i = 0; lazy && i < live.n; i++)
-                    lazy = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<T>::max_shift));
+                    lazy = bounds::inv_lazy_admits(kInvLayers<LOGN>, e.tables[map.prime[live.slot[i]]].p);
                 // floating-point instance: same contract (inputs below 2p, any representative out), every live prime below 2^50
                 bool fp = (flags & (kNttAnyRep | kNttCanonical)) != 0 && fp64_enabled() && !dyadic;
                 for (int i = 0; fp && i < live.n; i++)
@@ -2020,10 +2029,11 @@ namespace sealhip
     ntt_inv_half_kernel<LOGN + 1, LZ_, false, false, true>                                                               \
         <<<static_cast<unsigned>(chunk * 8), 1 << (LOGN - 5), wlds, e.lane().stream>>>(                                  \
             data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, nullptr, canon)
-                        // (the lazy-sum schedule of the larger shape has one more layer: its own bound on the primes)
+                        // (the lazy-sum schedule of the larger shape has one more layer: its own bound on the primes -- the
+                        //  predicate takes the layer count of the instance that is launched, ntt_inv_half_kernel<LOGN + 1, ..>)
                         bool lazy_w = lazy;
                         for (int i = 0; lazy_w && i < live.n; i++)
-                            lazy_w = e.tables[map.prime[live.slot[i]]].p < (u64(1) << (63 - InvLazy<LOGN>::max_shift));
+                            lazy_w = bounds::inv_lazy_admits(kInvLayers<LOGN + 1>, e.tables[map.prime[live.slot[i]]].p);
                         if (fp)
                             SEALHIP_INV_WHOLE(2);
                         else if (lazy_w)
@@ -2173,10 +2183,10 @@ namespace sealhip
             if (fp && src.base[0])
             {
                 if (src.reduce_mode == 4 || src.reduce_mode == 5 || src.reduce_mode == 7)
-                    fp = src.aux_p < (src.reduce_mode == 4 ? u64(1) << 52 : kFpPrimeBound); // (5, 7: sums of two words below 2P)
+                    fp = src.aux_p < (src.reduce_mode == 4 ? bounds::kFpInputBound : kFpPrimeBound); // (5, 7: sums of two words below 2P)
                 else
                     for (std::size_t i = 0; fp && i < e.key_moduli.size(); i++)
-                        fp = e.key_moduli[i] < (u64(1) << 52);
+                        fp = e.key_moduli[i] < bounds::kFpInputBound;
             }
             if (flags & kNttAnyRep)
             {
@@ -2185,7 +2195,7 @@ namespace sealhip
                 static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
                 bool ok = !exact_only && (flags & (kNttCanonical | kNttStrict)) == 0;
                 for (int i = 0; ok && i < live.n; i++)
-                    ok = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
+                    ok = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
                 if (!ok)
                     flags &= ~kNttAnyRep;
             }
@@ -2208,7 +2218,7 @@ namespace sealhip
             bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0 &&
                        red != 4 && red != 5 && red != 7;
             for (int i = 0; apx && i < live.n; i++)
-                apx = e.tables[map.prime[live.slot[i]]].p < (u64(1) << 58);
+                apx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
             if (red == 7 && (!fp || !kStoreExchange<T, 3, 7>))
                 return hipErrorInvalidValue; // ntt_can_fuse_moddown said no: the caller runs moddown_post itself
             if (fp && (red == 4 || red == 5 || red == 7))

@@ -1,0 +1,285 @@
+// ntt_bounds.hpp -- every "this shortcut cannot overflow" argument of the engine in ONE place, as code.
+//
+// The reference's invariant is that every intermediate of its lazy arithmetic fits a 64-bit word for moduli up to
+// SEAL_MOD_BIT_COUNT_MAX = 61 bits (native/src/seal/util/defines.h:33,52-53; butterflies util/ntt.cpp:245-281). The engine
+// takes shortcuts that are only bit-exact while *their* intermediates fit too (64-bit words for the integer kernels, the
+// 53-bit significand for the FP64 ones). Each shortcut has
+//   * its reduction SCHEDULE (which layer reduces what) -- the kernels in ntt.hip read it from here, nowhere else;
+//   * a worst-case magnitude RECURRENCE that walks that schedule layer by layer;
+//   * an ADMISSION predicate for the launchers, defined as "the recurrence stays below the limit for the largest prime of
+//     that size at every supported ring size" -- a constant derived at compile time, not a hand-written inequality.
+// tests/bounds_check.cpp enumerates prime sizes 20..61 bits x log n 14..16 x every schedule: admitted => peak below the
+// limit, one bit more => the recurrence really overflows (the predicates are tight, not just safe); and a model of the
+// floating-point modular product checks the per-product bound used here against exact integer arithmetic on
+// adversarial operands. (Round 2 shipped a whole-row inverse with the half-row shape's bound for 24 minutes; with this
+// header the same mistake fails a static_assert.)
+//
+// Plain C++17, no HIP: included by ntt.hip / pipeline.cpp and compiled on its own by the CPU test.
+#pragma once
+#include <cstdint>
+
+namespace sealhip
+{
+    namespace bounds
+    {
+        using u64 = unsigned long long;
+        using u128 = unsigned __int128;
+
+        constexpr int kMinHalfLogn = 14, kMaxHalfLogn = 16; // ring sizes served by the single-pass (half-row) kernels
+        constexpr int kMaxPrimeBits = 61;                   // SEAL_MOD_BIT_COUNT_MAX (util/defines.h:33)
+        constexpr u128 kWord = static_cast<u128>(1) << 64;  // integer kernels: every true value must stay below 2^64
+        constexpr long double kFpLimit = 9007199254740992.0L; // 2^53: FP64 kernels hold integers exactly below it
+
+        constexpr u64 max_prime_of_bits(int bits) // the worst case of a predicate "p < 2^bits"
+        {
+            return (bits >= 64 ? ~u64(0) : (u64(1) << bits) - 1);
+        }
+        // ... and where a handful of units matter (the FP64 inverse runs to 8p + O(1) against 2^53): the largest value an
+        // NTT prime of that size can have, p = 1 (mod 2N) (the context refuses anything else: ntt.cpp:37-52)
+        constexpr u64 max_ntt_prime_of_bits(int bits, int logn)
+        {
+            return bits > logn + 1 ? (u64(1) << bits) - (u64(1) << (logn + 1)) + 1 : 0;
+        }
+
+        // =====================================================================================================
+        // 1. Inverse transform, integer, lazy sums (ntt_inv_half_kernel<.., LZ = 1>, butterflies_inv_hs<MODE>).
+        // A shape with T on-chip layers (T = log n - 1 for the half-row form whose top layer is left to a consumer or to
+        // ntt_inv_top_kernel; T = log n for the whole-row form, whose layer T - 1 is BackwardLazyLast with n^-1 folded in).
+        // Layer l reduces its sum with barrett_lazy (MODE 2, -> [0, 2p)) only for l == r1 and l == T - 1; elsewhere the sum
+        // is left as it is (MODE 1). Values entering layer l are below 2^shift(l) * p; the difference operand gets exactly
+        // that bound added so that it stays non-negative. The product is a Shoup product of a 64-bit word: below 2p.
+        constexpr int inv_lazy_r1(int T)
+        {
+            return (T - 1) / 2;
+        }
+        constexpr int inv_lazy_mode(int T, int l)
+        {
+            return (l == inv_lazy_r1(T) || l == T - 1) ? 2 : 1;
+        }
+        constexpr int inv_lazy_shift(int T, int l)
+        {
+            return 1 + (l <= inv_lazy_r1(T) ? l : l - inv_lazy_r1(T) - 1);
+        }
+        // worst-case recurrence: the largest true value any instruction of the schedule forms (sum u + y, difference
+        // u - y + addend), for inputs below 2p. Also checks the schedule's own claim "values entering layer l are below
+        // 2^shift(l) p" -- returns 2^64 (overflow) if the claim were violated, so a wrong shift table cannot pass.
+        constexpr u128 inv_lazy_peak(int T, u64 p)
+        {
+            u128 bound = static_cast<u128>(2) * p; // inputs: what the reference requires of an inverse transform's input
+            u128 peak = bound;
+            for (int l = 0; l < T; l++)
+            {
+                const u128 claimed = static_cast<u128>(p) << inv_lazy_shift(T, l);
+                if (bound > claimed)
+                    return kWord; // schedule inconsistent
+                const u128 sum = 2 * claimed;       // u + y < 2 * claimed
+                const u128 diff = 2 * claimed;      // u - y + claimed < 2 * claimed
+                peak = sum > peak ? sum : peak;
+                peak = diff > peak ? diff : peak;
+                // outputs: the product is below 2p; the sum is reduced to below 2p (MODE 2) or kept (MODE 1)
+                bound = inv_lazy_mode(T, l) == 2 ? static_cast<u128>(2) * p : sum;
+            }
+            return peak;
+        }
+        constexpr int inv_lazy_max_shift(int T)
+        {
+            int m = 0;
+            for (int l = 0; l < T; l++)
+                m = inv_lazy_shift(T, l) > m ? inv_lazy_shift(T, l) : m;
+            return m;
+        }
+        // admission: largest prime size (bits) for which the recurrence stays below 2^64
+        constexpr int inv_lazy_prime_bits(int T)
+        {
+            int bits = 0;
+            for (int b = 1; b <= kMaxPrimeBits; b++)
+                if (inv_lazy_peak(T, max_prime_of_bits(b)) < kWord)
+                    bits = b;
+            return bits;
+        }
+        constexpr bool inv_lazy_admits(int T, u64 p)
+        {
+            return p <= max_prime_of_bits(inv_lazy_prime_bits(T));
+        }
+
+        // =====================================================================================================
+        // 2. Forward transform, integer (ntt_fwd_half_kernel<.., STRICT = 0 / 2>). The fork's forward butterfly
+        // (ForwardLazy, ntt.cpp:245-252) never reduces its first operand: u' = u + v, y' = u - v + 2p with v a lazy Shoup
+        // product below 2p, so values grow by 2p per layer; only the last layer (ForwardLazyLast, :254-261) brings its first
+        // operand below 2p with a Barrett step. On the 60-bit Bsk rows that growth wraps mod 2^64 and the wrapped words
+        // ARE the reference's result: the exact instances have no predicate. Shortcuts that change the
+        // representative (only where the consumer reduces whatever it reads):
+        //   kNttAnyRep   the last layer keeps its first operand unreduced (fin & 2);
+        //   kNttApprox   approximate Shoup quotient: v below 3p, y' = u - v + 3p, growth 3p per layer (STRICT = 2);
+        //   unreduced gathered inputs (key-switch mod-up without the conditional subtraction): inputs below 2p not p.
+        // All log n layers count (the top one is applied on load).
+        constexpr u128 fwd_int_peak(int logn, u64 p, int in_mult, bool apx, bool skip_last_barrett)
+        {
+            const u128 g = static_cast<u128>(apx ? 3 : 2) * p; // growth per layer = bound of the product
+            u128 bound = static_cast<u128>(in_mult) * p, peak = bound;
+            for (int l = 0; l < logn; l++)
+            {
+                u128 u = bound;
+                if (l == logn - 1 && !skip_last_barrett)
+                    u = static_cast<u128>(2) * p; // barrett_lazy of the first operand
+                const u128 out = u + g;           // u + v < u + g;  u - v + g <= u + g
+                peak = out > peak ? out : peak;
+                bound = out;
+            }
+            return peak;
+        }
+        // one predicate for both shortcuts together with unreduced inputs (the key-switch digit launches use all three)
+        constexpr int fwd_lazy_prime_bits()
+        {
+            int bits = 0;
+            for (int b = 1; b <= kMaxPrimeBits; b++)
+            {
+                bool ok = true;
+                for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+                    ok = ok && fwd_int_peak(logn, max_prime_of_bits(b), 2, true, true) < kWord;
+                if (ok)
+                    bits = b;
+            }
+            return bits;
+        }
+        constexpr int kFwdLazyPrimeBits = fwd_lazy_prime_bits();
+        static_assert(kFwdLazyPrimeBits == 58, "kNttAnyRep / kNttApprox / unreduced mod-up: primes below 2^58");
+        constexpr bool fwd_lazy_admits(u64 p) // kNttAnyRep, kNttApprox, mod-up without the conditional subtraction
+        {
+            return p <= max_prime_of_bits(kFwdLazyPrimeBits);
+        }
+        // largest output of an approximate-quotient launch, in units of p (documentation + test): 50 with kNttAnyRep
+        constexpr int fwd_apx_output_mult(int logn, bool anyrep)
+        {
+            return anyrep ? 2 + 3 * logn : 5;
+        }
+
+        // =====================================================================================================
+        // 3. Tensor product formed by the inverse transform's load (dyadic_redc in ntt.hip): t = (sum of NP products) *
+        // 2^-64 mod p as ONE Montgomery reduction, t < sum / 2^64 + p. Carry-free accumulation needs operands below 2^61
+        // (upper halves below 2^29: the middle accumulator holds 2 NP products below 2^61 each, NP <= 2). For the inverse
+        // transform's inputs t must be below 2p: sum / 2^64 <= p.
+        constexpr bool tensor_redc_ok(u64 p, int operand_mult, int np)
+        {
+            const u128 ob = static_cast<u128>(operand_mult) * p; // operands below operand_mult * p, i.e. at most ob - 1
+            if (ob > (static_cast<u128>(1) << 61) || np > 2)
+                return false;
+            // sum <= np (ob - 1)^2 < 2^123; t < sum / 2^64 + p, so t < 2p as soon as sum <= p 2^64 (< 2^125): exact in u128
+            return (ob - 1) * (ob - 1) * np <= static_cast<u128>(p) * kWord;
+        }
+        // operands below 4p (what the lazy forward transform stores) for primes below 2^59 ...
+        constexpr int tensor_prime_bits(int operand_mult)
+        {
+            int bits = 0;
+            for (int b = 1; b <= kMaxPrimeBits; b++)
+                if (tensor_redc_ok(max_prime_of_bits(b), operand_mult, 2))
+                    bits = b;
+            return bits;
+        }
+        constexpr int kTensorPrimeBits4p = tensor_prime_bits(4);
+        constexpr int kTensorPrimeBits2p = tensor_prime_bits(2);
+        static_assert(kTensorPrimeBits4p == 59, "fused tensor product on [0, 4p) operands: ciphertext primes below 2^59");
+        static_assert(kTensorPrimeBits2p == 60, "... on [0, 2p) operands (kNttReduceOut rows): the 60-bit Bsk primes");
+        constexpr bool tensor_admits_4p(u64 p)
+        {
+            return p <= max_prime_of_bits(kTensorPrimeBits4p);
+        }
+        constexpr bool tensor_admits_2p(u64 p)
+        {
+            return p <= max_prime_of_bits(kTensorPrimeBits2p);
+        }
+
+        // =====================================================================================================
+        // 4. FP64 instances (primes below 2^50; devmath.hpp fp_mulmod / fp_reduce). With u = 2^-53 the unit roundoff:
+        //   h = fl(y w), l = y w - h exactly (|l| <= u |y w|); t = fl(h * fl(1/p)) = (h / p)(1 + e), |e| <= 2u + u^2;
+        //   q = rint(t) (|q - t| <= 1/2; for |t| >= 2^52 t is an integer already); r = (h - q p) + l.
+        //   |h - q p| <= |h| |e| + p / 2 and |l| <= u |h|(1 + u), so
+        //       |r| <= p / 2 + 3 u |y| w (1 + 2^-50)  <=  (1/2 + 3 * 2^-53 |y|) p        (+ the tiny slack below)
+        // -- NOT (1/2 + 2^-52 |y|) p as round 2 assumed: the exact rounding error l and the rounding of h * (1/p) add up
+        // (p = 1125899886395393, y = 3857024279003347, w = 1125899289087767 gives |r| / p = 1.4006 against 1.3564).
+        // h - q p and the final sum are integers: exact as long as they stay below 2^53 in magnitude.
+        // A forward layer therefore takes a bound B (on every value) to B + (1/2 + 3 * 2^-53 B) p; with p <= U = 2^50 that
+        // is 1.375 B + U / 2: from a reduction (B = U / 2) FIVE layers stay below 8 U = 2^53 (1.19, 2.13, 3.43, 5.22,
+        // 7.68), the sixth does not (11.06). Round 2's schedule had two spans of six layers.
+        constexpr long double kFpSlack = 1.0L + 0x1p-40L;
+        constexpr long double fp_mul_bound(long double y, long double p) // |fp_mulmod(y, w, p)| for |y| <= y, 0 <= w < p
+        {
+            return 0.5L * p + 3.0L * 0x1p-53L * y * p * kFpSlack;
+        }
+        constexpr long double fp_reduce_bound(long double x, long double p) // |fp_reduce(x)| for |x| <= x < 2^53
+        {
+            return 0.5L * p + x * 0x1p-51L + 1.0L;
+        }
+        // Forward schedule (ntt_fwd_half_kernel<.., STRICT = 3>): the top layer on raw inputs (below in_bound: 2^52 for
+        // gathered words, p for residues), all values reduced; then the T = log n - 1 on-chip layers i = 0 .. T - 1
+        // (rounds 1-3: four each, final round: the rest), all 32 values of a lane reduced BEFORE layers 5 and 10; the store
+        // canonicalises (a reduction of values below 2^53).
+        constexpr bool fp_fwd_reduce_before_layer(int i)
+        {
+            return i == 5 || i == 10;
+        }
+        constexpr long double fp_fwd_peak(int logn, long double p, long double in_bound)
+        {
+            long double b = in_bound, peak = in_bound;
+            // top layer: u + r, u - r with r = fp_mulmod(y, w)
+            b = b + fp_mul_bound(b, p);
+            peak = b > peak ? b : peak;
+            b = fp_reduce_bound(b, p);
+            for (int i = 0; i < logn - 1; i++)
+            {
+                if (fp_fwd_reduce_before_layer(i))
+                    b = fp_reduce_bound(b, p);
+                b = b + fp_mul_bound(b, p);
+                peak = b > peak ? b : peak;
+            }
+            return peak; // (the canonicalisation reads values up to `peak`)
+        }
+        // Inverse schedule (ntt_inv_half_kernel<.., LZ = 2>): Gentleman-Sande layers l = 0 .. T - 1 on inputs below 2p,
+        // u' = u + y (the bound doubles), y' = fp_mulmod(u - y, w); both outputs reduced after layers l % 4 == 1 except the
+        // last on-chip layer (whose outputs the store, or the whole-row form's top layer, takes as they are).
+        constexpr bool fp_inv_reduce_after_layer(int T, int l)
+        {
+            return l % 4 == 1 && l != T - 1;
+        }
+        constexpr long double fp_inv_peak(int T, long double p)
+        {
+            long double b = 2.0L * p, peak = b;
+            for (int l = 0; l < T; l++)
+            {
+                const long double s = 2.0L * b; // |u + y|, |u - y| <= 2b
+                peak = s > peak ? s : peak;
+                const long double r = fp_mul_bound(s, p);
+                b = s > r ? s : r;
+                if (fp_inv_reduce_after_layer(T, l))
+                    b = fp_reduce_bound(b, p);
+            }
+            return peak;
+        }
+        constexpr int fp_prime_bits()
+        {
+            int bits = 0;
+            for (int b = kMaxHalfLogn + 2; b <= 52; b++)
+            {
+                bool ok = true;
+                for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+                {
+                    const long double p = static_cast<long double>(max_ntt_prime_of_bits(b, logn));
+                    ok = ok && fp_fwd_peak(logn, p, 0x1p52L) < kFpLimit;
+                    ok = ok && fp_inv_peak(logn - 1, p) < kFpLimit; // half-row form
+                    if (logn <= 15)
+                        ok = ok && fp_inv_peak(logn, p) < kFpLimit; // whole-row form (N = 2^14, 2^15)
+                }
+                if (ok)
+                    bits = b;
+            }
+            return bits;
+        }
+        constexpr int kFpPrimeBits = fp_prime_bits();
+        static_assert(kFpPrimeBits == 50, "FP64 instances: primes below 2^50 (and raw inputs below 2^52)");
+        constexpr u64 kFpInputBound = u64(1) << 52; // raw words a forward FP64 launch may be handed (fp_from_u64's range too)
+        constexpr bool fp_admits(u64 p)
+        {
+            return p <= max_prime_of_bits(kFpPrimeBits);
+        }
+    } // namespace bounds
+} // namespace sealhip

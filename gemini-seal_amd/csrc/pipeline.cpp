@@ -170,7 +170,7 @@ namespace sealhip
                 u64 pmax = 0;
                 for (int r = 0; r < rows; r++)
                     pmax = std::max(pmax, e.key_moduli[h.row_prime[r]]);
-                if (pmax < (u64(1) << 58))
+                if (bounds::fwd_lazy_admits(pmax)) // (inputs below 2p: the case the recurrence in ntt_bounds.hpp walks)
                     modup_mode = 0;
             }
             if (!gather)
@@ -230,15 +230,17 @@ namespace sealhip
                       "moddown_bfv");
                 continue;
             }
-            u64 p_special = 0, p_min = ~u64(0);
-            if (ckks && e.nsp == 1)
+            const u64 p_special = (ckks && e.nsp == 1) ? e.key_moduli[h.row_prime[k]] : 0;
+            // The gathered transform is handed the integer P - r < P instead of the residue (-(s mod P)) mod q_i: the same
+            // word wherever P <= q_i; where q_i < P < 2 q_i it is an unreduced input below 2 q_i, which the lazy forward
+            // transform takes as it is only while nothing can wrap (ntt_bounds.hpp section 2, inputs below 2p).
+            bool fold_ok = ckks && e.nsp == 1 && ntt_can_gather(e) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
+            for (int r = 0; fold_ok && r < k; r++)
             {
-                p_special = e.key_moduli[h.row_prime[k]];
-                for (int r = 0; r < k; r++)
-                    p_min = std::min(p_min, e.key_moduli[h.row_prime[r]]);
+                const u64 q = e.key_moduli[h.row_prime[r]];
+                fold_ok = p_special <= q || (p_special < 2 * q && bounds::fwd_lazy_admits(q));
             }
-            const bool fold_pre = ckks && e.nsp == 1 && ntt_can_gather(e) && p_special < 2 * p_min &&
-                                  p_special < (u64(1) << 58) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
+            const bool fold_pre = fold_ok;
             // the gathered transform below reads the special row as pairs (c, c + N/2): it can apply the top inverse layer
             const bool fold_top = fold_pre && ntt_can_defer_top(e, k);
             // ... and, in its floating-point form, finish the mod-down as it stores (reduce mode 7): temp is never written
@@ -366,7 +368,7 @@ namespace sealhip
             bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
                                 std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
             for (int r = 0; r < k; r++) // its Montgomery reduction lands below 2p for ciphertext primes under 2^59
-                fused_tensor = fused_tensor && e.key_moduli[r] < (u64(1) << 59);
+                fused_tensor = fused_tensor && bounds::tensor_admits_4p(e.key_moduli[r]);
             // the lift applies the forward transform's top layer to the Bsk rows it writes (kNttTopDone below)
             const bool lift_top = fused_tensor && bfv_lift_can_apply_top(e, h);
             for (int s = 0; s < sin; s++)

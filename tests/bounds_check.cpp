@@ -1,0 +1,339 @@
+// bounds_check.cpp -- CPU test of gemini-seal_amd/csrc/ntt_bounds.hpp (built and run by tests/test_host.py).
+// 1. Enumerates prime sizes 20..61 bits x log n 14..16 x every shortcut schedule: admitted => the worst-case recurrence
+//    stays below 2^64 (integer) / 2^53 (FP64); rejected by one bit => the recurrence really overflows (tight).
+// 2. Regression for the round-2 bug (whole-row inverse admitted with the half-row shape's bound): fails here.
+// 3. Checks the recurrences themselves against executions: a bit-level model of the FP64 modular product (same IEEE
+//    operations as devmath.hpp: multiply, fma, rint) on adversarial operands against exact __int128 arithmetic, and whole
+//    transforms run through the schedules with every intermediate magnitude tracked -- none may exceed what the
+//    recurrence predicts, and every value must stay congruent to an exact integer shadow.
+// Invariant restated: native/src/seal/util/defines.h:52-53 (lazy arithmetic fits the word), butterflies util/ntt.cpp:245-281.
+#include <cfenv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../gemini-seal_amd/csrc/ntt_bounds.hpp"
+
+using namespace sealhip::bounds;
+typedef __int128 i128;
+
+static int failures = 0;
+#define CHECK(cond, ...)                       \
+    do                                         \
+    {                                          \
+        if (!(cond))                           \
+        {                                      \
+            failures++;                        \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);          \
+            std::printf("\n");                 \
+        }                                      \
+    } while (0)
+
+// ---- the FP64 modular product exactly as devmath.hpp computes it (IEEE double, round to nearest even)
+static double fp_reduce_model(double x, double p, double pinv)
+{
+    return std::fma(-std::nearbyint(x * pinv), p, x);
+}
+static double fp_mulmod_model(double y, double w, double p, double pinv)
+{
+    const double h = y * w;
+    const double l = std::fma(y, w, -h);
+    const double q = std::nearbyint(h * pinv);
+    return std::fma(-q, p, h) + l;
+}
+static i128 mod_i128(i128 a, i128 p)
+{
+    i128 r = a % p;
+    return r < 0 ? r + p : r;
+}
+
+static void enumerate_predicates()
+{
+    int checked = 0;
+    // 1a. inverse, integer lazy sums: every shape the launchers use (T = log n - 1 half-row, T = log n whole-row)
+    for (int T = kMinHalfLogn - 1; T <= kMaxHalfLogn; T++)
+        for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+        {
+            const u64 p = max_prime_of_bits(bits);
+            const bool adm = inv_lazy_admits(T, p);
+            const u128 peak = inv_lazy_peak(T, p);
+            if (adm)
+                CHECK(peak < kWord, "inverse lazy T=%d bits=%d admitted but the recurrence overflows", T, bits);
+            else
+                CHECK(peak >= kWord, "inverse lazy T=%d bits=%d rejected although the recurrence fits (predicate not tight)", T, bits);
+            CHECK(inv_lazy_prime_bits(T) == 63 - inv_lazy_max_shift(T), "inverse lazy T=%d: closed form 63 - max_shift", T);
+            checked++;
+        }
+    // 1b. forward integer shortcuts (kNttAnyRep, kNttApprox, unreduced inputs), every combination that is launched
+    for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+        for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+        {
+            const u64 p = max_prime_of_bits(bits);
+            for (int in_mult = 1; in_mult <= 2; in_mult++)
+                for (int apx = 0; apx <= 1; apx++)
+                    for (int skip = 0; skip <= 1; skip++)
+                    {
+                        if (!apx && !skip && in_mult == 1)
+                            continue; // the reference's own sequence: no predicate (its wrap-around is the result)
+                        const u128 peak = fwd_int_peak(logn, p, in_mult, apx, skip);
+                        if (fwd_lazy_admits(p))
+                            CHECK(peak < kWord, "forward logn=%d bits=%d in<%dp apx=%d skip=%d admitted but overflows", logn, bits,
+                                  in_mult, apx, skip);
+                        checked++;
+                    }
+        }
+    {
+        // tight: one bit above the bound the full combination overflows at the largest ring
+        const u64 p = max_prime_of_bits(kFwdLazyPrimeBits + 1);
+        CHECK(fwd_int_peak(kMaxHalfLogn, p, 2, true, true) >= kWord, "forward lazy predicate is not tight");
+        CHECK(fwd_int_peak(kMaxHalfLogn, max_prime_of_bits(kFwdLazyPrimeBits), 2, true, true) / max_prime_of_bits(kFwdLazyPrimeBits) <
+                  static_cast<u128>(fwd_apx_output_mult(kMaxHalfLogn, true)) + 1,
+              "documented output bound 50p");
+    }
+    // 1c. fused tensor product
+    for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+    {
+        const u64 p = max_prime_of_bits(bits);
+        CHECK(tensor_admits_4p(p) == tensor_redc_ok(p, 4, 2), "tensor 4p bits=%d", bits);
+        CHECK(tensor_admits_2p(p) == tensor_redc_ok(p, 2, 2), "tensor 2p bits=%d", bits);
+        if (tensor_admits_4p(p))
+            CHECK(tensor_redc_ok(p, 4, 1), "one product must fit where two do");
+        checked += 2;
+    }
+    // 1d. FP64 schedules
+    for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+        for (int bits = 20; bits <= 52; bits++)
+        {
+            const long double p = static_cast<long double>(max_ntt_prime_of_bits(bits, logn));
+            const long double f = fp_fwd_peak(logn, p, 0x1p52L), ih = fp_inv_peak(logn - 1, p), iw = fp_inv_peak(logn, p);
+            if (fp_admits(max_ntt_prime_of_bits(bits, logn)))
+            {
+                CHECK(f < kFpLimit, "FP64 forward logn=%d bits=%d admitted but reaches 2^53", logn, bits);
+                CHECK(ih < kFpLimit, "FP64 inverse (half) logn=%d bits=%d admitted but reaches 2^53", logn, bits);
+                if (logn <= 15)
+                    CHECK(iw < kFpLimit, "FP64 inverse (whole) logn=%d bits=%d admitted but reaches 2^53", logn, bits);
+            }
+            else if (bits == kFpPrimeBits + 1)
+                CHECK(f >= kFpLimit && ih >= kFpLimit, "FP64 predicate not tight at %d bits", bits);
+            checked += 3;
+        }
+    // the round-2 schedule (reductions before layers 6 and 12: spans of six) does NOT pass the sound recurrence
+    {
+        const long double p = static_cast<long double>(max_ntt_prime_of_bits(50, 15));
+        long double b = fp_reduce_bound(0x1p52L + fp_mul_bound(0x1p52L, p), p), peak = 0;
+        for (int i = 0; i < 14; i++)
+        {
+            if (i == 6 || i == 12)
+                b = fp_reduce_bound(b, p);
+            b += fp_mul_bound(b, p);
+            peak = b > peak ? b : peak;
+        }
+        CHECK(peak >= kFpLimit, "the six-layer spans of round 2 should fail the sound bound (peak %.3Lf U)", peak / 0x1p50L);
+    }
+    std::printf("enumerated %d (schedule, ring, prime size) cases\n", checked);
+}
+
+static void regression_whole_row()
+{
+    // round 2, commit 5a53534: the whole-row inverse of a ring of 2^15 (T = 15 on-chip layers) was admitted with the half-row
+    // shape's bound (T = 14). With the predicate taken from the launched instance's layer count this cannot happen; the
+    // mistaken pairing itself must be detectably unsafe:
+    bool unsafe = false;
+    for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+    {
+        const u64 p = max_prime_of_bits(bits);
+        if (inv_lazy_admits(14, p) && inv_lazy_peak(15, p) >= kWord)
+            unsafe = true;
+    }
+    CHECK(unsafe, "half-row predicate applied to the whole-row shape should be caught (56-bit primes at N = 2^15)");
+    CHECK(inv_lazy_prime_bits(14) == 56 && inv_lazy_prime_bits(15) == 55, "bounds of the two shapes");
+}
+
+static void fp_product_model()
+{
+    // the advisor's counterexample to the round-2 bound (0.5 + 2^-52 |y|) p
+    {
+        const double p = 1125899886395393.0, y = 3857024279003347.0, w = 1125899289087767.0;
+        const double r = fp_mulmod_model(y, w, p, 1.0 / p);
+        const long double ratio = fabsl(static_cast<long double>(r)) / p;
+        CHECK(ratio > 0.5L + 0x1p-52L * y, "counterexample should exceed the old bound (ratio %.4Lf)", ratio);
+        CHECK(fabsl(static_cast<long double>(r)) <= fp_mul_bound(y, p), "counterexample within the sound bound");
+        CHECK(mod_i128(static_cast<i128>(r), static_cast<i128>(p)) ==
+                  mod_i128(static_cast<i128>(y) * static_cast<i128>(w), static_cast<i128>(p)),
+              "product model is exact");
+    }
+    std::mt19937_64 rng(12345);
+    long double worst = 0;
+    const u64 primes[] = { 1125899886395393ull, 1125899903107073ull, 1125899906826241ull, max_ntt_prime_of_bits(50, 14),
+                           max_ntt_prime_of_bits(49, 16), 562949953216513ull, 1099511480321ull };
+    for (u64 pu : primes)
+    {
+        const double p = static_cast<double>(pu), pinv = 1.0 / p;
+        for (int it = 0; it < 400000; it++)
+        {
+            // magnitudes up to the 2^53 limit, concentrated near the top; w near p and anywhere
+            const int yb = 40 + static_cast<int>(rng() % 13);
+            u64 ym = (rng() >> (64 - yb)) | (u64(1) << (yb - 1));
+            if (it % 7 == 0)
+                ym = (u64(1) << 53) - 1 - (rng() & 0xFFFF);
+            const double y = (rng() & 1) ? static_cast<double>(ym) : -static_cast<double>(ym);
+            u64 wu = rng() % pu;
+            if (it % 5 == 0)
+                wu = pu - 1 - (rng() & 0xFFFFF) % pu;
+            const double w = static_cast<double>(wu);
+            const double r = fp_mulmod_model(y, w, p, pinv);
+            const long double ar = fabsl(static_cast<long double>(r)), bd = fp_mul_bound(fabs(y), p);
+            if (ar > bd)
+            {
+                CHECK(false, "|r| = %.1Lf exceeds the bound %.1Lf (p=%llu y=%.0f w=%llu)", ar, bd, pu, y, wu);
+                return;
+            }
+            const long double excess = (ar / p - 0.5L) / (fabsl(static_cast<long double>(y)) * 0x1p-53L);
+            worst = excess > worst ? excess : worst;
+            if (ar < 0x1p53L)
+            {
+                const i128 want = mod_i128(static_cast<i128>(static_cast<long long>(y)) * static_cast<i128>(wu), pu);
+                if (mod_i128(static_cast<i128>(static_cast<long long>(r)), pu) != want)
+                {
+                    CHECK(false, "product not exact (p=%llu y=%.0f w=%llu)", pu, y, wu);
+                    return;
+                }
+            }
+        }
+    }
+    std::printf("FP64 product model: worst observed (|r|/p - 1/2) / (2^-53 |y|) = %.3Lf (bound 3)\n", worst);
+    CHECK(worst <= 3.0L, "observed coefficient above 3");
+    CHECK(worst > 1.0L, "the search should find operands beyond round 2's coefficient 2 * 2^-53 ... (found %.3Lf)", worst);
+}
+
+// ---- whole forward transform through the FP64 schedule, magnitudes tracked, exact shadow mod p.
+// The modulus need not be prime for this (no inverse is taken): the butterflies are sums and modular products.
+static void fp_forward_execution(int logn, u64 pu, int pattern)
+{
+    const int n = 1 << logn;
+    const double p = static_cast<double>(pu), pinv = 1.0 / p;
+    std::mt19937_64 rng(logn * 1000 + pattern);
+    std::vector<double> x(n);
+    std::vector<u64> shadow(n);
+    for (int i = 0; i < n; i++)
+    {
+        u64 v;
+        if (pattern == 0)
+            v = (u64(1) << 52) - 1; // the largest raw word a gathered launch may see
+        else if (pattern == 1)
+            v = (i & 1) ? (u64(1) << 52) - 1 : 0;
+        else if (pattern == 2)
+            v = pu - 1;
+        else
+            v = rng() & ((u64(1) << 52) - 1);
+        x[i] = static_cast<double>(v);
+        shadow[i] = v % pu;
+    }
+    long double peak = 0;
+    auto layer = [&](int gap, bool reduce_first) {
+        if (reduce_first)
+            for (int i = 0; i < n; i++)
+                x[i] = fp_reduce_model(x[i], p, pinv);
+        for (int blk = 0, t = 0; blk < n; blk += 2 * gap, t++)
+        {
+            // adversarial "twiddles": near p for one half of the blocks, random for the rest
+            const u64 wu = (t & 1) ? pu - 1 - (rng() & 0xFFFF) : rng() % pu;
+            const double w = static_cast<double>(wu);
+            for (int j = blk; j < blk + gap; j++)
+            {
+                const double u = x[j], y = x[j + gap];
+                const long double ay = fabsl(static_cast<long double>(y));
+                peak = ay > peak ? ay : peak;
+                const double r = fp_mulmod_model(y, w, p, pinv);
+                x[j] = u + r;
+                x[j + gap] = u - r;
+                const u64 sv = static_cast<u64>(static_cast<u128>(shadow[j + gap]) * wu % pu);
+                const u64 su = shadow[j];
+                shadow[j] = (su + sv) % pu;
+                shadow[j + gap] = (su + pu - sv) % pu;
+                const long double a0 = fabsl(static_cast<long double>(x[j])), a1 = fabsl(static_cast<long double>(x[j + gap]));
+                peak = a0 > peak ? a0 : peak;
+                peak = a1 > peak ? a1 : peak;
+            }
+        }
+    };
+    layer(n >> 1, false); // top layer on raw inputs
+    for (int i = 0; i < n; i++)
+        x[i] = fp_reduce_model(x[i], p, pinv);
+    for (int i = 0; i < logn - 1; i++)
+        layer(n >> (i + 2), fp_fwd_reduce_before_layer(i));
+    const long double predicted = fp_fwd_peak(logn, static_cast<long double>(pu), 0x1p52L);
+    CHECK(peak < kFpLimit, "FP64 forward execution logn=%d pattern=%d reached 2^53 (%.3Lf U)", logn, pattern, peak / 0x1p50L);
+    CHECK(peak <= predicted, "execution peak %.4Lf U above the recurrence %.4Lf U", peak / 0x1p50L, predicted / 0x1p50L);
+    int bad = 0;
+    for (int i = 0; i < n; i++)
+    {
+        double r = fp_reduce_model(x[i], p, pinv);
+        if (r < 0)
+            r += p;
+        bad += static_cast<u64>(r) != shadow[i];
+    }
+    CHECK(bad == 0, "FP64 forward execution logn=%d pattern=%d: %d words differ from the exact shadow", logn, pattern, bad);
+}
+
+// ---- inverse integer lazy-sum schedule executed on 64-bit words with a 128-bit shadow of every true value
+static void inv_lazy_execution(int T, u64 p)
+{
+    const int n = 1 << T;
+    std::mt19937_64 rng(T);
+    std::vector<u64> x(n);
+    for (int i = 0; i < n; i++)
+        x[i] = (i % 3 == 0) ? 2 * p - 1 : rng() % (2 * p);
+    u128 peak = 0;
+    bool wrapped = false;
+    for (int l = 0; l < T; l++)
+    {
+        const int gap = 1 << l;
+        const u64 addend = p << inv_lazy_shift(T, l);
+        for (int blk = 0; blk < n; blk += 2 * gap)
+        {
+            const u64 w = rng() % p;
+            const u64 ws = static_cast<u64>((static_cast<u128>(w) << 64) / p);
+            for (int j = blk; j < blk + gap; j++)
+            {
+                const u64 u = x[j], y = x[j + gap];
+                const u128 sum = static_cast<u128>(u) + y;
+                const i128 diff = static_cast<i128>(u) - static_cast<i128>(y) + static_cast<i128>(addend);
+                wrapped = wrapped || sum >= kWord || diff < 0 || static_cast<u128>(diff) >= kWord;
+                peak = sum > peak ? sum : peak;
+                peak = static_cast<u128>(diff) > peak ? static_cast<u128>(diff) : peak;
+                u64 s = static_cast<u64>(sum);
+                if (inv_lazy_mode(T, l) == 2) // barrett_lazy: x - floor(x * floor(2^64 / p) / 2^64) * p
+                    s = s - static_cast<u64>((static_cast<u128>(s) * static_cast<u64>(kWord / p)) >> 64) * p;
+                const u64 d = static_cast<u64>(diff);
+                const u64 q = static_cast<u64>((static_cast<u128>(d) * ws) >> 64);
+                x[j] = s;
+                x[j + gap] = d * w - q * p; // lazy Shoup product, below 2p
+            }
+        }
+    }
+    CHECK(!wrapped, "inverse lazy execution T=%d p=%llu wrapped", T, p);
+    CHECK(peak <= inv_lazy_peak(T, p), "inverse lazy execution T=%d above the recurrence", T);
+    bool below_2p = true;
+    for (int i = 0; i < n; i++)
+        below_2p = below_2p && x[i] < 2 * p;
+    CHECK(below_2p, "inverse lazy execution T=%d: outputs must be below 2p", T);
+}
+
+int main()
+{
+    std::fesetround(FE_TONEAREST);
+    enumerate_predicates();
+    regression_whole_row();
+    fp_product_model();
+    for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+        for (int pattern = 0; pattern < 4; pattern++)
+            fp_forward_execution(logn, max_ntt_prime_of_bits(kFpPrimeBits, logn), pattern);
+    for (int T = kMinHalfLogn - 1; T <= kMaxHalfLogn; T++)
+        inv_lazy_execution(T, max_prime_of_bits(inv_lazy_prime_bits(T)));
+    std::printf(failures ? "bounds_check: %d FAILURES\n" : "bounds_check: OK\n", failures);
+    return failures ? 1 : 0;
+}

@@ -823,6 +823,95 @@ def test_f1_transparent_mod63_and_native_rotate(sealhip):
         ev.rotate_vector_native(ctx.upload(src), k, count, 16, keys)  # power of two without a key
 
 
+@pytest.mark.parametrize("scheme,logn,bits", [
+    (1, 15, 55), (1, 15, 56), (1, 15, 58), (1, 15, 59), (1, 14, 56), (1, 14, 57), (1, 16, 55), (1, 16, 56),
+    (2, 15, 55), (2, 15, 56), (2, 15, 58), (2, 14, 56), (2, 16, 55)])
+def test_shortcut_boundaries_largest_admitted_primes(sealhip, scheme, logn, bits):
+    """csrc/ntt_bounds.hpp admits each shortcut up to a prime size (lazy-sum inverse: 2^55 whole-row / 2^56 half-row at
+    N = 2^15, 2^56 / 2^56 at 2^14, 2^55 at 2^16; kNttAnyRep, kNttApprox and the unreduced mod-up: 2^58; fused tensor
+    product: 2^59). The recurrences are proved on the CPU (tests/bounds_check.cpp); this drives the real pipelines with the
+    LARGEST primes below each bound and one size above it, and the inputs that maximise growth (all p-1, alternating,
+    half, plus random), bit-exact against the oracle: multiply + relinearize (BFV) / rotate + multiply + relinearize +
+    rescale (CKKS), and the standalone inverse on lazy-range inputs up to 2p-1.
+    Reference: evaluator.cpp:274-527,772-827,2259-2368, util/ntt.cpp:245-404."""
+    n, nk, t = 1 << logn, 4, 786433
+    kmods = sorted(O.get_primes(n, bits, nk))  # the nk largest primes below 2^bits
+    assert max(kmods) < (1 << bits) and min(kmods) > (1 << bits) - (1 << (bits - 8))
+    k = nk - 1
+    ctx = sealhip.Context(scheme, logn, kmods, 1, t if scheme == 1 else 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(scheme, logn, kmods, nsp=1, t=t if scheme == 1 else 0)
+    rng = np.random.default_rng(bits * 100 + logn)
+
+    def pattern(kind, mods, polys):
+        x = np.zeros((polys, len(mods), n), dtype=np.uint64)
+        for i, p in enumerate(mods):
+            if kind == 0:
+                x[:, i, :] = p - 1
+            elif kind == 1:
+                x[:, i, ::2] = p - 1
+            elif kind == 2:
+                x[:, i, n // 2:] = p - 1
+            else:
+                x[:, i] = rng.integers(0, p, (polys, n), dtype=np.uint64)
+        return x
+
+    key = np.stack([pattern(j % 4, kmods, 2) if j < 2 else pattern(3, kmods, 2) for j in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    a = np.stack([pattern(kind, kmods[:k], 2) for kind in (0, 1, 2, 3)])
+    b = np.stack([pattern(kind, kmods[:k], 2) for kind in (0, 0, 3, 3)])
+    count = a.shape[0]
+    mul = L.ref_bfv_multiply if scheme == 1 else L.ref_ckks_multiply
+    out = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, out)
+    exp = np.zeros((count, 3, k, n), dtype=np.uint64)
+    for c in range(count):
+        assert mul(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(b[c]), 2, O.ptr(exp[c])) == 0
+    assert np.array_equal(out.download(exp.shape), exp), "multiply"
+    ev.relinearize_inplace(out, 3, k, count, [dkey])
+    for c in range(count):
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp[c]), 3, keys) == 0
+    assert np.array_equal(out.download(exp.shape)[:, :2], exp[:, :2]), "relinearize"
+    if scheme == 2:
+        elt = ctx.galois_elt_from_step(3)
+        g = ctx.upload(a)
+        ev.apply_galois_inplace(g, k, count, elt, dkey)
+        expg = a.copy()
+        for c in range(count):
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(expg[c]), elt, O.ptr(key)) == 0
+        assert np.array_equal(g.download(expg.shape), expg), "apply_galois"
+        c2 = np.ascontiguousarray(exp[:, :2])
+        o = ctx.alloc(count * 2 * (k - 1) * n)
+        ev.rescale_to_next(ctx.upload(c2), 2, k, count, o)
+        exp_ms = np.zeros((count, 2, k - 1, n), dtype=np.uint64)
+        for c in range(count):
+            assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(c2[c]), 2, O.ptr(exp_ms[c])) == 0
+        assert np.array_equal(o.download(exp_ms.shape), exp_ms), "rescale"
+    # standalone transforms: canonical forward on residues, canonical inverse on the lazy range [0, 2p)
+    tabs = [O.Tables(logn, p) for p in kmods[:k]]
+    x = np.concatenate([pattern(kind, kmods[:k], 1) for kind in (0, 1, 2, 3)])
+    for lazy_in in (False, True):
+        y = x.copy()
+        if lazy_in:
+            for i, p in enumerate(kmods[:k]):
+                y[:, i, :] += np.uint64(p)  # every word in [p, 2p): all 2p-1 for the first pattern
+        buf = ctx.upload(y)
+        ctx.inverse_ntt_negacyclic_harvey(buf, x.shape[0], k)
+        e = x.copy()
+        for c in range(x.shape[0]):
+            for i in range(k):
+                L.ref_ntt_inverse(O.ptr(e[c, i]), C.byref(tabs[i].t))
+        assert np.array_equal(buf.download(x.shape), e), "inverse lazy_in=%s" % lazy_in
+    buf = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey(buf, x.shape[0], k)
+    e = x.copy()
+    for c in range(x.shape[0]):
+        for i in range(k):
+            L.ref_ntt_forward(O.ptr(e[c, i]), C.byref(tabs[i].t), 0)
+    assert np.array_equal(buf.download(x.shape), e), "forward"
+
+
 @pytest.mark.parametrize("k_first", [3, 7, 9])
 def test_bfv_multiply_extreme_values_59bit(sealhip, k_first):
     """Largest user primes the fork admits (59 bits, util/defines.h:40) and operands that are all p-1 / all zero /

@@ -180,6 +180,22 @@ def test_cpp_host_adapter_compiles_and_links(tmp_path):
     assert out.returncode == 0 and "host-only context ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_shortcut_bounds_are_proved_not_sampled(tmp_path):
+    """csrc/ntt_bounds.hpp: every admission predicate of the launchers (lazy-sum inverse per shape, kNttAnyRep / kNttApprox /
+    unreduced mod-up, fused tensor product, FP64 forward and inverse schedules) against its worst-case magnitude recurrence:
+    prime sizes 20..61 bits x log n 14..16 x every schedule, admitted => below 2^64 / 2^53, one bit more => overflow; the
+    round-2 whole-row bug (half-row bound on the larger shape) and round 2's six-layer FP64 spans both fail it; the FP64
+    product bound and the recurrences are checked against bit-level executions (tests/bounds_check.cpp).
+    Invariant: native/src/seal/util/defines.h:52-53, butterflies util/ntt.cpp:245-281."""
+    import subprocess
+
+    exe = str(tmp_path / "bounds_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "bounds_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bounds_check: OK" in out.stdout, out.stdout + out.stderr
+
+
 # ---------------------------------------------------------------- SURVEY 8(f3): ciphertext wire format (host parsing, no GPU)
 def _wire():
     import importlib.util
