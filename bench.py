@@ -6,7 +6,12 @@ A step = Evaluator::multiply + Evaluator::relinearize over one batch of independ
 ciphertexts that are already resident in HBM (config 3 of BASELINE.json: N=2^15, {55}x8 primes, k=7,
 |Bsk|=8, 7 key digits, t=786433, PARITY mode = bit-exact with the reference).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config 3|4|5] [--force-dist]
+
+--config selects the BASELINE.json line (default 3, the one the metric is quoted on; the driver's command is
+unchanged): 4 = CKKS N=2^15, 12 primes, Evaluator::rotate_vector over the rank's share of the 8192 ciphertexts with the
+replicated Galois key (evaluator.h:1201-1211); 5 = BFV N=2^16, 16 primes, multiply + relinearize + mod_switch_to_next
+(evaluator.cpp:996-1036). Same JSON schema, same self-verification, same multi-rank logic for all three.
 
 N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL). When no launcher has started the ranks
 (WORLD_SIZE unset) this process starts them itself as a child `python -m torch.distributed.run` -- before it
@@ -46,6 +51,70 @@ LOGN, BITS, NSP, PLAIN_T = 15, [55] * 8, 1, 786433
 # that the timed path never touches oracle/.
 CFG3_PRIMES = [36028797010444289, 36028797012606977, 36028797013000193, 36028797013327873, 36028797014376449,
                36028797014573057, 36028797014704129, 36028797017456641]
+# CoeffModulus::Create(32768, {50}x12) and (65536, {50}x16), checked against the oracle in the checker leg
+CFG4_PRIMES = [1125899885412353, 1125899885740033, 1125899886395393, 1125899887312897, 1125899896160257, 1125899899174913,
+               1125899901665281, 1125899902124033, 1125899903107073, 1125899903500289, 1125899903827969, 1125899904679937]
+CFG5_PRIMES = [1125899864506369, 1125899865948161, 1125899870011393, 1125899870404609, 1125899877875713, 1125899879710721,
+               1125899882987521, 1125899883380737, 1125899883642881, 1125899884036097, 1125899884167169, 1125899885740033,
+               1125899886395393, 1125899887312897, 1125899902124033, 1125899903827969]
+
+# The BASELINE.json lines bench.py can be timed on. `op`: what a step does to every ciphertext (pair) of the batch.
+# Byte accounting per unit: `compulsory` = what any implementation has to move (inputs read once, result
+# written once; keys are read once per batch and left out), `ntt_rows` = row transforms the reference performs for one
+# unit (x 16 N bytes = "NTT-equivalent" traffic, so that fused kernels show up as a gain).
+CONFIGS = {
+    3: {"scheme": 1, "logn": 15, "bits": [55] * 8, "primes": CFG3_PRIMES, "t": PLAIN_T, "op": "mul_relin", "batch": 4096,
+        "cpu_ops": 240, "unit": "ct_mul_relin/s",
+        "metric": "ciphertext multiply+relinearize/s (BFV N=2^15, 8 primes, bit-exact PARITY mode)",
+        "workload": "BASELINE config 3: BFV N=2^15, {55}x8 primes (k=7, |Bsk|=8, 7 digits), "
+                    "Evaluator::multiply + relinearize over independent ciphertexts resident in HBM"},
+    4: {"scheme": 2, "logn": 15, "bits": [50] * 12, "primes": CFG4_PRIMES, "t": 0, "op": "rotate", "batch": 1024,
+        "cpu_ops": 160, "unit": "rotate_vector/s",
+        "metric": "ciphertext rotate_vector/s (CKKS N=2^15, 12 primes, Galois key switch, bit-exact PARITY mode)",
+        "workload": "BASELINE config 4: CKKS N=2^15, {50}x12 primes (k=11, 11 decomposition digits: 16 are not reachable with "
+                    "12 primes, SURVEY 8), Evaluator::rotate_vector over the rank's share of 8192 ciphertexts resident in "
+                    "HBM, Galois key replicated per GPU"},
+    5: {"scheme": 1, "logn": 16, "bits": [50] * 16, "primes": CFG5_PRIMES, "t": PLAIN_T, "op": "mul_relin_modswitch",
+        "batch": 256, "cpu_ops": 16, "unit": "pipeline/s",
+        "metric": "multiply+relinearize+mod_switch_to_next pipelines/s (BFV N=2^16, 16 primes, bit-exact PARITY mode)",
+        "workload": "BASELINE config 5: BFV N=2^16, {50}x16 primes (k=15, |Bsk|=16, 15 digits), Evaluator::multiply + "
+                    "relinearize + mod_switch_to_next over independent ciphertexts resident in HBM"},
+}
+
+
+def unit_bytes(cfg):
+    """Per-unit byte accounting of a config, in bytes."""
+    n, nk = 1 << cfg["logn"], len(cfg["primes"])
+    k, nsp = nk - 1, 1
+    d = k  # ceil(k / nsp)
+    if cfg["op"] == "rotate":
+        compulsory = 2 * (2 * k * n * 8)  # read the ciphertext, write the rotated one
+        ntt_rows = k + d * (k + nsp - 1) + 2 * nsp + 2 * k  # target iNTT + digit NTTs + special iNTTs + temp NTTs (CKKS)
+    else:
+        compulsory = 48 * k * n  # two size-2 inputs read, one size-2 result written
+        ntt_rows = 7 * (2 * k + 1) + d * (k + nsp - 1) + 2 * nsp + 2 * k  # BFV multiply + relinearize (cfg3: 105 + 65)
+        if cfg["op"] == "mul_relin_modswitch":
+            compulsory = 2 * (2 * k * n * 8) + 2 * (k - 1) * n * 8
+    return {"compulsory": compulsory, "ntt_rows": ntt_rows, "ntt_equivalent": ntt_rows * 16 * n}
+
+
+def kernel_bytes_per_unit(cfg, tag):
+    """Own algorithmic bytes of the non-NTT kernels per unit (rows read once + rows written once, 8 N bytes per row;
+    DESIGN.md section 4), or None. The NTT tags are priced from the rows their launches report."""
+    n, nk = 1 << cfg["logn"], len(cfg["primes"])
+    k, nb, rows, d = nk - 1, nk, nk, nk - 1  # |Bsk| = k + 1 = nk, key rows = k + nsp
+    row = 8 * n
+    table = {
+        "bfv_lift": 4 * (k + nb) * row,                       # 4 polynomials: k rows in, |Bsk| rows out
+        "bfv_floor_sk": 3 * (k + nb + k) * row,               # 3 polynomials: k + |Bsk| rows in, k rows out
+        "ks_mac": (d * rows + 2 * rows) * row,                # digit rows in, both product polynomials out (key: per batch)
+        "ks_moddown_bfv": (2 * rows + 2 * k + 2 * k) * row,   # products in, ciphertext in and out
+        "ks_moddown_post": (2 * k + 2 * k + 2 * k + 2 * k) * row,
+        "galois": (2 * k + 2 * k) * row,
+        "divround_bfv": (2 * k + 2 * (k - 1)) * row,
+        "tensor_product": 7 * k * row,
+    }
+    return table.get(tag)
 
 
 # ------------------------------------------------------------------ multi-rank helpers (covered by gloo tests)
@@ -97,11 +166,12 @@ def barrier_sync():
         torch.cuda.synchronize()
 
 
-def gather_payload(payload, digest_fn):
+def gather_payload(payload, digest_fn, force=False):
     """The final gather of SURVEY 8(e): every rank's output slice to rank 0 (RCCL send/recv over xGMI under the nccl
     backend), timed on its own, then checked on rank 0 against the digests the ranks computed locally.
-    Returns None for a single rank."""
-    if not _dist_on() or dist.get_world_size() == 1:
+    Returns None for a single rank -- unless `force` (--force-dist): then the one rank gathers to itself, so that the
+    collective really runs on the backend (the rehearsal of the multi-GPU path on a one-GPU box)."""
+    if not _dist_on() or (dist.get_world_size() == 1 and not force):
         return None
     world, rank = dist.get_world_size(), dist.get_rank()
     mine = digest_fn(payload)
@@ -116,7 +186,7 @@ def gather_payload(payload, digest_fn):
     seen = 0
     if rank == 0:
         seen = sum(1 for r in range(world) if digest_fn(bufs[r]) == digests[r])
-    return {"bytes_per_rank": nbytes, "seconds": dt, "GBps_into_root": (world - 1) * nbytes / dt / 1e9,
+    return {"bytes_per_rank": nbytes, "seconds": dt, "GBps_into_root": max(world - 1, 1) * nbytes / dt / 1e9,
             "ranks_seen": seen, "backend": dist.get_backend()}
 
 
@@ -212,30 +282,47 @@ def load_oracle():
     return O, how
 
 
-def verify_against_oracle(O, key, a, b, out, items):
-    """multiply+relinearize of the given ciphertext pairs on the CPU oracle vs the words the engine produced."""
-    L = O.lib()
-    n = 1 << LOGN
-    kmods = O.coeff_modulus_create(n, BITS)
-    assert kmods == CFG3_PRIMES
-    ref = O.RefContext(1, LOGN, kmods, nsp=NSP, t=PLAIN_T)
-    k = ref.k_first
-    hkey = host_u64(key)
-    keys = (C.c_void_p * 1)(hkey.ctypes.data)
-    ok = []
-    for i in items:
-        ha, hb, got = host_u64(a[i]), host_u64(b[i]), host_u64(out[i])
-        exp = np.zeros((3, k, n), dtype=np.uint64)
-        assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(ha), 2, O.ptr(hb), 2, O.ptr(exp)) == 0
-        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp), 3, keys) == 0
-        ok.append(bool(np.array_equal(got, exp)))
-    return ok
+class OracleOp:
+    """One unit of a config's step on the CPU oracle (oracle/sealref.c): the checker of the timed path's output and the
+    thing the CPU baseline times. `run(a, b, reps)` -> the result words after applying the step `reps` times (the in-place
+    rotate of config 4 is applied once per step, so the timed output is the (warmup + steps)-fold rotation)."""
+
+    def __init__(self, O, cfg, key_host, galois_elt=None):
+        self.O, self.L, self.cfg = O, O.lib(), cfg
+        self.n = 1 << cfg["logn"]
+        kmods = O.coeff_modulus_create(self.n, cfg["bits"])
+        assert kmods == cfg["primes"], "hard-wired primes differ from CoeffModulus::Create"
+        self.ref = O.RefContext(cfg["scheme"], cfg["logn"], kmods, nsp=NSP, t=cfg["t"])
+        self.k = self.ref.k_first
+        self.key = key_host
+        self.keys = (C.c_void_p * 1)(key_host.ctypes.data)
+        self.elt = galois_elt
+        if cfg["scheme"] == 1:
+            self.ref.rns_tool(self.k)  # shared constants are built before any worker thread starts
+
+    def run(self, a, b, reps=1):
+        O, L, ref, k, n = self.O, self.L, self.ref, self.k, self.n
+        op = self.cfg["op"]
+        if op == "rotate":
+            x = a.copy()
+            for _ in range(reps):
+                assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(x), self.elt, O.ptr(self.key)) == 0
+            return x
+        out = np.zeros((3, k, n), dtype=np.uint64)
+        assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a), 2, O.ptr(b), 2, O.ptr(out)) == 0
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(out), 3, self.keys) == 0
+        if op == "mul_relin":
+            return out
+        c2 = np.ascontiguousarray(out[:2])
+        ms = np.zeros((2, k - 1, n), dtype=np.uint64)
+        assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(c2), 2, O.ptr(ms)) == 0
+        return ms
 
 
-def cpu_baseline(O, how, total_ops):
+def cpu_baseline(O, how, cfg, total_ops, galois_elt):
     """Times the CPU oracle (oracle/sealref.c, digest-identical to the reference) on a bounded sample of the SAME
     workload: one worker thread per CPU this process may use -- min(logical CPUs, scheduler affinity, cgroup CPU quota);
-    threads beyond the quota only get throttled -- each doing multiply+relinearize on its own ciphertexts (the
+    threads beyond the quota only get throttled -- each running the config's step on its own ciphertexts (the
     reference is single-threaded per call and thread-safe across calls). The host's CPU model and core counts are
     reported next to it, with the linear projection of the 1-thread rate to every physical core of the host (an upper
     bound: it assumes perfect scaling), because a GPU box hands its container only a share of the host's cores."""
@@ -248,29 +335,24 @@ def cpu_baseline(O, how, total_ops):
                           math.ceil(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else None) if c]
     threads = max(1, min(usable) if usable else 1)
     per_thread = max(1, int(round(total_ops / threads)))
-    n = 1 << LOGN
-    kmods = O.coeff_modulus_create(n, BITS)
-    ref = O.RefContext(1, LOGN, kmods, nsp=NSP, t=PLAIN_T)
-    k = ref.k_first
-    ref.rns_tool(k)  # build shared constants before the threads start
+    n, kmods = 1 << cfg["logn"], cfg["primes"]
+    k = len(kmods) - NSP
     rng = np.random.default_rng(1)
 
     def rows(mods):
         return np.stack([rng.integers(0, p, size=n, dtype=np.uint64) for p in mods])
 
     key = np.stack([rows(kmods * 2).reshape(2, len(kmods), n) for _ in range(k)])
-    work = [(rows(kmods[:k] * 2), rows(kmods[:k] * 2), np.zeros((3, k, n), dtype=np.uint64)) for _ in range(threads)]
-    keys = (C.c_void_p * 1)(key.ctypes.data)
+    op = OracleOp(O, cfg, key, galois_elt)
+    work = [(rows(kmods[:k] * 2).reshape(2, k, n), rows(kmods[:k] * 2).reshape(2, k, n)) for _ in range(threads)]
 
     def run(item, reps=per_thread):
-        a, b, out = item
         for _ in range(reps):
-            assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a), 2, O.ptr(b), 2, O.ptr(out)) == 0
-            assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(out), 3, keys) == 0
+            op.run(item[0], item[1])
 
     run(work[0], 1)  # page everything in
     t1 = time.perf_counter()
-    one_reps = 4
+    one_reps = 4 if cfg["logn"] < 16 else 1
     run(work[0], one_reps)
     one_thread = one_reps / (time.perf_counter() - t1)
     t0 = time.perf_counter()
@@ -280,18 +362,18 @@ def cpu_baseline(O, how, total_ops):
     # forward NTT/s on one core, same primes
     x = rows(kmods[:k])
     t1 = time.perf_counter()
-    reps = 8
+    reps = 8 if cfg["logn"] < 16 else 2
     for _ in range(reps):
         for i in range(k):
-            L.ref_ntt_forward(O.ptr(x[i]), ref.tables(i), 0)
+            L.ref_ntt_forward(O.ptr(x[i]), op.ref.tables(i), 0)
     ntt_s = reps * k / (time.perf_counter() - t1)
     out = {
         "value": threads * per_thread / dt,
-        "unit": "ct_mul_relin/s",
+        "unit": cfg["unit"],
         "cores": threads,
         "kind": "port",
-        "sample": "%d threads (one per CPU usable by this container) x %d BFV multiply+relinearize at N=2^15, 8 primes "
-                  "(same workload, %d ciphertext pairs)" % (threads, per_thread, threads * per_thread),
+        "sample": "%d threads (one per CPU usable by this container) x %d x the step of this config on the CPU oracle "
+                  "(same workload, %d units)" % (threads, per_thread, threads * per_thread),
         "seconds": dt,
         "value_1thread": one_thread,
         "forward_ntt_per_s_1core": ntt_s,
@@ -300,12 +382,15 @@ def cpu_baseline(O, how, total_ops):
     out.update(info)
     cores = info["physical_cores"] or info["logical_cpus"] or threads
     out["projected_all_physical_cores_linear"] = one_thread * cores
+    out["projection_note"] = ("the >= 10x CPU target is judged against a linear PROJECTION of the 1-thread rate to all %s "
+                              "physical cores (the container may use %d CPUs); it assumes perfect scaling of a "
+                              "memory-heavy workload, i.e. it is an upper bound on the host" % (cores, threads))
     return out
 
 
 # ------------------------------------------------------------------ workloads
 class EngineWorkload:
-    """config 3 on one MI355X through the C ABI (ctypes mirror of the Evaluator interface)."""
+    """One BASELINE config on one MI355X through the C ABI (ctypes mirror of the Evaluator interface)."""
 
     def __init__(self, args, rank, local_rank):
         import sealhip as S
@@ -313,38 +398,67 @@ class EngineWorkload:
         if not torch.cuda.is_available() or S.num_devices() < 1:
             raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
         torch.cuda.set_device(local_rank)
+        self.cfg = cfg = CONFIGS[args.config]
         self.dev = torch.device("cuda", local_rank)
         # one explicit stream for torch's fills/copies AND the engine's launches: everything below is ordered on it
         self.stream = torch.cuda.Stream(device=self.dev)
-        self.n, self.kmods = 1 << LOGN, CFG3_PRIMES
-        self.ctx = S.Context(S.SCHEME_BFV, LOGN, self.kmods, NSP, PLAIN_T, device=local_rank)
+        self.n, self.kmods = 1 << cfg["logn"], cfg["primes"]
+        self.ctx = S.Context(cfg["scheme"], cfg["logn"], self.kmods, NSP, cfg["t"], device=local_rank)
         self.ctx.set_stream(self.stream.cuda_stream)
         self.ev = S.Evaluator(self.ctx)
         self.S = S
         self.k, self.nk, self.B = self.ctx.k_first, len(self.kmods), args.batch
+        self.steps_done = 0
+        self.elt = self.ctx.galois_elt_from_step(1) if cfg["op"] == "rotate" else None
         k, n, B, dev = self.k, self.n, self.B, self.dev
         with torch.cuda.stream(self.stream):
             torch.manual_seed(1234 + rank)  # every rank owns different ciphertexts
             self.a = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
-            self.b = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
-            self.out = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
-            self.key = torch.empty((k, 2, self.nk, n), dtype=torch.int64, device=dev)
             fill_mod_rows(self.a, self.kmods[:k])
-            fill_mod_rows(self.b, self.kmods[:k])
-            torch.manual_seed(99)  # the relinearisation key is replicated on every GPU
+            self.key = torch.empty((k, 2, self.nk, n), dtype=torch.int64, device=dev)
+            if cfg["op"] == "rotate":
+                self.b = self.out = None
+            else:
+                self.b = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
+                self.out = torch.empty((B, 3, k, n), dtype=torch.int64, device=dev)
+                fill_mod_rows(self.b, self.kmods[:k])
+            self.out2 = self.c2 = None
+            if cfg["op"] == "mul_relin_modswitch":
+                self.c2 = torch.empty((B, 2, k, n), dtype=torch.int64, device=dev)
+                self.out2 = torch.empty((B, 2, k - 1, n), dtype=torch.int64, device=dev)
+            torch.manual_seed(99)  # the relinearisation / Galois key is replicated on every GPU
             fill_mod_rows(self.key, self.kmods)
             self.rk = S.KSwitchKeys(self.ctx, self.key, n_digits=k, from_host=False)
+            # the inputs of the items the checker leg verifies (config 4 rotates in place: keep what they were)
+            self.items = sorted({0, B // 2, B - 1})
+            self.saved_a = {i: host_u64(self.a[i]) for i in self.items}
 
     def step(self):
-        self.ev.multiply(self.a, 2, self.b, 2, self.k, self.B, self.out)
-        self.ev.relinearize_inplace(self.out, 3, self.k, self.B, [self.rk])
+        op, k, B = self.cfg["op"], self.k, self.B
+        if op == "rotate":
+            self.ev.rotate_vector_inplace(self.a, k, B, 1, {self.elt: self.rk})
+        else:
+            self.ev.multiply(self.a, 2, self.b, 2, k, B, self.out)
+            self.ev.relinearize_inplace(self.out, 3, k, B, [self.rk])
+            if op == "mul_relin_modswitch":
+                # the relinearized ciphertext is the first two polynomials of each item; the engine's batch entry wants
+                # them contiguous (one strided device copy, inside the timed region like everything else)
+                with torch.cuda.stream(self.stream):
+                    self.c2.copy_(self.out[:, :2])
+                self.ev.mod_switch_to_next(self.c2, 2, k, B, self.out2)
+        self.steps_done += 1
 
     def finish(self):
         self.ctx.synchronize()  # also surfaces a device-side failure of any launch (sticky flag)
 
+    def results(self):
+        op = self.cfg["op"]
+        return self.a if op == "rotate" else (self.out2 if op == "mul_relin_modswitch" else self.out)
+
     def result_slice(self, count):
         with torch.cuda.stream(self.stream):
-            res = self.out[:count, :2].contiguous()  # the size-2 results, compacted (what a caller gets back)
+            r = self.results()
+            res = r[:count, :2].contiguous()  # the size-2 results, compacted (what a caller gets back)
         self.stream.synchronize()  # the callers (digests, RCCL gather) work on other streams
         return res
 
@@ -352,12 +466,28 @@ class EngineWorkload:
         with torch.cuda.stream(self.stream):
             return cheap_digest(self.key[0, 0, :1])
 
+    def verify(self, O):
+        """The timed path's own output for items 0, B/2, B-1 against the CPU oracle, word for word."""
+        with torch.cuda.stream(self.stream):
+            op = OracleOp(O, self.cfg, host_u64(self.key), self.elt)
+            oks = []
+            for i in self.items:
+                got = host_u64(self.results()[i])
+                if self.cfg["op"] == "rotate":
+                    exp = op.run(self.saved_a[i], None, reps=self.steps_done)
+                else:
+                    exp = op.run(self.saved_a[i], host_u64(self.b[i]))
+                oks.append(bool(np.array_equal(got, exp)))
+        return oks
+
 
 class StubWorkload:
     """CPU stand-in with the same rank logic (seeds, replicated key, step, result slice) for the gloo tests of the
-    launcher: NOT the engine and never timed as such (`"stub": true` in the line)."""
+    launcher: NOT the engine and never timed as such (`"stub": true` in the line). --config changes the shape of the
+    stand-in's step the way it changes the engine's (in-place rotate for 4, a third stage for 5)."""
 
     def __init__(self, args, rank, local_rank):
+        self.cfg = CONFIGS[args.config]
         self.dev = torch.device("cpu")
         self.n, self.kmods = 64, [1073479681, 1073184769, 1072496641]
         self.k, self.nk, self.B = 2, 3, args.batch
@@ -370,13 +500,20 @@ class StubWorkload:
         self.local_rank = local_rank
 
     def step(self):
+        op = self.cfg["op"]
+        if op == "rotate":
+            self.a = (torch.roll(self.a, 1, dims=-1) + self.key[0, 0, 0, 0]) % self.kmods[0]
+            return
         self.out[:, :2] = (self.a * self.b + self.key[0, 0, 0, 0]) % self.kmods[0]
+        if op == "mul_relin_modswitch":
+            self.out[:, :2] = (self.out[:, :2] * 3) % self.kmods[0]
 
     def finish(self):
         pass
 
     def result_slice(self, count):
-        return self.out[:count, :2].contiguous()
+        src = self.a if self.cfg["op"] == "rotate" else self.out
+        return src[:count, :2].contiguous()
 
     def key_digest(self):
         return cheap_digest(self.key[0, 0, :1])
@@ -388,27 +525,42 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SEALHIP_BENCH_BATCH", "4096")),
-                    help="independent ciphertext pairs per GPU (BASELINE config 3: 4096)")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json line: 3 = BFV multiply+relinearize (the metric's config, default), 4 = CKKS "
+                         "rotate_vector, 5 = BFV N=2^16 multiply+relinearize+mod_switch_to_next")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="independent ciphertexts (pairs) per GPU; default per config: 4096 / 1024 / 256 "
+                         "(SEALHIP_BENCH_BATCH overrides the default)")
     ap.add_argument("--ntt-polys", type=int, default=4096,
-                    help="polynomials (x7 rows) in the NTT-only section; 4096 = the batch of the step (the rate grows "
+                    help="polynomials (x k rows) in the NTT-only section; 4096 = the batch of the step (the rate grows "
                          "with the launch: 31 %% of the roofline at 7 k rows, 36-38 %% at 29-57 k, DESIGN.md section 6)")
     ap.add_argument("--gather-cts", type=int, default=512,
                     help="size-2 result ciphertexts per rank in the final gather to rank 0 (N > 1 only; 3.67 MB each)")
-    ap.add_argument("--cpu-ops", type=int, default=240,
-                    help="multiply+relinearize operations of the CPU baseline sample (about 85 ms of one core each)")
+    ap.add_argument("--cpu-ops", type=int, default=None,
+                    help="units of the CPU baseline sample (default per config: 240 / 160 / 16, about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed path's output")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) and run every collective of the multi-rank path even "
+                         "with one rank: barrier, all_reduce, all_gather and the final gather (to self)")
     ap.add_argument("--measure-traffic", action="store_true",
-                    help="first collect the HBM PMC counters of the NTT kernels (two rocprofv3 --pmc child runs of this "
+                    help="first collect the HBM PMC counters of the step (two rocprofv3 --pmc child runs of this "
                          "command at batch 256) and record them in profiles/traffic.json; roofline.traffic then comes "
                          "from this run's own measurement")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload + gloo (tests of the rank logic only)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    if args.batch is None:
+        env = os.environ.get("SEALHIP_BENCH_BATCH")
+        args.batch = int(env) if env and args.config == 3 else cfg["batch"]
+    if args.cpu_ops is None:
+        args.cpu_ops = cfg["cpu_ops"]
+    return args
 
 
 def main(argv=None):
     args = parse_args(argv)
+    cfg = CONFIGS[args.config]
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -420,13 +572,18 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match the %d launched ranks (WORLD_SIZE)" % (args.gpus, world))
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # --force-dist without a launcher: a one-rank group of our own
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
         if args.stub:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     w = (StubWorkload if args.stub else EngineWorkload)(args, rank, local_rank)
     B, k, n = w.B, w.k, w.n
     lo, hi = shard_range(world * B, rank, world)  # this rank's slice of the global batch (weak scaling: B each)
@@ -454,7 +611,7 @@ def main(argv=None):
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     shares = {tkey: round(v["ms"] / total_ms, 4) for tkey, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
-    # launches per full row transform at N=2^15: the single-pass kernels complete a transform per launch, the tiled
+    # launches per full row transform: the single-pass kernels complete a transform per launch, the tiled
     # pass kernel needs two launches (each then counts for half of the 16*N algorithmic bytes)
     PASSES = {"ntt_fwd_half": 1, "ntt_inv_half": 1, "ntt_fwd_pass": 2, "ntt_inv_pass": 2}
 
@@ -471,7 +628,15 @@ def main(argv=None):
                 "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches": v["launches"], "share_of_step_kernel_time": v["ms"] / total_ms}
 
-    roof = None
+    roof, traffic_rec = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if prof and os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("kernels_sha") == kernels_sha() and rec.get("config", 3) == args.config:
+                traffic_rec = rec  # a record of another build or config is ignored (traffic stays null)
+        except Exception:
+            pass
     if prof:
         dominant = max(prof, key=lambda tkey: prof[tkey]["ms"])
         roof = ntt_roofline(dominant) if dominant in PASSES else (ntt_roofline("ntt_fwd_half") or ntt_roofline("ntt_fwd_pass"))
@@ -479,22 +644,48 @@ def main(argv=None):
             roof = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None, "traffic": None}
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS
-        # command, tools/measure_traffic.sh; gfx950 correction applied): profiles/traffic.json records bytes per row for
-        # the build it was measured on; a record of another build is ignored (traffic stays null)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and roof.get("rows_per_launch"):
-            try:
-                rec = json.load(open(tpath))
-                if rec.get("kernels_sha") == kernels_sha():
-                    roof["traffic"] = rec[roof["kernel"]]["hbm_bytes_per_row_per_launch"] * roof["rows_per_launch"]
-                    roof["traffic_source"] = "profiles/traffic.json (%s)" % rec.get("measured", "rocprofv3 --pmc")
-            except Exception:
-                pass
+        # command, --measure-traffic; gfx950 correction applied): profiles/traffic.json records bytes per row for the
+        # build it was measured on
+        if traffic_rec and roof.get("rows_per_launch") and roof["kernel"] in traffic_rec:
+            roof["traffic"] = traffic_rec[roof["kernel"]]["hbm_bytes_per_row_per_launch"] * roof["rows_per_launch"]
+            roof["traffic_source"] = "profiles/traffic.json (%s)" % traffic_rec.get("measured", "rocprofv3 --pmc")
+
+    # ---- the pipeline-level roofline and the top kernels against their own algorithmic bytes
+    pipeline, kernels = None, None
+    if prof:
+        ub = unit_bytes(cfg)
+        per_gpu = value / world
+        pipeline = {
+            "unit": cfg["unit"].split("/")[0],
+            "compulsory_bytes_per_unit": ub["compulsory"],
+            "compulsory_frac_of_hbm": ub["compulsory"] * per_gpu / 1e9 / HBM_PEAK_GBS,
+            "ntt_rows_per_unit": ub["ntt_rows"],
+            "ntt_equivalent_bytes_per_unit": ub["ntt_equivalent"],
+            "ntt_equivalent_frac_of_hbm": ub["ntt_equivalent"] * per_gpu / 1e9 / HBM_PEAK_GBS,
+            "measured_hbm_bytes_per_unit": traffic_rec["step"]["hbm_bytes_per_unit"] if traffic_rec and "step" in traffic_rec else None,
+        }
+        if pipeline["measured_hbm_bytes_per_unit"]:
+            pipeline["measured_frac_of_hbm"] = pipeline["measured_hbm_bytes_per_unit"] * per_gpu / 1e9 / HBM_PEAK_GBS
+            pipeline["measured_over_compulsory"] = pipeline["measured_hbm_bytes_per_unit"] / ub["compulsory"]
+        kernels = []
+        units_timed = B * args.steps
+        for tag, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5]:
+            if tag in PASSES:
+                alg = v["units"] * 16 * n / PASSES[tag]
+            else:
+                per_unit = kernel_bytes_per_unit(cfg, tag)
+                alg = per_unit * units_timed if per_unit else None
+            ent = {"kernel": tag, "ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                   "algorithmic_bytes_per_step": alg / args.steps if alg else None,
+                   "frac_of_hbm": (alg / (v["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS) if alg else None}
+            if traffic_rec and tag in traffic_rec.get("per_kernel", {}):
+                ent["measured_hbm_bytes_per_unit"] = traffic_rec["per_kernel"][tag]
+            kernels.append(ent)
 
     # ---- NTT-only section: forward-NTT/s (the other half of the BASELINE metric), same primes, same device
     ntt = None
     if not args.stub and args.ntt_polys > 0:
-        P = args.ntt_polys
+        P = args.ntt_polys if cfg["logn"] < 16 else max(1, args.ntt_polys // 4)
         with torch.cuda.stream(w.stream):
             x = torch.empty((P, k, n), dtype=torch.int64, device=w.dev)
             fill_mod_rows(x, w.kmods[:k])
@@ -515,12 +706,12 @@ def main(argv=None):
             "forward_ntt_per_s": world * ntt_rows / ntt_dt,
             "forward_ntt_per_s_kernel_time": ntt_rows / ntt_kernel_s,
             "hbm_roofline_frac": (ntt_rows * 16 * n / ntt_kernel_s) / 1e9 / HBM_PEAK_GBS,
-            "rows": P * k, "reps": reps,
+            "rows": P * k, "reps": reps, "n": n,
         }
         del x
 
-    # ---- the final gather (N > 1): every rank's result slice to rank 0 over RCCL, timed on its own
-    gather = gather_payload(w.result_slice(min(B, args.gather_cts)), cheap_digest)
+    # ---- the final gather (N > 1, or --force-dist): every rank's result slice to rank 0 over RCCL, timed on its own
+    gather = gather_payload(w.result_slice(min(B, args.gather_cts)), cheap_digest, force=args.force_dist)
     key_digests = gather_digests(w.key_digest())  # the key must be the same on every rank
     rank_digests = gather_digests(cheap_digest(w.result_slice(min(B, 4))))
 
@@ -529,22 +720,19 @@ def main(argv=None):
     if not args.stub and not (args.no_verify and (args.no_cpu_baseline or world > 1)):
         O, how = load_oracle()
         if not args.no_verify:
-            items = sorted({0, B // 2, B - 1})
-            with torch.cuda.stream(w.stream):
-                oks = verify_against_oracle(O, w.key, w.a, w.b, w.out, items)
-            verified = all_ranks_true(all(oks))
+            items = w.items
+            verified = all_ranks_true(all(w.verify(O)))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(O, how, args.cpu_ops)
+            cpu = cpu_baseline(O, how, cfg, args.cpu_ops, w.elt)
             cpu["gpu_over_cpu_%dthreads_measured" % cpu["cores"]] = value / cpu["value"]
             cpu["gpu_over_cpu_1thread"] = value / cpu["value_1thread"]
             cpu["gpu_over_cpu_all_physical_cores_projected"] = value / cpu["projected_all_physical_cores_linear"]
 
     if rank == 0:
         line = {
-            "metric": "stub rank-logic rehearsal (NOT the engine)" if args.stub else
-                      "ciphertext multiply+relinearize/s (BFV N=2^15, 8 primes, bit-exact PARITY mode)",
+            "metric": "stub rank-logic rehearsal (NOT the engine)" if args.stub else cfg["metric"],
             "value": value,
-            "unit": "ct_mul_relin/s",
+            "unit": cfg["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -554,11 +742,12 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: BFV N=2^15, {55}x8 primes (k=7, |Bsk|=8, 7 digits), "
-                                   "Evaluator::multiply + relinearize over independent ciphertexts resident in HBM",
+            "config": {"workload": cfg["workload"], "baseline_config": args.config,
                        "ciphertexts_per_gpu": B, "global_batch": world * B, "mode": "PARITY",
                        "parallelism": "dp%d (independent ciphertexts sharded, no data-path collective)" % world},
             "roofline": roof,
+            "pipeline_roofline": pipeline,
+            "kernels": kernels,
             "cpu_baseline": cpu,
             "ntt": ntt,
             "kernel_time_shares": shares,
@@ -566,6 +755,7 @@ def main(argv=None):
             "verified_vs_oracle": verified,
             "gather": gather,
             "rccl_ranks_seen": gather["ranks_seen"] if gather else (1 if world == 1 else 0),
+            "dist_initialized": _dist_on(),
             "key_replicated": len(set(key_digests)) == 1,
             "rank_digests": ["%016x" % d for d in rank_digests],
         }
@@ -579,12 +769,20 @@ def main(argv=None):
         raise SystemExit("bench.py: the timed path's output differs from the CPU oracle (items %s)" % items)
 
 
+KERNEL_TAGS = (("ntt_fwd_half_kernel", "ntt_fwd_half"), ("ntt_inv_half_kernel", "ntt_inv_half"), ("ntt_inv_top_kernel", "ntt_inv_top"),
+               ("ntt_pass_kernel", "ntt_pass"), ("bfv_lift", "bfv_lift"), ("bfv_floor_sk", "bfv_floor_sk"),
+               ("ks_mac", "ks_mac"), ("ks_moddown_bfv", "ks_moddown_bfv"), ("ks_moddown_post", "ks_moddown_post"),
+               ("ks_moddown_pre", "ks_moddown_pre"), ("galois_kernel", "galois"), ("divround_bfv", "divround_bfv"),
+               ("tensor_product", "tensor_product"), ("copy_rows", "copy_rows"))
+
+
 def measure_traffic(args):
-    """--measure-traffic: HBM bytes per launch of the NTT kernels from the PMC counters, collected as
-    MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE in their own rocprofv3 --pmc passes over this very
-    command at a reduced batch; values in KB; on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane read stream and
-    is doubled). Runs the passes as child processes before this process touches the GPU and records the result, with
-    the identity of the kernel sources, in profiles/traffic.json."""
+    """--measure-traffic: HBM bytes of the step from the PMC counters, collected as MI355X_MICROARCH.md prescribes
+    (FETCH_SIZE and WRITE_SIZE in their own rocprofv3 --pmc passes over this very command at a reduced batch; values in
+    KB; on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane read stream and is doubled). Per launch and row for the
+    NTT kernels (roofline.traffic), per unit for every kernel and for the step as a whole (pipeline_roofline, kernels).
+    Runs the passes as child processes before this process touches the GPU and records the result, with the identity of
+    the kernel sources and the config, in profiles/traffic.json."""
     import csv
     import glob
     import shutil
@@ -593,14 +791,15 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
+    batch, steps = min(256, args.batch), 2
     totals = {}  # tag -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "rows": rows, "launches": n}
+    everything = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="sealhip_pmc_", dir="/tmp")
-        # the multiply+relinearize step only (no NTT-only section): the same mix of forward / inverse launches that
-        # roofline.achieved is measured over
+        # the step only (no NTT-only section): the same mix of launches that roofline.achieved is measured over
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-               os.path.abspath(__file__), "--batch", "256", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
-               "--no-verify", "--ntt-polys", "0"]
+               os.path.abspath(__file__), "--config", str(args.config), "--batch", str(batch), "--steps", str(steps),
+               "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--ntt-polys", "0"]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -608,26 +807,36 @@ def measure_traffic(args):
             return None
         for row in csv.DictReader(open(files[0])):
             name = row["Kernel_Name"]
-            if "ntt_fwd_half_kernel" in name:
-                tag = "ntt_fwd_half"
-            elif "ntt_inv_half_kernel" in name:
-                tag = "ntt_inv_half"
-            else:
+            val = float(row["Counter_Value"])
+            if "fill_mod" in name or "at::native" in name or "distribution" in name:
+                continue  # torch's input fills are not part of the step
+            everything[counter] += val
+            tag = next((t for key, t in KERNEL_TAGS if key in name), None)
+            if tag is None:
                 continue
             t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "rows": 0.0, "launches": 0})
-            t[counter] += float(row["Counter_Value"])
+            t[counter] += val
             if counter == "FETCH_SIZE":
-                t["rows"] += int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # two workgroups per row
+                t["rows"] += int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # half kernels: two workgroups per row
                 t["launches"] += 1
         shutil.rmtree(d, ignore_errors=True)
-    rec = {"kernels_sha": kernels_sha(), "measured": time.strftime("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %Y-%m-%d"),
-           "command": "bench.py --batch 256 --steps 2 --warmup 0 --ntt-polys 0 (every launch of the kernel in the step)"}
+    units = batch * steps
+    rec = {"kernels_sha": kernels_sha(), "config": args.config,
+           "measured": time.strftime("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %Y-%m-%d"),
+           "command": "bench.py --config %d --batch %d --steps %d --warmup 0 --ntt-polys 0 (every launch of the step)"
+                      % (args.config, batch, steps),
+           "step": {"hbm_bytes_per_unit": (2 * everything["FETCH_SIZE"] + everything["WRITE_SIZE"]) * 1024 / units,
+                    "fetch_kb_raw_total": everything["FETCH_SIZE"], "write_kb_total": everything["WRITE_SIZE"], "units": units},
+           "per_kernel": {}}
     for tag, t in totals.items():
-        if not t["rows"]:
+        rec["per_kernel"][tag] = (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / units
+        if tag not in ("ntt_fwd_half", "ntt_inv_half") or not t["rows"]:
             continue
         # summed over every launch of the kernel in the step (the variants differ: gathered / in place, with or without
         # the fused tensor product), divided by the rows they transform
         rec[tag] = {"hbm_bytes_per_row_per_launch": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / t["rows"],
+                    "read_bytes_per_row": 2 * t["FETCH_SIZE"] * 1024 / t["rows"],
+                    "write_bytes_per_row": t["WRITE_SIZE"] * 1024 / t["rows"],
                     "rows_total": t["rows"], "launches": t["launches"], "fetch_size_kb_raw_total": t["FETCH_SIZE"],
                     "write_size_kb_total": t["WRITE_SIZE"]}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

@@ -2116,6 +2116,58 @@ def test_bench_shapes_with_a_small_arena():
     assert r.returncode == 0 and " passed" in tail, tail
 
 
+def _bench_child(argv, launcher=False, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    bench_py = os.path.join(os.path.dirname(HERE), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", "29577"]
+    r = subprocess.run(cmd + [bench_py] + argv, env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    out, err = r.stdout.decode("utf-8", "replace"), r.stderr.decode("utf-8", "replace")
+    assert r.returncode == 0, (out[-1500:], err[-1500:])
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-1500:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launcher", [True, False], ids=["under_torchrun", "own_group"])
+def test_bench_rccl_path_with_one_rank(launcher):
+    """The multi-GPU path of bench.py on the real backend, as far as one GPU allows: a child process (as the driver starts
+    it: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-dist ...`, and once with bench.py
+    building its own one-rank group) runs init_process_group("nccl", device_id=...), the timing barrier, all_reduce
+    (max-over-ranks), all_gather (digests) and the final gather of the result slice -- to itself -- on RCCL, verifies the
+    timed output against the oracle, and reports `rccl_ranks_seen` from the collective. SURVEY 8(e); the workload is
+    evaluator.cpp:235-272,772-827 (multiply + relinearize)."""
+    line = _bench_child(["--gpus", "1", "--force-dist", "--batch", "64", "--steps", "1", "--warmup", "1",
+                         "--no-cpu-baseline", "--ntt-polys", "0", "--gather-cts", "16"], launcher=launcher)
+    assert line["dist_initialized"] is True and line["n_gpus"] == 1
+    assert line["gather"]["backend"] == "nccl" and line["gather"]["ranks_seen"] == 1 and line["rccl_ranks_seen"] == 1
+    assert line["gather"]["bytes_per_rank"] == 16 * 2 * 7 * 32768 * 8
+    assert line["verified_vs_oracle"] is True and line["verified_items"] == [0, 32, 63]
+    assert line["key_replicated"] is True and line["roofline"]["kernel"] == "ntt_fwd_half"
+
+
+@pytest.mark.parametrize("config,batch", [(4, 9), (5, 3)])
+def test_bench_other_baseline_configs_verify_themselves(config, batch):
+    """bench.py --config 4 (CKKS rotate_vector, evaluator.h:1201-1211; the in-place rotation applied warmup + steps times
+    equals the oracle's repeated apply_galois) and --config 5 (BFV N = 2^16 multiply + relinearize + mod_switch_to_next,
+    evaluator.cpp:996-1036): the same JSON schema, the first / middle / last item checked word for word against the oracle."""
+    line = _bench_child(["--config", str(config), "--batch", str(batch), "--steps", "2", "--warmup", "1",
+                         "--no-cpu-baseline", "--ntt-polys", "0"])
+    assert line["config"]["baseline_config"] == config and line["config"]["ciphertexts_per_gpu"] == batch
+    assert line["verified_vs_oracle"] is True and len(line["verified_items"]) == 3
+    assert line["unit"] == {4: "rotate_vector/s", 5: "pipeline/s"}[config]
+    assert line["roofline"]["kernel"].startswith("ntt_") and 0 < line["roofline"]["frac"] < 1
+    assert line["pipeline_roofline"]["compulsory_bytes_per_unit"] > 0 and len(line["kernels"]) >= 3
+
+
 @pytest.mark.skipif("SEALHIP_TEST_SMALL_ARENA_COUNT" not in os.environ, reason="child of test_bench_shapes_with_a_small_arena")
 def test_small_arena_child(sealhip):
     assert os.environ.get("SEALHIP_WORKSPACE_MB") == "64"

@@ -162,6 +162,55 @@ def test_bench_spawns_its_own_ranks_and_gathers_gloo():
     assert bad.returncode != 0 and "does not match" in bad.stderr
 
 
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_other_baseline_configs_multi_rank_gloo(config):
+    """`bench.py --config 4 / 5` (BASELINE's 8-GPU lines: rotate_vector over sharded ciphertexts with the replicated
+    Galois key, evaluator.h:1201-1211; multiply + relinearize + mod_switch_to_next, evaluator.cpp:996-1036) go through
+    the same launcher, sharding, timing and gather code as config 3: rehearsed with two gloo ranks and the stub step."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--config", str(config),
+                          "--steps", "2", "--warmup", "1", "--batch", "5", "--gather-cts", "3"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["baseline_config"] == config and line["config"]["global_batch"] == 10
+    assert ("config %d" % config) in line["config"]["workload"]
+    assert line["unit"] == {4: "rotate_vector/s", 5: "pipeline/s"}[config]
+    assert line["rccl_ranks_seen"] == 2 and line["gather"]["ranks_seen"] == 2 and line["key_replicated"] is True
+    assert len(set(line["rank_digests"])) == 2
+
+
+def test_bench_force_dist_runs_the_collectives_with_one_rank_gloo():
+    """--force-dist: a single rank still initialises the process group and runs barrier / all_reduce / all_gather and the
+    final gather (to itself), so `rccl_ranks_seen` comes from the collective and not from the world == 1 shortcut. This is
+    the CPU twin (gloo) of the GPU test that runs the same command on the nccl backend, with and without a launcher."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--stub", "--force-dist", "--steps", "1", "--batch", "4"]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                "127.0.0.1", "--master-port", "29573"]
+    for cmd in ([sys.executable] + base, launcher + base):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["dist_initialized"] is True and line["n_gpus"] == 1
+        assert line["gather"]["backend"] == "gloo" and line["gather"]["ranks_seen"] == 1 and line["rccl_ranks_seen"] == 1
+    # without the flag the one-rank run does not touch torch.distributed at all
+    out = subprocess.run([sys.executable] + [a for a in base if a != "--force-dist"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["dist_initialized"] is False and line["gather"] is None and line["rccl_ranks_seen"] == 1
+
+
 def _build_adapter(tmp_path):
     import subprocess
 
