@@ -1517,6 +1517,9 @@ namespace sealhip
         // (what the lazy forward transform stores), below 2p for primes up to 2^61 -- the wrapped 60-bit Bsk rows hold
         // arbitrary 64-bit words (which dyadic_product_coeffmod accepts, polyarithsmallmod.cpp:63-117), so the forward
         // launch that produces them reduces every word with barrett_lazy before it stores it (kNttReduceOut).
+#ifndef SEALHIP_NTT_TENSOR_GROUPED
+#define SEALHIP_NTT_TENSOR_GROUPED 1
+#endif
         struct DyadicSrc
         {
             const u64 *x;                        // forward-transformed operands: item-major, 4 polynomials of kb rows
@@ -1692,6 +1695,24 @@ namespace sealhip
                     return;
                 poly = v % npolys;
                 position = static_cast<int>(v / npolys);
+            }
+            else if constexpr (DY && SEALHIP_NTT_TENSOR_GROUPED)
+            {
+                // The three output polynomials of one (item, prime) read the same four input rows (c_0: a_0 b_0, c_1: all
+                // four, c_2: a_1 b_1): enumerate them next to each other -- v = (prime position, item, output) -- so that the six
+                // workgroups run on one XCD at the same time and every input half row is fetched from HBM once and found in
+                // that XCD's L2 by its second reader (prime-major as before: the twiddle tables stay L2-resident).
+                // live.slot[] is sorted by slot = I * kb + r, i.e. three runs of the same nr prime rows.
+                const unsigned xcd = blockIdx.x & 7u;
+                const std::size_t slot = blockIdx.x >> 3, npolys = nrows / map.rows;
+                half = static_cast<int>(slot & 1);
+                const std::size_t v = static_cast<std::size_t>(xcd) * chunk + (slot >> 1);
+                if ((slot >> 1) >= chunk || v >= npolys * static_cast<std::size_t>(live.n))
+                    return;
+                const int nr = live.n / 3;
+                const std::size_t pr = v / 3;
+                position = static_cast<int>(v - pr * 3) * nr + static_cast<int>(pr / npolys);
+                poly = pr % npolys;
             }
             else if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
                 return;
