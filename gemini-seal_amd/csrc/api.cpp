@@ -50,6 +50,7 @@ struct sealhip_graph
     Lane *lane = nullptr;                  // the lane it was captured on (its arena addresses are baked in)
     unsigned long long generation = 0;     // Lane::alloc_generation at capture
     unsigned long long key_generation = 0; // Engine::key_generation at capture (key addresses are baked in too)
+    unsigned long long pool_id = 0;        // LanePool::id of the context it belongs to (checked at launch)
 };
 
 namespace
@@ -909,8 +910,9 @@ long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t
 long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *a, uint32_t size_a, size_t count,
                               uint64_t *out)
 {
-    // bfv_square / ckks_square (evaluator.cpp:560-770) compute the same canonical residues as
-    // multiply(a, a): 2*c0*c1 mod p == c0*c1 + c1*c0 mod p.
+    // bfv_square / ckks_square (evaluator.cpp:560-770) as their own path: a size-2 operand is lifted / transformed once and
+    // c_1 = x_0 x_1 is formed once and added to itself; any other size goes through multiply(a, a) like the reference
+    // (:579-583, :720-724). The canonical residues equal multiply(a, a)'s: 2 c0 c1 mod p == c0 c1 + c1 c0 mod p.
     REQUIRE_PTR(ctx);
     REQUIRE_PTR(a);
     REQUIRE_PTR(out);
@@ -923,11 +925,9 @@ long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *
             throw std::invalid_argument("out must not alias the operand");
         const u64 *pa = reinterpret_cast<const u64 *>(a);
         if (e.scheme == 1)
-            op_bfv_multiply(e, static_cast<int>(k), pa, static_cast<int>(size_a), pa, static_cast<int>(size_a), count,
-                            reinterpret_cast<u64 *>(out));
+            op_bfv_square(e, static_cast<int>(k), pa, static_cast<int>(size_a), count, reinterpret_cast<u64 *>(out));
         else
-            op_ckks_multiply(e, static_cast<int>(k), pa, static_cast<int>(size_a), pa, static_cast<int>(size_a), count,
-                             reinterpret_cast<u64 *>(out));
+            op_ckks_square(e, static_cast<int>(k), pa, static_cast<int>(size_a), count, reinterpret_cast<u64 *>(out));
     });
 }
 
@@ -1442,7 +1442,8 @@ long sealhip_graph_capture_end(sealhip_context *ctx, sealhip_graph **graph)
         }
         g->lane = &e.lane();
         g->generation = e.lane().alloc_generation;
-        g->key_generation = e.key_generation;
+        g->key_generation = e.key_generation.load();
+        g->pool_id = e.lanes->id;
         *graph = g.release();
     });
 }
@@ -1453,12 +1454,18 @@ long sealhip_graph_launch(sealhip_context *ctx, sealhip_graph *graph)
     REQUIRE_PTR(graph);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        // replay on the lane the graph was captured on (its arena is part of the graph), whichever thread asks
+        if (graph->pool_id != e.lanes->id)
+            throw std::invalid_argument("the graph was captured on another context");
+        // replay on the lane the graph was captured on (its arena is part of the graph), whichever thread asks. The caller's
+        // own lane is released first: two threads that launch graphs captured on each other's lanes would otherwise take
+        // the two lane locks in opposite order
         Lane &l = *graph->lane;
+        if (&l != &e.lane() && !g_locks.empty())
+            g_locks.pop_back();
         std::lock_guard<std::recursive_mutex> busy(l.busy);
         if (graph->generation != l.alloc_generation)
             throw std::logic_error("the graph is stale: the workspace was re-allocated by a larger operation after the capture");
-        if (graph->key_generation != e.key_generation)
+        if (graph->key_generation != e.key_generation.load())
             throw std::logic_error("the graph is stale: a key-switch key was destroyed after the capture");
         SEALHIP_CHECK(hipGraphLaunch(graph->exec, l.stream));
     });

@@ -101,9 +101,6 @@ namespace sealhip
         e->lanes->device = device;
         e->lanes->id = next_pool_id();
         // sticky device-side failure flag in host-mapped (coherent) memory: no copy is needed to read it after a sync
-        SEALHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->h_fault), sizeof(unsigned), hipHostMallocMapped));
-        *e->h_fault = 0;
-        SEALHIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&e->d_fault), e->h_fault, 0));
         SEALHIP_CHECK(ntt_init_kernels());
         std::vector<PrimeDev> pd(n_primes);
         for (int i = 0; i < n_primes; i++)
@@ -169,6 +166,8 @@ namespace sealhip
             (void)hipFree(ws);
         if (d_tickets)
             (void)hipFree(d_tickets);
+        if (h_fault)
+            (void)hipHostFree(h_fault);
         if (own_stream && stream)
             (void)hipStreamDestroy(stream);
     }
@@ -187,6 +186,9 @@ namespace sealhip
         SEALHIP_CHECK(hipSetDevice(device));
         SEALHIP_CHECK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
         l->own_stream = true;
+        SEALHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&l->h_fault), sizeof(unsigned), hipHostMallocMapped));
+        *l->h_fault = 0;
+        SEALHIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&l->d_fault), l->h_fault, 0));
         all.push_back(std::move(l));
         return all.back().get();
     }
@@ -270,19 +272,27 @@ namespace sealhip
             }
             for (hipStream_t s : streams)
                 SEALHIP_CHECK(hipStreamSynchronize(s));
+            // every lane has been waited for: a failure of any of them fails this call (and is consumed by it)
+            bool any = false;
+            {
+                std::lock_guard<std::mutex> lock(lanes->mu);
+                for (auto &l : lanes->all)
+                    if (l->h_fault && __atomic_exchange_n(l->h_fault, 0u, __ATOMIC_ACQ_REL))
+                        any = true;
+            }
+            if (any)
+                throw std::runtime_error("forward NTT: sibling workgroup wait timed out; results of that launch are invalid");
+            return;
         }
-        else
-            SEALHIP_CHECK(hipStreamSynchronize(lane().stream));
+        SEALHIP_CHECK(hipStreamSynchronize(lane().stream));
         check_fault();
     }
 
     void Engine::check_fault() const
     {
-        if (h_fault && __atomic_load_n(h_fault, __ATOMIC_ACQUIRE))
-        {
-            __atomic_store_n(h_fault, 0u, __ATOMIC_RELEASE);
+        Lane &l = lane();
+        if (l.h_fault && __atomic_exchange_n(l.h_fault, 0u, __ATOMIC_ACQ_REL))
             throw std::runtime_error("forward NTT: sibling workgroup wait timed out; results of that launch are invalid");
-        }
     }
 
     unsigned *Engine::ntt_tickets(std::size_t nrows) const
@@ -359,8 +369,6 @@ namespace sealhip
             (void)hipFree(d_ckks_inv_roots);
         for (auto &kv : ckks_decode)
             (void)hipFree(kv.second);
-        if (h_fault)
-            (void)hipHostFree(h_fault);
     }
 
     LevelTools &Engine::level_host(int k)

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -232,6 +233,10 @@ namespace sealhip
         std::vector<ProfRecord> prof;
         unsigned *d_tickets = nullptr; // per-row tickets of the single-pass forward NTT
         std::size_t tickets_cap = 0;
+        // Sticky failure flag of this lane's launches (today: the forward NTT's sibling hand-off timing out), one word of
+        // host-mapped memory per lane: a time-out in one thread's launch must fail THAT thread's next host-visible point,
+        // not be seen and cleared by another thread's
+        unsigned *h_fault = nullptr, *d_fault = nullptr;
         void *ws = nullptr; // workspace arena (stream-ordered reuse)
         std::size_t ws_bytes = 0, ws_used = 0;
         std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
@@ -265,17 +270,17 @@ namespace sealhip
         // device
         std::shared_ptr<LanePool> lanes;
         Lane &lane() const; // the calling thread's lane of this context (created on first use)
-        // Sticky failure flag of the device code (today: the forward NTT's sibling hand-off timing out), in host-mapped
-        // memory: kernels store to d_fault, every entry point that makes results host-visible reads h_fault after its
-        // stream synchronisation (sync_and_check) and fails with E_UNEXPECTED.
-        unsigned *h_fault = nullptr, *d_fault = nullptr;
+        // Device-side failures are reported through the lane's sticky flag (Lane::h_fault): kernels store to it, every entry
+        // point that makes results host-visible reads it after its stream synchronisation (sync_and_check) and fails with
+        // E_UNEXPECTED. all_lanes: every lane is synchronised and every lane's flag is read (and cleared).
         void sync_and_check(bool all_lanes = false) const;
-        void check_fault() const; // the flag alone, after a synchronisation the caller has done itself
+        void check_fault() const; // the calling thread's lane alone, after a synchronisation the caller has done itself
         // debug hooks of the NTT hand-off (sealhip_debug_ntt_handoff): spin limit of the sibling wait and
         // suppression of the "finished reading" signal, to drive the failure path in the tests
         unsigned ntt_spin_limit = 1u << 24;
         bool ntt_suppress_signal = false;
-        unsigned long long key_generation = 0; // bumps when a key-switch key is destroyed (graphs embed key pointers)
+        // bumps when a key-switch key is destroyed (graphs embed key pointers); read by other threads' graph launches
+        std::atomic<unsigned long long> key_generation{ 0 };
         PrimeDev *d_primes = nullptr;
         std::vector<void *> owned;
         std::map<int, std::unique_ptr<LevelTools>> levels;
@@ -407,7 +412,7 @@ namespace sealhip
                                 const RowMap &map, int flags);
     // inverse NTT that forms the (2,2) ciphertext tensor product on load (needs ntt_can_gather(e)); see ntt.hip
     hipError_t launch_intt_tensor(const Engine &e, u64 *data, const u64 *x, std::size_t item_stride, std::size_t poly_stride,
-                                  int kb, std::size_t nrows, const RowMap &map, int flags);
+                                  int kb, std::size_t nrows, const RowMap &map, int flags, bool square = false);
     hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in,
                                    std::size_t in_stride, u64 *out, std::size_t out_stride, std::size_t count,
                                    int out_rows);
@@ -490,6 +495,9 @@ namespace sealhip
     void op_modup(Engine &e, int k, int bundle, u64 *ext, std::size_t count);
     void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
     void op_ckks_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
+    // Evaluator::square as its own path (evaluator.cpp:560-770): the operand is lifted / transformed once
+    void op_bfv_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out);
+    void op_ckks_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out);
     void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out);
     void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count);
     void op_rescale_special_inplace(Engine &e, int k, u64 *poly, std::size_t count);

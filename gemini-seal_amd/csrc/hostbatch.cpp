@@ -38,12 +38,19 @@ namespace sealhip
         {
             if (need <= cap)
                 return;
-            if (host)
-                SEALHIP_CHECK(hipHostFree(host));
-            if (dev)
-                SEALHIP_CHECK(hipFree(dev));
-            host = dev = nullptr;
+            // every pointer is cleared before the call that may throw: a failed free or allocation must not leave the slot
+            // with a dangling pointer and a stale capacity (the next call would reuse it, the destructor free it twice)
             cap = 0;
+            if (char *h = host)
+            {
+                host = nullptr;
+                SEALHIP_CHECK(hipHostFree(h));
+            }
+            if (char *d = dev)
+            {
+                dev = nullptr;
+                SEALHIP_CHECK(hipFree(d));
+            }
             if (with_host)
                 SEALHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host), need, hipHostMallocDefault));
             SEALHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dev), need));
@@ -146,15 +153,26 @@ namespace sealhip
                     body(i);
                 return;
             }
-            std::vector<std::thread> pool;
-            pool.reserve(nthreads);
-            for (std::size_t t = 0; t < nthreads; t++)
-                pool.emplace_back([&, t] {
-                    for (std::size_t i = t; i < m; i += nthreads)
-                        body(i);
-                });
-            for (auto &th : pool)
-                th.join();
+            // joins whatever was started, also when a thread cannot be created or the body throws on this thread: a joinable
+            // std::thread that is destroyed calls std::terminate -- inside a C ABI entry point
+            struct Joiner
+            {
+                std::vector<std::thread> pool;
+                ~Joiner()
+                {
+                    for (auto &th : pool)
+                        if (th.joinable())
+                            th.join();
+                }
+            } workers;
+            workers.pool.reserve(nthreads);
+            const auto stripe = [&](std::size_t t) {
+                for (std::size_t i = t; i < m; i += nthreads)
+                    body(i);
+            };
+            for (std::size_t t = 1; t < nthreads; t++)
+                workers.pool.emplace_back(stripe, t);
+            stripe(0); // the calling thread takes a stripe itself
         }
     } // namespace
 

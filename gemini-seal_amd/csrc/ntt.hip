@@ -1525,6 +1525,9 @@ namespace sealhip
             const u64 *x;                        // forward-transformed operands: item-major, 4 polynomials of kb rows
             std::size_t item_stride, poly_stride; // words
             int kb;
+            // Evaluator::square (evaluator.cpp:560-702): TWO polynomials per item; c_0 = x_0^2, c_1 = x_0 x_1 added to itself
+            // (:650-651), c_2 = x_1^2
+            int square;
         };
         // IL words in lock step: t_j = (sum of NP products of operands below 2^61) * 2^-64 mod p as a Montgomery reduction,
         // t_j < sum / 2^64 + p. 4 multiplier instructions per product (the operands' upper halves are below 2^29, so the
@@ -1600,7 +1603,9 @@ namespace sealhip
         constexpr int kInvLoadArr = (SEALHIP_NTT_LOAD_EXCHANGE != 0 && (T - 12) >= 2) ? 1 : 4;
 
         // the half row's 32 words per lane, arrangement A, as products of two (c_0, c_2) or four (c_1) input rows
-        template <int T, int A>
+        // SAME: b is a (a square: one load). TWICE: the product added to itself, t + t below 4p brought back below 2p with
+        // one conditional subtraction (the reference's add_poly_coeffmod of the product with itself: same residue).
+        template <int T, int A, bool SAME = false, bool TWICE = false>
         __device__ __forceinline__ void h_load_dyadic2(u64 (&x)[32], const u64 *__restrict__ a, const u64 *__restrict__ b,
                                                        int jloc, u64 p, u64 ninv)
         {
@@ -1613,7 +1618,10 @@ namespace sealhip
                 {
                     const int idx = jloc + Arr<T, A>::slot_index((batch * 4 + i) * 2);
                     va[i] = *reinterpret_cast<const ulonglong2 *>(a + idx);
-                    vb[i] = *reinterpret_cast<const ulonglong2 *>(b + idx);
+                    if constexpr (SAME)
+                        vb[i] = va[i];
+                    else
+                        vb[i] = *reinterpret_cast<const ulonglong2 *>(b + idx);
                 }
 #pragma unroll
                 for (int g = 0; g < 2; g++)
@@ -1624,7 +1632,14 @@ namespace sealhip
                     dyadic_redc<4, 1>(t, aa, bb, p, ninv);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
+                    {
+                        if constexpr (TWICE)
+                        {
+                            const u64 d = t[j] << 1, two_p = p << 1; // t below 2p <= 2^62
+                            t[j] = d >= two_p ? d - two_p : d;
+                        }
                         x[(batch * 4 + 2 * g) * 2 + j] = t[j];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1658,16 +1673,11 @@ namespace sealhip
             }
         }
 
-        // TOPF: the top layer (gap N/2, BackwardLazyLast ntt.cpp:274-281) in the same launch. Both workgroups of a row store
-        // their lazy half (plain stores: they should stay in L2), publish it (fence + ticket), and whichever finishes SECOND
-        // -- it still holds its own half in registers -- reads the sibling's half back, applies the layer to both halves and
-        // stores the whole row. Nobody waits for anybody: the first finisher just leaves. Saves the separate streaming
-        // kernel (read N + write N from HBM) of the standalone inverse transforms.
         // WHOLE: the same workgroup shape (2^T coefficients, T = LOGN - 1) applied to a whole row of a ring of 2^T coefficients:
         // one workgroup per row, all T layers on chip -- the last of them is the row's top layer (BackwardLazyLast with
         // n^-1 folded in, ntt.cpp:274-281) -- so the standalone inverse is ONE launch that reads and writes the row once,
         // instead of the half-row kernel plus the streaming top-layer pass. All three arithmetic forms, N = 2^14 and 2^15.
-        template <int LOGN, int LZ, bool DY, bool TOPF = false, bool WHOLE = false>
+        template <int LOGN, int LZ, bool DY, bool WHOLE = false>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
@@ -1675,10 +1685,9 @@ namespace sealhip
                                                                                   const u64 *__restrict__ src,
                                                                                   std::size_t src_poly_stride,
                                                                                   LiveSlots live, DyadicSrc dy,
-                                                                                  unsigned *__restrict__ tickets = nullptr,
                                                                                   int canonical = 0)
         {
-            static_assert(!WHOLE || (!DY && !TOPF), "whole-row form: plain transforms");
+            static_assert(!WHOLE || !DY, "whole-row form: plain transforms");
             constexpr int T = LOGN - 1;
             constexpr int LOGR = WHOLE ? T : LOGN; // log2 of the row length
             constexpr int N = 1 << LOGR;
@@ -1720,7 +1729,7 @@ namespace sealhip
             const unsigned short pid = map.prime[row % map.rows];
             const PrimeDev P = primes[pid];
             constexpr bool FP = LZ == 2; // two_p / neg_p then carry the bits of p and 1/p as doubles (see fp_reduce_all)
-            static_assert(!FP || (!DY && !TOPF), "the floating-point instance serves plain half transforms only");
+            static_assert(!FP || !DY, "the floating-point instance serves plain half transforms only");
             const u64 p = P.p, two_p = FP ? fp_bits(P.p_d) : P.two_p;
             const u64 *tw = FP ? reinterpret_cast<const u64 *>(P.inv_d) : P.inv;
             const int gbase = half << T;
@@ -1743,7 +1752,14 @@ namespace sealhip
                     const int slot = live.slot[position], I = slot / dy.kb, r = slot - I * dy.kb;
                     const u64 *xr = dy.x + poly * dy.item_stride + (static_cast<std::size_t>(r) << LOGN) + gbase;
                     const std::size_t ps = dy.poly_stride;
-                    if (I == 1) // block-uniform
+                    if (dy.square) // (launch-uniform) two polynomials per item
+                    {
+                        if (I == 1)
+                            h_load_dyadic2<T, LA, false, true>(x, xr, xr + ps, jl, p, P.ninv);
+                        else
+                            h_load_dyadic2<T, LA, true>(x, xr + (I >> 1) * ps, nullptr, jl, p, P.ninv);
+                    }
+                    else if (I == 1) // block-uniform
                         h_load_dyadic4<T, LA>(x, xr, xr + 3 * ps, xr + ps, xr + 2 * ps, jl, p, P.ninv);
                     else if (I == 0)
                         h_load_dyadic2<T, LA>(x, xr, xr + 2 * ps, jl, p, P.ninv);
@@ -1829,7 +1845,6 @@ namespace sealhip
             }
             else
                 RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
-            if constexpr (!TOPF)
             {
                 const int jb = Arr<T, 1>::tid_index(fresh(tid));
 #pragma unroll
@@ -1840,66 +1855,6 @@ namespace sealhip
                                  fp_to_u64(fp_canonical(fp_of(x[s + 1]), fp_of(two_p), fp_of(neg_p))));
                     else
                         store_nt(halfp + jb + Arr<T, 1>::slot_index(s), x[s], x[s + 1]);
-                }
-            }
-            else
-            {
-                const int jb = Arr<T, 1>::tid_index(fresh(tid));
-                // The half is published with agent-scope (sc1) stores: written through this XCD's L2, so the sibling can read
-                // it wherever it runs. A device-wide release fence instead would write back the whole L2 (one per XCD on this
-                // chip) for every workgroup -- measured 5x slower than the two-launch form. What remains to be ordered is
-                // "my stores have completed before my ticket": a wait for the outstanding stores (workgroup-scope fence).
-#pragma unroll
-                for (int s = 0; s < 32; s++)
-                    __hip_atomic_store(halfp + jb + Arr<T, 1>::slot_index(s), x[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                unsigned *flag = reinterpret_cast<unsigned *>(lds); // (the exchange buffer is free: the barrier above)
-                if (tid == 0)
-                    *flag = __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                if (*flag == 0)
-                    return; // the sibling finishes later and does the top layer for both
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                u64 *lo_half = data + (row << LOGN);
-                const u64 *sib = lo_half + ((half ^ 1) << T);
-#pragma unroll
-                for (int batch = 0; batch < 4; batch++)
-                {
-                    ulonglong2 sv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) // agent-scope loads: past any stale line of this CU's L1 / a foreign L2
-                    {
-                        const u64 *q = sib + jb + Arr<T, 1>::slot_index((batch * 4 + i) * 2);
-                        sv[i].x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sv[i].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                    {
-                        const int s = (batch * 4 + i) * 2;
-                        ulonglong2 r0, r1;
-#pragma unroll
-                        for (int e2 = 0; e2 < 2; e2++)
-                        {
-                            const u64 mine = x[s + e2], other = e2 ? sv[i].y : sv[i].x;
-                            const u64 u = half ? other : mine, v = half ? mine : other; // u: lower half, v: upper half
-                            u64 tt = u + v;
-                            tt = tt >= two_p ? tt - two_p : tt;
-                            u64 a0 = mulmod_lazy_hs<true>(tt, P.inv_n, P.inv_n_shoup, neg_p);
-                            u64 a1 = mulmod_lazy_hs<true>(u - v + two_p, P.inv_n_w, P.inv_n_w_shoup, neg_p);
-                            if (canonical)
-                            {
-                                a0 = a0 >= p ? a0 - p : a0;
-                                a1 = a1 >= p ? a1 - p : a1;
-                            }
-                            (e2 ? r0.y : r0.x) = a0;
-                            (e2 ? r1.y : r1.x) = a1;
-                        }
-                        const int idx = jb + Arr<T, 1>::slot_index(s);
-                        store_nt(lo_half + idx, r0.x, r0.y);
-                        store_nt(lo_half + (1 << T) + idx, r1.x, r1.y);
-                    }
                 }
             }
         }
@@ -2025,15 +1980,9 @@ namespace sealhip
                 for (int i = 0; fp && i < live.n; i++)
                     fp = e.tables[map.prime[live.slot[i]]].p < kFpPrimeBound;
                 const DyadicSrc dy = dyadic ? *dyadic : DyadicSrc{};
-                // standalone transforms (top layer not left to a consumer): SEALHIP_NTT_INV_ONE_LAUNCH=1 lets the second
-                // finisher of every row apply the top layer instead of the streaming top-layer kernel. Bit-exact, measured
-                // (profiles/r02): 6.7 vs 7.4 M NTT/s at N = 2^14, 3.29 vs 3.26 at 2^15, 1.43 vs 1.41 at 2^16 -- what the
-                // second launch costs, the longer-lived workgroups cost too; so the two-launch form stays the default.
-                static const bool one_launch = std::getenv("SEALHIP_NTT_INV_ONE_LAUNCH") != nullptr;
-                const bool topf = !(flags & kNttDeferTop) && !dyadic && one_launch && !fp;
-                unsigned *tickets = topf ? e.ntt_tickets(nrows) : nullptr;
-                if (topf && !tickets)
-                    return hipErrorOutOfMemory;
+                // (A one-launch standalone inverse by sibling hand-off -- the second finisher of a row applying the top layer to
+                //  both halves -- was measured in round 2 and brought nothing; its cross-workgroup publish
+                //  rested on workgroup-scope fences, so the path was removed rather than kept as an unsupported option.)
                 if constexpr (LOGN <= 15)
                 {
                     // whole-row form (see the kernel): standalone floating-point transforms (the top layer is not left to a
@@ -2042,14 +1991,14 @@ namespace sealhip
                         const char *env = std::getenv("SEALHIP_NTT_WHOLE_ROW");
                         return env ? std::strtoul(env, nullptr, 0) : ((1ul << 14) | (1ul << 15));
                     }();
-                    if (!dyadic && !topf && !(flags & kNttDeferTop) && ((whole_mask >> LOGN) & 1))
+                    if (!dyadic && !(flags & kNttDeferTop) && ((whole_mask >> LOGN) & 1))
                     {
                         const std::size_t wlds = static_cast<std::size_t>(hpad(1 << (LOGN - 1))) * 8;
                         const int canon = (flags & kNttCanonical) ? 1 : 0;
 #define SEALHIP_INV_WHOLE(LZ_)                                                                                          \
-    ntt_inv_half_kernel<LOGN + 1, LZ_, false, false, true>                                                               \
+    ntt_inv_half_kernel<LOGN + 1, LZ_, false, true>                                                                      \
         <<<static_cast<unsigned>(chunk * 8), 1 << (LOGN - 5), wlds, e.lane().stream>>>(                                  \
-            data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, nullptr, canon)
+            data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, canon)
                         // (the lazy-sum schedule of the larger shape has one more layer: its own bound on the primes -- the
                         //  predicate takes the layer count of the instance that is launched, ntt_inv_half_kernel<LOGN + 1, ..>)
                         bool lazy_w = lazy;
@@ -2068,17 +2017,6 @@ namespace sealhip
 #define SEALHIP_INV_HALF(LZ_, DY_)                                                                                    \
     ntt_inv_half_kernel<LOGN, LZ_, DY_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy)
-#define SEALHIP_INV_HALF_TOP(LZ_)                                                                                      \
-    ntt_inv_half_kernel<LOGN, LZ_, false, true><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
-        data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, tickets, (flags & kNttCanonical) ? 1 : 0)
-                if (topf)
-                {
-                    if (lazy)
-                        SEALHIP_INV_HALF_TOP(1);
-                    else
-                        SEALHIP_INV_HALF_TOP(0);
-                    return hipGetLastError();
-                }
                 if (dyadic)
                 {
                     if (lazy)
@@ -2093,7 +2031,6 @@ namespace sealhip
                 else
                     SEALHIP_INV_HALF(0, false);
 #undef SEALHIP_INV_HALF
-#undef SEALHIP_INV_HALF_TOP
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
@@ -2223,7 +2160,7 @@ namespace sealhip
             ProfScope prof(e, "ntt_fwd_half", transformed_rows(nrows, map));
 #define SEALHIP_FWD_HALF(STRICT_, RED_)                                                                              \
     ntt_fwd_half_kernel<LOGN, STRICT_, RED_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
-        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, src, chunk, live)
+        data, e.d_primes, map, nrows, flags, tickets, e.lane().d_fault, e.ntt_spin_limit, src, chunk, live)
             int red = src.base[0] ? src.reduce_mode : 0;
             if (flags & kNttReduceOut)
             {
@@ -2255,14 +2192,14 @@ namespace sealhip
                 {
                     if constexpr (kStoreExchange<T, 3, 7>)
                         ntt_fwd_half_kernel<LOGN, 3, 7><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                            data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                            data, e.d_primes, map, nrows, flags, tickets, e.lane().d_fault, e.ntt_spin_limit, fsrc, chunk, live);
                 }
                 else if (red == 5)
                     ntt_fwd_half_kernel<LOGN, 3, 5><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                        data, e.d_primes, map, nrows, flags, tickets, e.lane().d_fault, e.ntt_spin_limit, fsrc, chunk, live);
                 else
                     ntt_fwd_half_kernel<LOGN, 3, 4><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>(
-                        data, e.d_primes, map, nrows, flags, tickets, e.d_fault, e.ntt_spin_limit, fsrc, chunk, live);
+                        data, e.d_primes, map, nrows, flags, tickets, e.lane().d_fault, e.ntt_spin_limit, fsrc, chunk, live);
             }
             else if (fp)
             {
@@ -2357,9 +2294,7 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            const void *inv[7] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false, true>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false, true>),
-                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false>),
+            const void *inv[5] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, true>),
@@ -2372,9 +2307,9 @@ namespace sealhip
             }
             if constexpr (LOGN <= 15)
             {
-                const void *whole[3] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 2, false, false, true>),
-                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 1, false, false, true>),
-                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 0, false, false, true>) };
+                const void *whole[3] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 2, false, true>),
+                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 1, false, true>),
+                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 0, false, true>) };
                 for (const void *f : whole)
                 {
                     err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hpad(1 << (LOGN - 1)) * 8);
@@ -2562,13 +2497,13 @@ namespace sealhip
     // rows x (item-major: 4 polynomials of kb rows each, item_stride words apart); map has 3 * kb rows (output polynomial
     // I, row r at slot I * kb + r); the stored values carry the Montgomery factor 2^-64 (see DyadicSrc)
     hipError_t launch_intt_tensor(const Engine &e, u64 *data, const u64 *x, std::size_t item_stride, std::size_t poly_stride,
-                                  int kb, size_t nrows, const RowMap &map, int flags)
+                                  int kb, size_t nrows, const RowMap &map, int flags, bool square)
     {
         if (!(e.use_half_kernel && e.logn >= 14 && e.logn <= 16) || map.rows != 3 * kb)
             return hipErrorInvalidValue;
         if (nrows == 0)
             return hipSuccess;
-        const DyadicSrc dy{ x, item_stride, poly_stride, kb };
+        const DyadicSrc dy{ x, item_stride, poly_stride, kb, square ? 1 : 0 };
         if (e.logn == 14)
             return launch_half_inv<14>(e, data, nrows, map, flags, nullptr, 0, &dy);
         if (e.logn == 15)

@@ -342,12 +342,18 @@ namespace sealhip
     // ------------------------------------------------------------------------------------------
     // bfv_multiply (evaluator.cpp:274-445)
     // ------------------------------------------------------------------------------------------
+    // b == nullptr: bfv_square of a size-2 ciphertext (evaluator.cpp:560-702) -- the two polynomials of `a` are lifted and
+    // transformed once (:604-634) and the tensor product is c_0 = x_0^2, c_1 = x_0 x_1 added to itself, c_2 = x_1^2
+    // (:644-657); everything after it is bfv_multiply's tail.
     void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out)
     {
         LevelTools &lt = e.level(k);
         const RnsDev &h = lt.h_rns;
         const std::size_t N = e.n;
-        const int nB = h.nB, kb = k + nB, sin = sa + sb, dest = sa + sb - 1;
+        const bool sq = b == nullptr;
+        if (sq && (sa != 2 || sb != 2))
+            throw std::logic_error("op_bfv_multiply: the square path takes size-2 operands");
+        const int nB = h.nB, kb = k + nB, sin = sq ? sa : sa + sb, dest = sa + sb - 1;
         const std::size_t w_x = static_cast<std::size_t>(sin) * kb * N;
         const std::size_t w_d = static_cast<std::size_t>(dest) * kb * N;
         const std::size_t chunk = plan_chunk(e, count, (w_x + w_d) * sizeof(u64), 2);
@@ -388,7 +394,7 @@ namespace sealhip
                 NttSource ns{};
                 big.rows = sin * kb;
                 ns.base[0] = a + off * sa * poly_q;
-                ns.base[1] = b + off * sb * poly_q;
+                ns.base[1] = sq ? nullptr : b + off * sb * poly_q;
                 ns.poly_stride[0] = sa * poly_q;
                 ns.poly_stride[1] = sb * poly_q;
                 for (int s = 0; s < sin; s++)
@@ -433,9 +439,9 @@ namespace sealhip
                         mq.prime[I * kb + r] = r < k ? lt.map_qbsk.prime[r] : kSkipRow;
                         mb.prime[I * kb + r] = r < k ? kSkipRow : lt.map_qbsk.prime[r];
                     }
-                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mq, kNttDeferTop | kNttAnyRep),
+                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mq, kNttDeferTop | kNttAnyRep, sq),
                       "intt(tensor, q rows)");
-                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop), "intt(tensor, Bsk rows)");
+                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop, sq), "intt(tensor, Bsk rows)");
                 for (int I = 0; I < dest; I++)
                     check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
                                               dest * poly_q, m, 2),
@@ -443,7 +449,9 @@ namespace sealhip
                 continue;
             }
             // step (4) (:376-420)
-            check(launch_tensor_product(e, X, sa, w_x, X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
+            // (square: both operands are the same two transformed polynomials; the kernel then forms x_0 x_1 once and adds it
+            //  to itself, :650-651)
+            check(launch_tensor_product(e, X, sa, w_x, sq ? X : X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
             // step (5) (:423-424); with the single-pass kernels the top inverse layer and the canonicalisation are
             // applied by the consumer while it loads (saves one read+write pass over D)
             if (defer)
@@ -465,6 +473,20 @@ namespace sealhip
                                           dest * poly_q, m, defer ? 1 : 0),
                       "floor_sk");
         }
+    }
+
+    void op_bfv_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out)
+    {
+        if (sa != 2)
+            return op_bfv_multiply(e, k, a, sa, a, sa, count, out); // evaluator.cpp:579-583
+        op_bfv_multiply(e, k, a, 2, nullptr, 2, count, out);
+    }
+
+    // ckks_square (evaluator.cpp:704-770): size != 2 -> ckks_multiply (:720-724); else the tensor kernel's square form
+    // (a == b: x_0^2, x_0 x_1 + x_0 x_1, x_1^2 -- five row passes per prime instead of seven)
+    void op_ckks_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out)
+    {
+        op_ckks_multiply(e, k, a, sa, a, sa, count, out);
     }
 
     // ckks_multiply (evaluator.cpp:447-527)

@@ -78,6 +78,25 @@ namespace sealhip
                 const u64 *pa = a + item * a_stride + off;
                 const u64 *pb = b + item * b_stride + off;
                 u64 *po = out + item * out_stride + off;
+                if (sa == 2 && sb == 2 && a == b)
+                {
+                    // Evaluator::square (evaluator.cpp:644-657, :752-760): x_0^2, x_0 x_1 added to itself, x_1^2
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(pa);
+                    const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(pa + poly_words);
+                    ulonglong2 c0, c1, c2;
+                    c0.x = mul_mod(a0.x, a0.x, P.p, P.cr0, P.cr1);
+                    c0.y = mul_mod(a0.y, a0.y, P.p, P.cr0, P.cr1);
+                    c1.x = mul_mod(a0.x, a1.x, P.p, P.cr0, P.cr1);
+                    c1.y = mul_mod(a0.y, a1.y, P.p, P.cr0, P.cr1);
+                    c1.x = add_mod(c1.x, c1.x, P.p);
+                    c1.y = add_mod(c1.y, c1.y, P.p);
+                    c2.x = mul_mod(a1.x, a1.x, P.p, P.cr0, P.cr1);
+                    c2.y = mul_mod(a1.y, a1.y, P.p, P.cr0, P.cr1);
+                    *reinterpret_cast<ulonglong2 *>(po) = c0;
+                    *reinterpret_cast<ulonglong2 *>(po + poly_words) = c1;
+                    *reinterpret_cast<ulonglong2 *>(po + 2 * poly_words) = c2;
+                    continue;
+                }
                 if (sa == 2 && sb == 2)
                 {
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(pa);

@@ -1274,6 +1274,108 @@ int ref_bfv_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, con
     return 0;
 }
 
+/* evaluator.cpp:560-702 (bfv_square). A ciphertext of size != 2 takes the multiply path (:579-583); for size 2 the
+ * two polynomials are lifted and transformed ONCE (:604-634), the tensor product is c_0 = a_0^2, c_1 = a_0 a_1 added to
+ * itself, c_2 = a_1^2 (:644-657) over q and over Bsk, the inverse transforms are the canonicalising ones (:663-664), and the
+ * floor / base-conversion tail (:667-701) is the one of bfv_multiply. */
+int ref_bfv_square(ref_context *c, size_t k, const uint64_t *a, size_t sa, uint64_t *out)
+{
+    if (sa != 2)
+        return ref_bfv_multiply(c, k, a, sa, a, sa, out); /* :579-583 */
+    const ref_rns_tool *rt = ref_context_rns_tool(c, k);
+    if (!rt)
+        return -1;
+    const size_t n = c->n, B = rt->Bsk_size, dest = 3;
+    const int strict = c->mode == REF_MODE_STRICT;
+    uint64_t *temp = (uint64_t *)malloc(sizeof(uint64_t) * n * (B + 1));
+    uint64_t *xq = (uint64_t *)malloc(sizeof(uint64_t) * n * k * 2);
+    uint64_t *xB = (uint64_t *)malloc(sizeof(uint64_t) * n * B * 2);
+    /* :604-634 behz_extend_base_convert_to_ntt over the two polynomials */
+    for (size_t pidx = 0; pidx < 2; pidx++)
+    {
+        const uint64_t *src = a + pidx * k * n;
+        uint64_t *dq = xq + pidx * k * n, *dB = xB + pidx * B * n;
+        memcpy(dq, src, sizeof(uint64_t) * n * k);                      /* :607 set_poly */
+        for (size_t i = 0; i < k; i++)
+            ref_ntt_forward_lazy(dq + i * n, &c->key_tables[i], strict); /* :609 */
+        ref_fastbconv_m_tilde(rt, src, temp);                           /* :615 */
+        ref_sm_mrq(rt, temp, dB);                                       /* :618 */
+        for (size_t i = 0; i < B; i++)
+            ref_ntt_forward_lazy(dB + i * n, &rt->Bsk_ntt[i], strict);  /* :621 */
+    }
+    uint64_t *dq = (uint64_t *)calloc(n * k * dest, sizeof(uint64_t));
+    uint64_t *dB = (uint64_t *)calloc(n * B * dest, sizeof(uint64_t));
+    /* :644-660 behz_ciphertext_square over q, then over Bsk */
+    for (size_t r = 0; r < k; r++)
+    {
+        const ref_modulus *m = &c->key_mod[r];
+        const uint64_t *x0 = xq + r * n, *x1 = xq + (k + r) * n;
+        ref_dyadic_product_coeffmod(x0, x0, n, m, dq + r * n);                                  /* :647 */
+        ref_dyadic_product_coeffmod(x0, x1, n, m, dq + (k + r) * n);                            /* :650 */
+        ref_add_poly_coeffmod(dq + (k + r) * n, dq + (k + r) * n, n, m, dq + (k + r) * n);      /* :651 */
+        ref_dyadic_product_coeffmod(x1, x1, n, m, dq + (2 * k + r) * n);                        /* :654 */
+    }
+    for (size_t r = 0; r < B; r++)
+    {
+        const ref_modulus *m = &rt->Bsk[r];
+        const uint64_t *x0 = xB + r * n, *x1 = xB + (B + r) * n;
+        ref_dyadic_product_coeffmod(x0, x0, n, m, dB + r * n);
+        ref_dyadic_product_coeffmod(x0, x1, n, m, dB + (B + r) * n);
+        ref_add_poly_coeffmod(dB + (B + r) * n, dB + (B + r) * n, n, m, dB + (B + r) * n);
+        ref_dyadic_product_coeffmod(x1, x1, n, m, dB + (2 * B + r) * n);
+    }
+    /* :663-664 (the canonicalising inverse, unlike bfv_multiply's :423-424 -- same residues) */
+    for (size_t I = 0; I < dest; I++)
+    {
+        for (size_t r = 0; r < k; r++)
+            ref_ntt_inverse(dq + (I * k + r) * n, &c->key_tables[r]);
+        for (size_t r = 0; r < B; r++)
+            ref_ntt_inverse(dB + (I * B + r) * n, &rt->Bsk_ntt[r]);
+    }
+    /* :667-701 */
+    uint64_t *tqB = (uint64_t *)malloc(sizeof(uint64_t) * n * (k + B));
+    uint64_t *tB = (uint64_t *)malloc(sizeof(uint64_t) * n * B);
+    for (size_t I = 0; I < dest; I++)
+    {
+        for (size_t r = 0; r < k; r++)
+            ref_multiply_poly_scalar_coeffmod(dq + (I * k + r) * n, n, c->t, &c->key_mod[r], tqB + r * n);
+        for (size_t r = 0; r < B; r++)
+            ref_multiply_poly_scalar_coeffmod(dB + (I * B + r) * n, n, c->t, &rt->Bsk[r], tqB + (k + r) * n);
+        ref_fast_floor(rt, tqB, tB);
+        ref_fastbconv_sk(rt, tB, out + I * k * n);
+    }
+    free(tqB);
+    free(tB);
+    free(dq);
+    free(dB);
+    free(temp);
+    free(xq);
+    free(xB);
+    return 0;
+}
+
+/* evaluator.cpp:704-770 (ckks_square): size != 2 -> ckks_multiply (:720-724); else c_0 = a_0^2, c_1 = a_0 a_1 + a_0 a_1,
+ * c_2 = a_1^2 (:752-760), copied back (:763). (The scale bookkeeping :727-733, 766 is host metadata.) */
+int ref_ckks_square(ref_context *c, size_t k, const uint64_t *a, size_t sa, uint64_t *out)
+{
+    if (sa != 2)
+        return ref_ckks_multiply(c, k, a, sa, a, sa, out);
+    const size_t n = c->n;
+    uint64_t *tmp = (uint64_t *)calloc(n * k * 3, sizeof(uint64_t));
+    for (size_t r = 0; r < k; r++)
+    {
+        const ref_modulus *m = &c->key_mod[r];
+        const uint64_t *x0 = a + r * n, *x1 = a + (k + r) * n;
+        ref_dyadic_product_coeffmod(x0, x0, n, m, tmp + r * n);                                   /* :753 */
+        ref_dyadic_product_coeffmod(x0, x1, n, m, tmp + (k + r) * n);                             /* :756 */
+        ref_add_poly_coeffmod(tmp + (k + r) * n, tmp + (k + r) * n, n, m, tmp + (k + r) * n);     /* :757 */
+        ref_dyadic_product_coeffmod(x1, x1, n, m, tmp + (2 * k + r) * n);                         /* :760 */
+    }
+    memcpy(out, tmp, sizeof(uint64_t) * n * k * 3); /* :763 */
+    free(tmp);
+    return 0;
+}
+
 /* evaluator.cpp:447-527 */
 int ref_ckks_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
                       uint64_t *out)

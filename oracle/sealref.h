@@ -168,6 +168,9 @@ int ref_bfv_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, con
 /* evaluator.cpp:447-527 */
 int ref_ckks_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, const uint64_t *b, size_t sb,
                       uint64_t *out);
+/* evaluator.cpp:560-702 / :704-770: Evaluator::square as its own path (size-2 operands; other sizes fall through to multiply) */
+int ref_bfv_square(ref_context *c, size_t k, const uint64_t *a, size_t sa, uint64_t *out);
+int ref_ckks_square(ref_context *c, size_t k, const uint64_t *a, size_t sa, uint64_t *out);
 /* evaluator.cpp:2259-2368; ct = 2 polys (k rows) updated in place; target = k rows;
    key = digits x 2 x n_key x N (K1 layout, keygenerator.cpp:325-369) */
 int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key);

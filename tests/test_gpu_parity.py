@@ -475,8 +475,12 @@ def test_batched_chain_vs_oracle_all_levels(sealhip, scheme, logn, bits, nsp, t)
         sq = ctx.alloc(count * 3 * k * n)
         ev.square(ctx.upload(a), 2, k, count, sq)
         exps = np.zeros((count, 3, k, n), dtype=np.uint64)
+        exps2 = np.zeros((count, 3, k, n), dtype=np.uint64)
+        sqr = L.ref_bfv_square if scheme == 1 else L.ref_ckks_square
         for c in range(count):
-            assert mul(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(a[c]), 2, O.ptr(exps[c])) == 0
+            assert sqr(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(exps[c])) == 0  # evaluator.cpp:560-770 restated
+            assert mul(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(a[c]), 2, O.ptr(exps2[c])) == 0  # cross-check
+        assert np.array_equal(exps, exps2), "oracle: square vs multiply(a, a) k=%d" % k
         assert np.array_equal(sq.download(exps.shape), exps), "square k=%d" % k
         ev.relinearize_inplace(out, 3, k, count, [dkey])
         keys = (C.c_void_p * 1)(key.ctypes.data)
@@ -910,6 +914,45 @@ def test_shortcut_boundaries_largest_admitted_primes(sealhip, scheme, logn, bits
         for i in range(k):
             L.ref_ntt_forward(O.ptr(e[c, i]), C.byref(tabs[i].t), 0)
     assert np.array_equal(buf.download(x.shape), e), "forward"
+
+
+@pytest.mark.parametrize("scheme,logn,bits", [(1, 15, [55] * 4), (1, 14, [50] * 3 + [58]), (1, 16, [50] * 3), (1, 12, [36, 36, 37]),
+                                              (1, 15, [59, 59, 59]), (2, 15, [50] * 4), (2, 13, [40, 40, 41])])
+def test_square_is_its_own_path(sealhip, scheme, logn, bits):
+    """Evaluator::square (evaluator.cpp:528-558) -> bfv_square (:560-702) / ckks_square (:704-770): a size-2 operand is
+    lifted and transformed once and c_1 = x_0 x_1 is added to itself; other sizes go through multiply. The engine's path
+    (two lifts / 2 (k + |Bsk|) forward rows, the doubling inside the fused inverse load or the tensor kernel) against the
+    oracle's branch-by-branch restatement, with multiply(a, a) as the cross-check on both sides, extreme values included
+    (all p-1: the doubled product is the largest lazy value the inverse is handed)."""
+    n, t = 1 << logn, 786433
+    kmods = O.coeff_modulus_create(n, bits)
+    k = len(kmods) - 1
+    ctx = sealhip.Context(scheme, logn, kmods, 1, t if scheme == 1 else 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(scheme, logn, kmods, nsp=1, t=t if scheme == 1 else 0)
+    rng = np.random.default_rng(7 * logn + scheme)
+    mul = L.ref_bfv_multiply if scheme == 1 else L.ref_ckks_multiply
+    sqr = L.ref_bfv_square if scheme == 1 else L.ref_ckks_square
+    for size in (2, 3):
+        a = np.stack([rand_rows(rng, kmods[:k] * size, n).reshape(size, k, n) for _ in range(3)])
+        for i, p in enumerate(kmods[:k]):
+            a[0, :, i, :] = p - 1
+            a[1, 0, i, ::2] = p - 1
+        count, dest = a.shape[0], 2 * size - 1
+        out = ctx.alloc(count * dest * k * n)
+        ev.square(ctx.upload(a), size, k, count, out)
+        got = out.download((count, dest, k, n))
+        out2 = ctx.alloc(count * dest * k * n)
+        da = ctx.upload(a)
+        ev.multiply(da, size, ctx.upload(a), size, k, count, out2)
+        for c in range(count):
+            exp = np.zeros((dest, k, n), dtype=np.uint64)
+            assert sqr(C.byref(ref.c), k, O.ptr(a[c]), size, O.ptr(exp)) == 0
+            assert np.array_equal(got[c], exp), "square size=%d item %d" % (size, c)
+            exp2 = np.zeros((dest, k, n), dtype=np.uint64)
+            assert mul(C.byref(ref.c), k, O.ptr(a[c]), size, O.ptr(a[c]), size, O.ptr(exp2)) == 0
+            assert np.array_equal(exp, exp2), "oracle: square vs multiply(a, a)"
+        assert np.array_equal(out2.download(got.shape), got), "engine: multiply(a, a) vs square"
 
 
 @pytest.mark.parametrize("k_first", [3, 7, 9])

@@ -337,6 +337,38 @@ def test_digest_end_to_end(row):
     assert got == row["digests"]
 
 
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_square_restatement_is_pinned_through_multiply(cfg):
+    """oracle ref_bfv_square / ref_ckks_square restate evaluator.cpp:560-702 / :704-770 branch by branch. The reference holds
+    no known answer for square on raw inputs (its Evaluator tests encrypt first), so the restatement is pinned through the
+    function the survey's digests DO pin: on the digest inputs of config 1 (BFV) and config 2 (CKKS) square(a) must equal
+    multiply(a, a) word for word (2 x_0 x_1 mod p == x_0 x_1 + x_1 x_0 mod p; the canonicalising inverse of :663-664 against
+    the lazy one of :423-424 leaves the same residues), and multiply(a, b) reproduces the reference's digest. A size-3
+    operand takes the multiply branch (:579-583, :720-724)."""
+    import synth
+
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == cfg][0]
+    inp = synth.end_to_end_inputs(row)
+    n, k, logn = inp["n"], inp["k"], inp["logn"]
+    ref = O.RefContext(row["scheme"], logn, inp["kmods"], nsp=row["nsp"], t=row["t"])
+    mul = L.ref_bfv_multiply if row["scheme"] == 1 else L.ref_ckks_multiply
+    sqr = L.ref_bfv_square if row["scheme"] == 1 else L.ref_ckks_square
+    a, b = inp["a"], inp["b"]
+    out = np.zeros((3, k, n), dtype=np.uint64)
+    assert mul(C.byref(ref.c), k, O.ptr(a), 2, O.ptr(b), 2, O.ptr(out)) == 0
+    assert h(out) == row["digests"]["mul"]  # the pin
+    for x in (a, b):
+        s1, s2 = np.zeros_like(out), np.zeros_like(out)
+        assert sqr(C.byref(ref.c), k, O.ptr(x), 2, O.ptr(s1)) == 0
+        assert mul(C.byref(ref.c), k, O.ptr(x), 2, O.ptr(x), 2, O.ptr(s2)) == 0
+        assert np.array_equal(s1, s2)
+    x3 = np.concatenate([a, b[:1]])
+    s1, s2 = np.zeros((5, k, n), dtype=np.uint64), np.zeros((5, k, n), dtype=np.uint64)
+    assert sqr(C.byref(ref.c), k, O.ptr(x3), 3, O.ptr(s1)) == 0
+    assert mul(C.byref(ref.c), k, O.ptr(x3), 3, O.ptr(x3), 3, O.ptr(s2)) == 0
+    assert np.array_equal(s1, s2)
+
+
 def test_small_vectors_regression():
     """The committed full small-N vectors (made by the pinned oracle) still come out of the oracle word for word."""
     import subprocess

@@ -1,4 +1,4 @@
-"""Absolute kernel times (HIP events) of one step: tools/step_profile.py [batch] [cfg1|cfg3|cfg4|cfg4mul|cfg5]
+"""Absolute kernel times (HIP events) of one step: tools/step_profile.py [batch] [cfg1|cfg3|cfg3sq|cfg4|cfg4mul|cfg5]
 cfg1 / cfg3 / cfg5: BFV multiply+relinearize at that config (cfg5: + mod_switch_to_next); cfg4: CKKS rotate_vector at
 config 4; cfg4mul: CKKS multiply+relinearize. Run it under rocprofv3 --kernel-trace to see what the tags do not cover."""
 import os, sys
@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 which = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 n = 1 << 15
-if which == "cfg3":
+if which in ("cfg3", "cfg3sq"):
     k, pr = 7, bench.CFG3_PRIMES
     ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433)
 elif which == "cfg1":
@@ -33,7 +33,11 @@ def step():
     if which == "cfg4":
         ev.rotate_vector_inplace(x, k, B, 1, {elt: rk})
     else:
-        ev.multiply(x, 2, y, 2, k, B, o); ev.relinearize_inplace(o, 3, k, B, [rk])
+        if which == "cfg3sq":
+            ev.square(x, 2, k, B, o)
+        else:
+            ev.multiply(x, 2, y, 2, k, B, o)
+        ev.relinearize_inplace(o, 3, k, B, [rk])
         if which == "cfg5":
             ev.mod_switch_to_next(o.view(B, 3, k, n)[:, :2].contiguous(), 2, k, B, o2)
 step(); ctx.synchronize()
