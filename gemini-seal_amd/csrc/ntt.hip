@@ -558,8 +558,18 @@ namespace sealhip
                 }
                 else if (fin & 1)
                 {
-                    v.x = v.x >= two_p ? v.x - two_p : v.x;
-                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    if constexpr (STRICT == 2)
+                    {
+                        // canonical output of the approximate-quotient schedule (values below 50p, ntt_bounds.hpp section 2):
+                        // one Barrett step to [0, 2p), one conditional subtraction
+                        v.x = barrett_lazy_hs(v.x, rdp, neg_p);
+                        v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                    }
+                    else
+                    {
+                        v.x = v.x >= two_p ? v.x - two_p : v.x;
+                        v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    }
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
@@ -687,8 +697,18 @@ namespace sealhip
                 }
                 else if (fin & 1)
                 {
-                    v.x = v.x >= two_p ? v.x - two_p : v.x;
-                    v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    if constexpr (STRICT == 2)
+                    {
+                        // canonical output of the approximate-quotient schedule (values below 50p, ntt_bounds.hpp section 2):
+                        // one Barrett step to [0, 2p), one conditional subtraction
+                        v.x = barrett_lazy_hs(v.x, rdp, neg_p);
+                        v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                    }
+                    else
+                    {
+                        v.x = v.x >= two_p ? v.x - two_p : v.x;
+                        v.y = v.y >= two_p ? v.y - two_p : v.y;
+                    }
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
@@ -2177,6 +2197,20 @@ namespace sealhip
                        red != 4 && red != 5 && red != 7;
             for (int i = 0; apx && i < live.n; i++)
                 apx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
+            // The canonicalising wrapper (ntt.h:225-246) on primes with head-room: the canonical residue does not depend on
+            // the representatives the layers pass on, so an in-place canonical transform runs the cheapest exact schedule --
+            // approximate quotient, no Barrett step in the last layer, values below (3 log n + 1) p (ntt_bounds.hpp section 2)
+            // -- and canonicalises with one Barrett step as it stores. SEALHIP_NTT_CANON_EXACT=1: the reference's sequence.
+            static const bool canon_exact = std::getenv("SEALHIP_NTT_CANON_EXACT") != nullptr;
+            bool capx = !no_apx && !canon_exact && !fp && red == 0 && (flags & kNttCanonical) != 0 &&
+                        (flags & (kNttStrict | kNttReduceOut)) == 0;
+            for (int i = 0; capx && i < live.n; i++)
+                capx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
+            if (capx)
+            {
+                apx = true;
+                flags |= kNttAnyRep;
+            }
             if (red == 7 && (!fp || !kStoreExchange<T, 3, 7>))
                 return hipErrorInvalidValue; // ntt_can_fuse_moddown said no: the caller runs moddown_post itself
             if (fp && (red == 4 || red == 5 || red == 7))

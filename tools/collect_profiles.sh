@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the round's rocprofv3 evidence for bench.py, written under gpurun_out/<tag>/ so that it is
 # merged back; copy what is to be judged into profiles/<round>/ afterwards.
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/${tag}_profiles
 mkdir -p $out
@@ -16,8 +16,12 @@ cd $root && python3 bench.py --measure-traffic --steps 3 --warmup 1 > $out/bench
 cp $root/profiles/traffic.json $out/traffic.json 2>/dev/null
 # 3. the plain default run (what the driver runs), with the CPU baseline
 python3 bench.py > $out/bench_default.jsonl 2> $out/bench_default.err
-# 4. other configs and the boundary measurements
-python3 tools/bench_configs.py > $out/configs_1gpu.jsonl 2> $out/configs_1gpu.err
+# 4. other configs: BASELINE lines 4 and 5 through bench.py itself (round 3), configs 1 and 2 through tools/bench_configs.py
+python3 bench.py --config 4 > $out/bench_cfg4.jsonl 2> $out/bench_cfg4.err
+python3 bench.py --config 5 > $out/bench_cfg5.jsonl 2> $out/bench_cfg5.err
+python3 tools/bench_configs.py --only cfg1,cfg2 > $out/configs_1gpu.jsonl 2> $out/configs_1gpu.err
+# 4b. the multi-rank path on the real backend with one rank (RCCL collectives incl. the gather to self)
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29579 bench.py --gpus 1 --force-dist --no-cpu-baseline --ntt-polys 0 > $out/bench_force_dist.jsonl 2> $out/bench_force_dist.err
 python3 tools/ntt_only.py --polys 4096 > $out/ntt_only.txt 2>&1
 python3 tools/ntt_only.py --polys 4096 --inverse >> $out/ntt_only.txt 2>&1
 python3 tools/ntt_only.py --logn 14 --polys 1024 >> $out/ntt_only.txt 2>&1
@@ -25,6 +29,7 @@ python3 tools/ntt_only.py --logn 14 --polys 1024 --inverse >> $out/ntt_only.txt 
 python3 tools/ntt_only.py --logn 16 --polys 512 >> $out/ntt_only.txt 2>&1
 python3 tools/ntt_only.py --logn 16 --polys 512 --inverse >> $out/ntt_only.txt 2>&1
 python3 tools/step_profile.py 1024 > $out/step_profile_b1024.txt 2>&1
+python3 tools/step_profile.py 1024 cfg3sq 2>&1 | grep "^cfg" >> $out/step_profile_b1024.txt
 python3 tools/step_profile.py 1024 cfg4 2>&1 | grep "^cfg" > $out/step_profile_side_configs.txt
 python3 tools/step_profile.py 1024 cfg4mul 2>&1 | grep "^cfg" >> $out/step_profile_side_configs.txt
 python3 tools/step_profile.py 256 cfg5 2>&1 | grep "^cfg" >> $out/step_profile_side_configs.txt
