@@ -797,6 +797,42 @@ long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, 
 
 namespace
 {
+    // Transparency as a flag output (sealhip_transparency_sink): an Evaluator entry clears the flags of its batch, then either
+    // lets the final kernel of the operation write them (fused: multiply, square, relinearize, apply_galois) or runs the
+    // read pass over its result (the remaining entries).
+    struct SinkScope
+    {
+        Engine &e;
+        Lane &l;
+        bool on;
+        SinkScope(Engine &eng, size_t count, bool fused) : e(eng), l(eng.lane()), on(l.tsink != nullptr)
+        {
+            if (!on)
+                return;
+            if (count > l.tsink_cap)
+                throw std::invalid_argument("the transparency sink is smaller than this batch");
+            if (count)
+                SEALHIP_CHECK(hipMemsetAsync(l.tsink, 0, count * sizeof(unsigned), l.stream));
+            l.tsink_base = 0;
+            l.tsink_cur = fused ? l.tsink : nullptr;
+        }
+        void arm() // (relinearize: only its last key switch stores the final polynomial 1)
+        {
+            if (on)
+                l.tsink_cur = l.tsink;
+        }
+        void read_pass(const u64 *result, uint32_t size, size_t poly_words, size_t count)
+        {
+            if (on && size >= 2 && count)
+                check_launch(launch_nonzero_tail(e, result, poly_words * size, poly_words, count, l.tsink), "transparency");
+        }
+        ~SinkScope()
+        {
+            l.tsink_cur = l.tsink_arm = nullptr;
+            l.tsink_base = 0;
+        }
+    };
+
     // Evaluator::multiply (evaluator.cpp:235-527) on device batches
     void do_multiply(Engine &e, uint32_t k, const u64 *a, uint32_t size_a, const u64 *b, uint32_t size_b, size_t count, u64 *out)
     {
@@ -814,7 +850,7 @@ namespace
 
     // relinearize_internal (evaluator.cpp:772-827) on a device batch
     void do_relinearize(Engine &e, uint32_t k, u64 *p, uint32_t size, size_t count, const sealhip_kswitch_key *const *relin_keys,
-                        uint32_t n_relin_keys)
+                        uint32_t n_relin_keys, SinkScope *sink = nullptr)
     {
         check_level(e, k);
         if (size < 2 || size > 16)
@@ -831,6 +867,8 @@ namespace
             const sealhip_kswitch_key *key = relin_keys[key_power - 2];
             if (!key)
                 throw std::invalid_argument("not enough relinearization keys");
+            if (sink && I + 3 == size)
+                sink->arm(); // the last key switch stores the final polynomial 1
             op_switch_key(e, static_cast<int>(k), p, size * poly, p + (size - 1) * poly, size * poly, count, key->key);
         }
     }
@@ -902,6 +940,7 @@ long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
+        SinkScope sink(e, count, true);
         do_multiply(e, k, reinterpret_cast<const u64 *>(a), size_a, reinterpret_cast<const u64 *>(b), size_b, count,
                     reinterpret_cast<u64 *>(out));
     });
@@ -924,6 +963,7 @@ long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *
         if (out == a)
             throw std::invalid_argument("out must not alias the operand");
         const u64 *pa = reinterpret_cast<const u64 *>(a);
+        SinkScope sink(e, count, true);
         if (e.scheme == 1)
             op_bfv_square(e, static_cast<int>(k), pa, static_cast<int>(size_a), count, reinterpret_cast<u64 *>(out));
         else
@@ -938,7 +978,10 @@ long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *c
     REQUIRE_PTR(ct);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        do_relinearize(e, k, reinterpret_cast<u64 *>(ct), size, count, relin_keys, n_relin_keys);
+        SinkScope sink(e, count, false);
+        do_relinearize(e, k, reinterpret_cast<u64 *>(ct), size, count, relin_keys, n_relin_keys, &sink);
+        if (size == 2) // nothing was done (evaluator.cpp:798-802): the flags describe the input
+            sink.read_pass(reinterpret_cast<const u64 *>(ct), 2, static_cast<std::size_t>(k) * e.n, count);
     });
 }
 
@@ -1176,7 +1219,9 @@ long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, cons
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
+        SinkScope sink(e, count, false);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false);
+        sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
 }
 
@@ -1188,7 +1233,9 @@ long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const u
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
+        SinkScope sink(e, count, false);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), true);
+        sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
 }
 
@@ -1201,6 +1248,7 @@ long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *
     return guarded([&] {
         Engine &e = device_engine(ctx);
         check_level(e, k);
+        SinkScope sink(e, count, true);
         op_apply_galois(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), count, galois_elt, galois_key->key);
     });
 }
@@ -1232,10 +1280,12 @@ long sealhip_evaluator_negate(sealhip_context *ctx, uint32_t k, const uint64_t *
         check_level(e, k);
         if (size < 1)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        SinkScope sink(e, count, false);
         check_launch(launch_ct_linear(e, CtLinearOp::Negate, reinterpret_cast<const u64 *>(ct), static_cast<int>(size),
                                       nullptr, 0, 0, reinterpret_cast<u64 *>(out), count,
                                       e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
                      "negate");
+        sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k) * e.n, count);
     });
 }
 
@@ -1255,10 +1305,12 @@ static long add_sub_entry(sealhip_context *ctx, uint32_t k, const uint64_t *a, u
         // encrypted1 first, evaluator.cpp:131-132; a raw buffer cannot grow)
         if (out == a && size_b > size_a)
             throw std::invalid_argument("in-place result needs a destination of max(size_a, size_b) polynomials");
+        SinkScope sink(e, count, false);
         check_launch(launch_ct_linear(e, sub ? CtLinearOp::Sub : CtLinearOp::Add, reinterpret_cast<const u64 *>(a),
                                       static_cast<int>(size_a), reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), 0,
                                       reinterpret_cast<u64 *>(out), count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
                      sub ? "sub" : "add");
+        sink.read_pass(reinterpret_cast<const u64 *>(out), std::max(size_a, size_b), static_cast<std::size_t>(k) * e.n, count);
     });
 }
 
@@ -1291,6 +1343,8 @@ long sealhip_evaluator_multiply_plain_ntt(sealhip_context *ctx, uint32_t k, uint
                                       reinterpret_cast<const u64 *>(plain_ntt), 0, plain_stride, reinterpret_cast<u64 *>(ct),
                                       count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
                      "multiply_plain_ntt");
+        SinkScope sink(e, count, false); // (clears, then reads the result: nothing in between)
+        sink.read_pass(reinterpret_cast<const u64 *>(ct), size, static_cast<std::size_t>(k) * e.n, count);
     });
 }
 
@@ -1309,6 +1363,23 @@ long sealhip_evaluator_multiply_plain(sealhip_context *ctx, uint32_t k, uint64_t
             throw std::invalid_argument("plain_stride is smaller than one plaintext");
         op_multiply_plain(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), static_cast<int>(size), count,
                           reinterpret_cast<const u64 *>(plain), plain_stride);
+        SinkScope sink(e, count, false);
+        sink.read_pass(reinterpret_cast<const u64 *>(ct), size, static_cast<std::size_t>(k) * e.n, count);
+    });
+}
+
+long sealhip_transparency_sink(sealhip_context *ctx, uint32_t *nonzero_flags, size_t capacity)
+{
+    REQUIRE_PTR(ctx);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        Lane &l = e.lane();
+        if (nonzero_flags && capacity == 0)
+            throw std::invalid_argument("a transparency sink needs room for at least one ciphertext");
+        static_assert(sizeof(unsigned) == sizeof(uint32_t), "flag words");
+        l.tsink = reinterpret_cast<unsigned *>(nonzero_flags);
+        l.tsink_cap = nonzero_flags ? capacity : 0;
+        l.tsink_cur = l.tsink_arm = nullptr;
     });
 }
 
@@ -1365,7 +1436,10 @@ long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t 
     }
     return guarded([&] {
         Engine &e = device_engine(ctx);
+        // (the NAF fallback applies several automorphisms: the flags are read off the final ciphertext)
+        SinkScope sink(e, count, false);
         do_rotate(e, k, reinterpret_cast<u64 *>(ct), count, steps, galois_elts, galois_keys, n_keys);
+        sink.read_pass(reinterpret_cast<const u64 *>(ct), 2, static_cast<std::size_t>(k) * e.n, count);
     });
 }
 

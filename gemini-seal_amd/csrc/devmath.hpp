@@ -93,6 +93,17 @@ namespace sealhip
         yb = fp_bits(fp_mulmod(u - y, fp_of(wb), p, pinv));
     }
 
+    // Transparency sink (Ciphertext::is_transparent, ciphertext.h:471-476; checked after every Evaluator operation when
+    // SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT is defined, evaluator.cpp:265-271): tflags[item] becomes non-zero iff some word of
+    // polynomials 1.. of the item's result is non-zero. The LAST kernel of multiply / relinearize / apply_galois notes it
+    // for the words it stores anyway -- no separate read pass over the result. `nz` is the OR of the lane's words of
+    // polynomials 1..; the flag is only written while it is still zero (benign race: every writer stores 1).
+    __device__ __forceinline__ void note_nonzero(unsigned *__restrict__ tflags, std::size_t item, u64 nz)
+    {
+        if (tflags != nullptr && nz != 0 && tflags[item] == 0)
+            tflags[item] = 1;
+    }
+
     // streaming stores (nontemporal hint): outputs that the producing kernel does not read again should not push the
     // constant tables (twiddles, key slices) out of L2
     __device__ __forceinline__ void store_stream(u64 *p, u64 v)

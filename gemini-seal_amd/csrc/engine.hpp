@@ -65,6 +65,7 @@ namespace sealhip
             std::size_t ct_stride;
             const u64 *c0_src;              // optional, [m][c0_stride]
             std::size_t c0_stride;
+            unsigned *tflags;               // optional transparency sink of the m ciphertexts (devmath.hpp note_nonzero)
         } md;
     };
     constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
@@ -233,6 +234,15 @@ namespace sealhip
         std::vector<ProfRecord> prof;
         unsigned *d_tickets = nullptr; // per-row tickets of the single-pass forward NTT
         std::size_t tickets_cap = 0;
+        // Transparency sink (sealhip_transparency_sink): device flags, one word per ciphertext of the operation's batch.
+        // tsink_cur is what the final kernel of the operation in flight writes to (null outside an Evaluator entry that
+        // supports it: internal launches of composite operations must not touch the caller's flags)
+        unsigned *tsink = nullptr, *tsink_cur = nullptr;
+        std::size_t tsink_cap = 0;
+        // ... and what the NEXT launch of a sink-capable final kernel writes to (set by pipeline.cpp's SinkArm around exactly
+        // that launch: the chunk's first item of tsink_cur)
+        unsigned *tsink_arm = nullptr;
+        std::size_t tsink_base = 0; // first item of an enclosing chunk loop (op_apply_galois around op_switch_key)
         // Sticky failure flag of this lane's launches (today: the forward NTT's sibling hand-off timing out), one word of
         // host-mapped memory per lane: a time-out in one thread's launch must fail THAT thread's next host-visible point,
         // not be seen and cleared by another thread's
@@ -434,6 +444,8 @@ namespace sealhip
     // batches of ciphertexts [count][size][k][N]; b_item_stride only for MulPlain (0 = one plaintext for all)
     hipError_t launch_ct_linear(const Engine &e, CtLinearOp op, const u64 *a, int sa, const u64 *b, int sb,
                                 std::size_t b_item_stride, u64 *out, std::size_t count, const RowMap &map);
+    hipError_t launch_nonzero_words(const Engine &e, const u64 *data, std::size_t item_stride, std::size_t words,
+                                    std::size_t count, unsigned *flags);
     hipError_t launch_nonzero_tail(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t skip_words,
                                    std::size_t count, unsigned *flags);
     hipError_t launch_out_of_range(const Engine &e, const u64 *ct, std::size_t item_words, std::size_t count,

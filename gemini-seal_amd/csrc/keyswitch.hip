@@ -271,7 +271,7 @@ namespace sealhip
                                                                            std::size_t ct_item_stride,
                                                                            std::size_t npolys, int logn,
                                                                            int add_into_ct, const u64 *__restrict__ c0_src,
-                                                                           std::size_t c0_stride)
+                                                                           std::size_t c0_stride, unsigned *__restrict__ tflags)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn;
             const int k = d->k;
@@ -290,10 +290,14 @@ namespace sealhip
             {
                 // polynomial `poly` is component (poly & 1) of ciphertext (poly >> 1)
                 u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
+                u64 w;
                 if (!c0_src)
-                    *pc = add_mod(v, *pc, Q.p);
+                    w = add_mod(v, *pc, Q.p);
                 else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
-                    *pc = (poly & 1) ? v : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c], Q.p);
+                    w = (poly & 1) ? v : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c], Q.p);
+                *pc = w;
+                if (poly & 1)
+                    note_nonzero(tflags, poly >> 1, w);
             }
             else
                 *pp = v;
@@ -333,7 +337,7 @@ namespace sealhip
                                                                           std::size_t prod_stride, u64 *__restrict__ ct,
                                                                           std::size_t ct_item_stride, std::size_t npolys,
                                                                           int logn, const u64 *__restrict__ c0_src,
-                                                                          std::size_t c0_stride)
+                                                                          std::size_t c0_stride, unsigned *__restrict__ tflags)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn, half = N >> 1;
             const int k = d->k, nsp = d->nsp;
@@ -382,17 +386,22 @@ namespace sealhip
             u64 pv[2];
             row_pair<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q, pv[0], pv[1]);
             u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
+            u64 nz = 0;
 #pragma unroll
             for (int h = 0; h < 2; h++)
             {
                 const u64 v = mulmod_shoup(pv[h] + temp[h], d->invP[q], d->invP_shoup[q], Q.p);
+                u64 w;
                 if (!c0_src)
-                    pc[h * half] = add_mod(v, pc[h * half], Q.p);
+                    w = add_mod(v, pc[h * half], Q.p);
                 else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
-                    pc[h * half] = (poly & 1) ? v
-                                              : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c + h * half],
-                                                        Q.p);
+                    w = (poly & 1) ? v
+                                   : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c + h * half], Q.p);
+                pc[h * half] = w;
+                nz |= w;
             }
+            if (poly & 1) // component 1 of ciphertext poly >> 1: what is_transparent looks at
+                note_nonzero(tflags, poly >> 1, nz);
         }
 
         inline unsigned blocks_for(std::size_t lanes)
@@ -499,10 +508,10 @@ namespace sealhip
         ProfScope prof(e, "ks_moddown_bfv", 0);
         if (top_deferred)
             ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride);
+                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride, e.lane().tsink_arm);
         else
             ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride);
+                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride, e.lane().tsink_arm);
         return hipGetLastError();
     }
 
@@ -516,7 +525,8 @@ namespace sealhip
         const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << e.logn;
         ProfScope prof(e, "ks_moddown_post", 0);
         ks_moddown_post_kernel<<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-            d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct, c0_src, c0_stride);
+            d, e.d_primes, prod, prod_stride, temp, temp_stride, ct, ct_item_stride, npolys, e.logn, add_into_ct, c0_src, c0_stride,
+            add_into_ct ? e.lane().tsink_arm : nullptr);
         return hipGetLastError();
     }
 } // namespace sealhip

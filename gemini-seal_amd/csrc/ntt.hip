@@ -1085,9 +1085,10 @@ namespace sealhip
         template <int T>
         __device__ __forceinline__ void h_store_moddown(const u64 (&x)[32], int tid, const u64 *__restrict__ prod_half,
                                                         u64 *__restrict__ ct_half, const u64 *__restrict__ c0_half, bool add_ct,
-                                                        u64 inv_p, u64 inv_p_shoup, u64 p)
+                                                        u64 inv_p, u64 inv_p_shoup, u64 p, unsigned *__restrict__ tflag)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
+            u64 nz = 0; // transparency sink: OR of the words stored into component 1 (tflag is null for component 0)
 #pragma unroll
             for (int b = 0; b < 32; b += 8)
             {
@@ -1114,8 +1115,10 @@ namespace sealhip
                         v1 = add_mod(v1, cc[i].y, p);
                     }
                     store_nt(ct_half + off, v0, v1);
+                    nz |= v0 | v1;
                 }
             }
+            note_nonzero(tflag, 0, nz);
         }
 
         template <int LOGN, int STRICT, int REDUCE>
@@ -1280,7 +1283,8 @@ namespace sealhip
                     u64 *ct_half = src.md.ct + (pl >> 1) * src.md.ct_stride + (((pl & 1) * map.rows + q) << LOGN) + gbase;
                     const u64 *c0_half =
                         (src.md.c0_src && !(pl & 1)) ? src.md.c0_src + (pl >> 1) * src.md.c0_stride + (q << LOGN) + gbase : nullptr;
-                    h_store_moddown<T>(x, fresh(tid), prod_half, ct_half, c0_half, src.md.c0_src == nullptr, ip, ips, P.p);
+                    h_store_moddown<T>(x, fresh(tid), prod_half, ct_half, c0_half, src.md.c0_src == nullptr, ip, ips, P.p,
+                                       (src.md.tflags && (pl & 1)) ? src.md.tflags + (pl >> 1) : nullptr);
                 }
                 else
                     h_store_rows<T>(x, rowp + gbase, fresh(tid));

@@ -85,6 +85,29 @@ namespace sealhip
         return (w_coeff + nd * rows * N + 2 * rows * N + 2 * static_cast<std::size_t>(k) * N) * sizeof(u64);
     }
 
+    namespace
+    {
+        // Transparency sink (devmath.hpp note_nonzero): the sink of the operation in flight, shifted to a chunk's first
+        // item, and the scope around the ONE launch that stores the result's polynomials 1..
+        unsigned *sink_at(Engine &e, std::size_t off)
+        {
+            Lane &l = e.lane();
+            return l.tsink_cur ? l.tsink_cur + l.tsink_base + off : nullptr;
+        }
+        struct SinkArm
+        {
+            Lane &l;
+            SinkArm(Engine &e, unsigned *flags) : l(e.lane())
+            {
+                l.tsink_arm = flags;
+            }
+            ~SinkArm()
+            {
+                l.tsink_arm = nullptr;
+            }
+        };
+    } // namespace
+
     // ------------------------------------------------------------------------------------------
     // switch_key_inplace (evaluator.cpp:2259-2368)
     // ------------------------------------------------------------------------------------------
@@ -226,6 +249,7 @@ namespace sealhip
                 const bool defer = ntt_can_defer_top(e, k);
                 // (ks_moddown_bfv reduces what it reads canonically: any representative below 2p will do)
                 check(launch_ntt(e, prod, m * 2 * rows, map_rows, true, (defer ? kNttDeferTop : 0) | kNttAnyRep), "intt(prod)");
+                SinkArm arm(e, sink_at(e, off)); // (component 1 of the m ciphertexts of this chunk)
                 check(launch_ks_moddown_bfv(e, lt.d_ks, h, prod, ext_item, ctp, ct_stride, 2 * m, defer, c0p, c0_stride),
                       "moddown_bfv");
                 continue;
@@ -269,6 +293,7 @@ namespace sealhip
                     ns.md.ct_stride = ct_stride;
                     ns.md.c0_src = c0p;
                     ns.md.c0_stride = c0_stride;
+                    ns.md.tflags = sink_at(e, off);
                 }
                 ns.aux_p = p_special;
                 ns.aux_cr1 = HostModulus(p_special).cr1;
@@ -294,9 +319,12 @@ namespace sealhip
                     check(launch_ntt(e, prod, m * 2 * rows, skip_map(map_rows, 0, k), true, kNttAnyRep), "intt(prod)");
             }
             if (!fold_store)
+            {
+                SinkArm arm(e, sink_at(e, off));
                 check(launch_ks_moddown_post(e, lt.d_ks, h, prod, ext_item, temp, static_cast<std::size_t>(k) * N, ctp,
                                              ct_stride, 2 * m, 1, c0p, c0_stride),
                       "moddown_post");
+            }
         }
     }
 
@@ -443,9 +471,12 @@ namespace sealhip
                       "intt(tensor, q rows)");
                 check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop, sq), "intt(tensor, Bsk rows)");
                 for (int I = 0; I < dest; I++)
+                {
+                    SinkArm arm(e, I >= 1 ? sink_at(e, off) : nullptr); // polynomials 1.. of the product
                     check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
                                               dest * poly_q, m, 2),
                           "floor_sk");
+                }
                 continue;
             }
             // step (4) (:376-420)
@@ -469,9 +500,12 @@ namespace sealhip
                 check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, kNttCanonical), "intt(D)");
             // steps (6)-(8) (:427-444)
             for (int I = 0; I < dest; I++)
+            {
+                SinkArm arm(e, I >= 1 ? sink_at(e, off) : nullptr);
                 check(launch_bfv_floor_sk(e, lt.d_rns, h, D + I * poly_x, w_d, out + off * dest * poly_q + I * poly_q,
                                           dest * poly_q, m, defer ? 1 : 0),
                       "floor_sk");
+            }
         }
     }
 
@@ -494,6 +528,7 @@ namespace sealhip
     {
         LevelTools &lt = e.level(k);
         const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        SinkArm arm(e, sink_at(e, 0));
         check(launch_tensor_product(e, a, sa, sa * poly, b, sb, sb * poly, out, (sa + sb - 1) * poly, count, lt.map_q),
               "tensor");
     }
@@ -609,6 +644,15 @@ namespace sealhip
             // The reference copies galois(c0) back (:1903 / :1917), zeroes c1 (:1928) and lets the key switch add its two
             // polynomials into that ciphertext (:1934-1935). Here the key switch's last kernel writes (galois(c0) + r0, r1)
             // directly: same sums, no copy pass and no fill pass over the ciphertext.
+            e.lane().tsink_base = off; // (the nested chunk loop counts its items from this chunk's first ciphertext)
+            struct BaseReset
+            {
+                Lane &l;
+                ~BaseReset()
+                {
+                    l.tsink_base = 0;
+                }
+            } base_reset{ e.lane() };
             op_switch_key(e, k, c, 2 * poly, scratch + poly, 2 * poly, m, key, scratch, 2 * poly);
         }
     }

@@ -64,7 +64,7 @@ namespace sealhip
         __global__ __launch_bounds__(kThreads) void tensor_product_kernel(
             const u64 *__restrict__ a, int sa, std::size_t a_stride, const u64 *__restrict__ b, int sb,
             std::size_t b_stride, u64 *__restrict__ out, std::size_t out_stride, const PrimeDev *__restrict__ primes,
-            RowMap map, int logn, std::size_t npairs_per_item, std::size_t count)
+            RowMap map, int logn, std::size_t npairs_per_item, std::size_t count, unsigned *__restrict__ tflags)
         {
             const std::size_t total = npairs_per_item * count;
             const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
@@ -95,6 +95,7 @@ namespace sealhip
                     *reinterpret_cast<ulonglong2 *>(po) = c0;
                     *reinterpret_cast<ulonglong2 *>(po + poly_words) = c1;
                     *reinterpret_cast<ulonglong2 *>(po + 2 * poly_words) = c2;
+                    note_nonzero(tflags, item, c1.x | c1.y | c2.x | c2.y);
                     continue;
                 }
                 if (sa == 2 && sb == 2)
@@ -113,6 +114,7 @@ namespace sealhip
                     *reinterpret_cast<ulonglong2 *>(po) = c0;
                     *reinterpret_cast<ulonglong2 *>(po + poly_words) = c1;
                     *reinterpret_cast<ulonglong2 *>(po + 2 * poly_words) = c2;
+                    note_nonzero(tflags, item, c1.x | c1.y | c2.x | c2.y);
                     continue;
                 }
                 const int dest = sa + sb - 1;
@@ -133,6 +135,8 @@ namespace sealhip
                         acc.y = add_mod(mul_mod(va.y, vb.y, P.p, P.cr0, P.cr1), acc.y, P.p);
                     }
                     *reinterpret_cast<ulonglong2 *>(po + I * poly_words) = acc;
+                    if (I >= 1)
+                        note_nonzero(tflags, item, acc.x | acc.y);
                 }
             }
         }
@@ -392,7 +396,7 @@ namespace sealhip
             return hipSuccess;
         ProfScope prof(e, "tensor_product", 0);
         tensor_product_kernel<<<grid_for(pairs * count), kThreads, 0, e.lane().stream>>>(
-            a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count);
+            a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count, e.lane().tsink_arm);
         return hipGetLastError();
     }
 
@@ -483,6 +487,21 @@ namespace sealhip
                                                                 pairs, count);
             break;
         }
+        return hipGetLastError();
+    }
+
+    // flags[item] |= "some word of [data + item * item_stride, + words) is non-zero" (the read pass the fused kernels avoid)
+    hipError_t launch_nonzero_words(const Engine &e, const u64 *data, std::size_t item_stride, std::size_t words,
+                                    std::size_t count, unsigned *flags)
+    {
+        if (words == 0 || count == 0)
+            return hipSuccess;
+        if (words > item_stride)
+            return hipErrorInvalidValue;
+        ProfScope prof(e, "nonzero_tail", 0);
+        // (item_words = stride, skip = stride - words, base shifted back so that the tail is [data, data + words))
+        nonzero_tail_kernel<<<grid_for(words / 2 * count), kThreads, 0, e.lane().stream>>>(
+            data - (item_stride - words), item_stride, item_stride - words, count, flags);
         return hipGetLastError();
     }
 

@@ -308,7 +308,7 @@ namespace sealhip
                                                                          const u64 *__restrict__ in,
                                                                          std::size_t in_stride, u64 *__restrict__ out,
                                                                          std::size_t out_stride, std::size_t count,
-                                                                         int logn, int mont)
+                                                                         int logn, int mont, unsigned *__restrict__ tflags)
         {
             constexpr int KA = KMAX < 0 ? -KMAX : KMAX;
             const std::size_t N = static_cast<std::size_t>(1) << logn;
@@ -481,6 +481,7 @@ namespace sealhip
             const auto *pBm = kc(d->pBm);
             const auto *nBm = kc(d->nBm);
             const auto *BtoQ = kc(d->B_to_qm);
+            u64 nz = 0; // OR of the words this column stores (transparency sink)
             const auto q_row = [&](int i) {
                 const u64 c = neg ? pBm[i] : nBm[i];
                 const auto *mrow = BtoQ + i * B;
@@ -505,7 +506,9 @@ namespace sealhip
                             mac128(l2, h2, tb[j], mrow[j]);
                 }
                 const u64 qp = d->q_p[i];
-                pout[i * N] = redc_finish(redc128(l2, h2, qp, d->q_ninv[i]), qp, d->q_rdp[i], small);
+                const u64 w = redc_finish(redc128(l2, h2, qp, d->q_ninv[i]), qp, d->q_rdp[i], small);
+                pout[i * N] = w;
+                nz |= w;
                 __builtin_amdgcn_sched_barrier(0);
             };
             if constexpr (KMAX < 0)
@@ -513,6 +516,7 @@ namespace sealhip
             else
                 for (int i = 0; i < k; i++)
                     q_row(i);
+            note_nonzero(tflags, cc.item, nz); // (the launcher passes the sink for polynomials 1.. of the product only)
         }
 
         // fast_floor (rns.cpp:983-1023), optionally preceded by the multiplication by t of
@@ -923,6 +927,9 @@ namespace sealhip
         if (!count)
             return hipSuccess;
         const unsigned grid = blocks_for(count, e.logn);
+        // transparency sink armed for this launch (pipeline.cpp SinkArm: polynomials 1.. of a product): the fused kernel
+        // notes non-zero words as it stores them; the step-by-step kernels are followed by the read pass instead
+        unsigned *tflags = e.lane().tsink_arm;
         ProfScope prof(e, "bfv_floor_sk", 0);
         if (h.k <= 32 && !e.unfused_rns)
         {
@@ -932,10 +939,10 @@ namespace sealhip
         if (deferred_top)                                                                                            \
             bfv_floor_sk2_kernel<KM, true><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,       \
                                                                            out_stride, count, e.logn,               \
-                                                                           deferred_top == 2 ? 1 : 0);              \
+                                                                           deferred_top == 2 ? 1 : 0, tflags);      \
         else                                                                                                         \
             bfv_floor_sk2_kernel<KM, false><<<grid, kThreads, 0, e.lane().stream>>>(d, e.d_primes, in, in_stride, out,      \
-                                                                            out_stride, count, e.logn, 0);          \
+                                                                            out_stride, count, e.logn, 0, tflags);  \
     } while (0)
             switch (h.redc_small ? h.k : 0)
             {
@@ -963,7 +970,10 @@ namespace sealhip
         if (deferred_top)
             return hipErrorInvalidValue;
         SEALHIP_DISPATCH_K(h.k, bfv_floor_sk_kernel, d, e.d_primes, in, in_stride, out, out_stride, count, e.logn);
-        return hipGetLastError();
+        hipError_t err = hipGetLastError();
+        if (err == hipSuccess && tflags)
+            err = launch_nonzero_words(e, out, out_stride, static_cast<std::size_t>(h.k) << e.logn, count, tflags);
+        return err;
     }
 
     hipError_t launch_divround_bfv(const Engine &e, const RnsDev *d, const RnsDev &, const u64 *in,

@@ -116,6 +116,7 @@ SYMBOLS = {
     "sealhip_evaluator_multiply_plain_ntt": [_vp, _u32, _vp, _u32, _sz, _vp, _sz],
     "sealhip_evaluator_multiply_plain": [_vp, _u32, _vp, _u32, _sz, _vp, _sz],
     "sealhip_is_transparent": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_transparency_sink": [_vp, _vp, _sz],
     "sealhip_modulo_poly_coeffs_63": [_vp, _vp, _sz, _u32, _u32, _vp],
     "sealhip_evaluator_rotate_vector": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
     "sealhip_decryptor_dot_product_ct_sk": [_vp, _u32, _vp, _u32, _sz, _vp, _i32, _vp],
@@ -445,6 +446,11 @@ class Context:
         flags = np.zeros(count, dtype=np.uint8)
         _check(lib().sealhip_is_transparent(self.handle, k, _ptr(ct), size, count, flags.ctypes.data))
         return flags.astype(bool)
+
+    def transparency_sink(self, flags, capacity):
+        """The is_transparent test as a flag output of the Evaluator operations: `flags` = device buffer of `capacity`
+        uint32 words (None removes the sink); after an operation flags[i] != 0 iff polynomials 1.. of result i are non-zero."""
+        _check(lib().sealhip_transparency_sink(self.handle, _ptr(flags) if flags is not None else None, capacity))
 
     def dot_product_ct_sk(self, ct, size, k, count, sk_powers_ntt, is_ntt_form, out):
         """Decryptor::dot_product_ct_sk_array (decryptor.cpp:218-265)"""

@@ -287,6 +287,16 @@ long sealhip_evaluator_multiply_plain(sealhip_context *ctx, uint32_t k, uint64_t
    SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:265-271); the adapter does the same with this flag. */
 long sealhip_is_transparent(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,
                             uint8_t *transparent);
+/* The same test as a FLAG OUTPUT of the operations ("provide it as a flag output of the kernels"; replaces the
+   read pass of Ciphertext::is_transparent that evaluator.cpp:265-271 runs after every operation). `nonzero_flags` is DEVICE
+   memory, `capacity` 32-bit words; it belongs to the calling thread's lane of the context until it is replaced or removed
+   (nullptr). While a sink is set, every sealhip_evaluator_* entry that produces ciphertexts first clears flags[0 .. count) and
+   then makes flags[i] non-zero iff polynomials 1.. of result i hold a non-zero word: multiply, square, relinearize and
+   apply_galois note it in the kernel that stores those polynomials anyway (no pass over the result); mod_switch_to_next,
+   rescale_to_next, rotate_vector, add, sub, negate and multiply_plain(_ntt) run the read pass on their result, on the stream.
+   A batch larger than `capacity` is E_INVALIDARG. Nothing synchronises: read the flags after sealhip_synchronize (or on the
+   lane's stream). Composite entries (multiply_many, exponentiate, the *_host batches) leave the flags alone. */
+long sealhip_transparency_sink(sealhip_context *ctx, uint32_t *nonzero_flags, size_t capacity);
 /* modulo_poly_coeffs_63 (polyarithsmallmod.h:98-120): Barrett-63 reduction of rows with values < 2^63 */
 long sealhip_modulo_poly_coeffs_63(sealhip_context *ctx, const uint64_t *a, size_t count, uint32_t k, uint32_t base,
                                    uint64_t *result);

@@ -642,6 +642,42 @@ def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
                 assert np.array_equal(got, want), (count, rep)
 
 
+def test_cfg2_full_batch_1024_polynomials(sealhip):
+    """BASELINE config 2 at its FULL batch: CKKS N = 2^14, 6 primes, forward + inverse NTT over 1024 key-level polynomials
+    (6144 rows in one launch, the shape tools/bench_configs.py times). The golden digest polynomial of the survey sits at
+    the first, a middle and the last position of the batch (launch-size dependent choices: XCD chunking, whole-row inverse
+    grid) between random polynomials; those three reproduce the compiled reference's digests, sampled random ones equal
+    the oracle word for word, and the whole batch round-trips (ntt.cpp:292-404)."""
+    rows = [r for r in DIG["ntt_digests"] if r["logn"] == 14 and len(r["bits"]) == 6 and set(r["bits"]) == {50}]
+    row = rows[0] if rows else None
+    logn, n = 14, 1 << 14
+    mods = O.coeff_modulus_create(n, [50] * 6)
+    x1 = O.SplitMix(0x5EA1 + 1000 * logn + 6).fill(6, n, mods) if row else None  # the survey's generator (test_ntt_golden_digests)
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    tabs = [O.Tables(logn, p) for p in mods]
+    rng = np.random.default_rng(2)
+    P = 1024
+    x = np.stack([rng.integers(0, p, size=(P, n), dtype=np.uint64) for p in mods], axis=1)
+    marks = [0, 517, P - 1]
+    if x1 is not None:
+        assert h(x1) == row["input"]
+        for m in marks:
+            x[m] = x1
+    d = ctx.upload(x)
+    ctx.ntt_negacyclic_harvey(d, P, 5, sealhip.BASE_KEY)  # level k = 5 of BASE_KEY = all 6 key primes
+    f = d.download(x.shape)
+    for m in marks + [1, 300, 1000]:
+        e = x[m].copy()
+        for i in range(6):
+            L.ref_ntt_forward(O.ptr(e[i]), C.byref(tabs[i].t), 0)
+        assert np.array_equal(f[m], e), m
+    if x1 is not None:
+        for m in marks:
+            assert h(f[m]) == row["fwd"], m
+    ctx.inverse_ntt_negacyclic_harvey(d, P, 5, sealhip.BASE_KEY)
+    assert np.array_equal(d.download(x.shape), x)
+
+
 def test_full_size_batch_indexing_and_threads(sealhip):
     """cfg3 at full size with a batch of identical ciphertexts: every item must reproduce the compiled reference's
     digest (exercises item strides / chunking at BASELINE size), also when two host threads drive the same context."""
@@ -787,6 +823,88 @@ def test_f1_multiply_plain(sealhip, logn):
     # unsupported: CKKS context for the coefficient-form product, and a plain modulus above a prime
     with pytest.raises(sealhip.LogicError):
         e2.multiply_plain_inplace(c2.upload(ct), size, k, count, c2.upload(plains), n, ntt_form=False)
+
+
+@pytest.mark.parametrize("scheme,logn,bits", [(1, 15, [55] * 4), (1, 12, [36, 36, 37]), (2, 15, [50] * 4), (2, 15, [58] * 4),
+                                              (2, 12, [40, 40, 40, 41])])
+def test_transparency_is_a_flag_output_of_the_operations(sealhip, scheme, logn, bits):
+    """the transparent-ciphertext test the reference runs after every operation (evaluator.cpp:265-271,
+    ciphertext.h:471-476) as a flag output of the kernels (sealhip_transparency_sink). Batches in which some results are
+    transparent by construction (second polynomials zero, so products / key switches / automorphisms of them are zero): the
+    flags written by multiply, square, relinearize, apply_galois (fused into the storing kernel), mod_switch / rescale,
+    rotate_vector, add, negate (read pass on the result) must equal the separate device reduction sealhip_is_transparent on
+    the same result, and the known pattern; results with a sink equal results without one; an operation on a fresh batch
+    clears what an earlier one left."""
+    n, t = 1 << logn, 786433
+    kmods = O.coeff_modulus_create(n, bits)
+    k = len(kmods) - 1
+    ctx = sealhip.Context(scheme, logn, kmods, 1, t if scheme == 1 else 0)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(5 * logn + scheme)
+    count = 6
+    zero_items = [1, 4]  # their second polynomial is zero
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    for i in zero_items:
+        a[i, 1] = 0
+        b[i, 1] = 0
+    a[2, 1] = 0
+    a[2, 1, k - 1, n - 1] = 1  # one non-zero word: not transparent
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    flags = ctx.alloc((count + 1) // 2)
+    flags.upload(np.full((count + 1) // 2, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))  # stale garbage: every op must clear first
+
+    def got():
+        return (flags.download().view(np.uint32)[:count] != 0).tolist()
+
+    want = [i not in zero_items for i in range(count)]
+    ctx.transparency_sink(flags, count)
+    try:
+        # multiply (products of ciphertexts whose second polynomials are zero have zero polynomials 1 and 2)
+        prod = ctx.alloc(count * 3 * k * n)
+        ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, prod)
+        assert got() == want == [not v for v in ctx.is_transparent(prod, 3, k, count).tolist()], "multiply"
+        ref_prod = prod.download((count, 3, k, n)).copy()
+        sq = ctx.alloc(count * 3 * k * n)
+        ev.square(ctx.upload(a), 2, k, count, sq)
+        assert got() == [not v for v in ctx.is_transparent(sq, 3, k, count).tolist()], "square"
+        assert got()[1] is False and got()[4] is False and got()[0] is True
+        # relinearize (of the products: polynomial 2 zero -> nothing is added -> polynomial 1 stays zero)
+        ev.relinearize_inplace(prod, 3, k, count, [dkey])
+        relin = np.ascontiguousarray(prod.download((count, 3, k, n))[:, :2])
+        assert got() == want == [not v for v in ctx.is_transparent(ctx.upload(relin), 2, k, count).tolist()], "relinearize"
+        # apply_galois
+        g = ctx.upload(a)
+        ev.apply_galois_inplace(g, k, count, ctx.galois_elt_from_step(1), dkey)
+        assert got() == want == [not v for v in ctx.is_transparent(g, 2, k, count).tolist()], "apply_galois"
+        ref_g = g.download((count, 2, k, n)).copy()
+        # mod_switch_to_next / rescale_to_next (read pass)
+        o = ctx.alloc(count * 2 * (k - 1) * n)
+        (ev.mod_switch_to_next if scheme == 1 else ev.rescale_to_next)(ctx.upload(a), 2, k, count, o)
+        assert got() == want == [not v for v in ctx.is_transparent(o, 2, k - 1, count).tolist()], "level down"
+        # add: a + (-a) is transparent everywhere; negate keeps the pattern
+        neg = ctx.alloc(count * 2 * k * n)
+        ev.negate(ctx.upload(a), 2, k, count, neg)
+        assert got() == want, "negate"
+        s = ctx.alloc(count * 2 * k * n)
+        ev.add(ctx.upload(a), 2, neg, 2, k, count, s)
+        assert got() == [False] * count, "add"
+        # a smaller batch only touches its own flags; a larger one than the sink is refused
+        ev.negate(ctx.upload(a[:2]), 2, k, 2, ctx.alloc(2 * 2 * k * n))
+        assert got()[:2] == want[:2]
+        ctx.transparency_sink(flags, 2)
+        with pytest.raises(ValueError):
+            ev.negate(ctx.upload(a), 2, k, count, neg)
+    finally:
+        ctx.transparency_sink(None, 0)
+    # the same operations without a sink give the same words
+    prod2 = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, prod2)
+    assert np.array_equal(prod2.download((count, 3, k, n)), ref_prod)
+    g2 = ctx.upload(a)
+    ev.apply_galois_inplace(g2, k, count, ctx.galois_elt_from_step(1), dkey)
+    assert np.array_equal(g2.download((count, 2, k, n)), ref_g)
 
 
 def test_f1_transparent_mod63_and_native_rotate(sealhip):
