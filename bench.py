@@ -531,9 +531,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None,
                     help="independent ciphertexts (pairs) per GPU; default per config: 4096 / 1024 / 256 "
                          "(SEALHIP_BENCH_BATCH overrides the default)")
-    ap.add_argument("--ntt-polys", type=int, default=4096,
-                    help="polynomials (x k rows) in the NTT-only section; 4096 = the batch of the step (the rate grows "
-                         "with the launch: 31 %% of the roofline at 7 k rows, 36-38 %% at 29-57 k, DESIGN.md section 6)")
+    ap.add_argument("--ntt-polys", type=int, default=8192,
+                    help="polynomials (x k rows) in one launch of the NTT-only section (a quarter of it at N = 2^16). The "
+                         "rate grows with the launch until ~57 k rows (round 3, same box: 35.1 %% of the roofline at 14 k "
+                         "rows, 38.2 %% at 29 k, 39.5 %% at 57 k and at 115 k): 8192 x 7 rows is the steady state")
     ap.add_argument("--gather-cts", type=int, default=512,
                     help="size-2 result ciphertexts per rank in the final gather to rank 0 (N > 1 only; 3.67 MB each)")
     ap.add_argument("--cpu-ops", type=int, default=None,
