@@ -2400,14 +2400,15 @@ def test_ntt_handoff_failure_surfaces_at_every_host_visible_point(sealhip):
 
 def test_exact_ntt_variants_still_match_the_golden_digests():
     """The lazy-sum inverse and the last-layer shortcut of the forward transform are switched off with
-    SEALHIP_NTT_EXACT_INV / SEALHIP_NTT_EXACT_FWD (read once per process, hence the child process): the exact kernels
+    SEALHIP_NTT_EXACT_INV / SEALHIP_NTT_EXACT_FWD, the canonical transform's approximate-quotient schedule (round 3) with
+    SEALHIP_NTT_CANON_EXACT (read once per process, hence the child process): the exact kernels
     must reproduce the same golden digests of the compiled reference as the default ones do in this process."""
     import subprocess
     import sys
 
-    env = dict(os.environ, SEALHIP_NTT_EXACT_INV="1", SEALHIP_NTT_EXACT_FWD="1")
+    env = dict(os.environ, SEALHIP_NTT_EXACT_INV="1", SEALHIP_NTT_EXACT_FWD="1", SEALHIP_NTT_CANON_EXACT="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "end_to_end_golden_digests or ntt_golden_digests"],
+                        "-k", "end_to_end_golden_digests or ntt_golden_digests or ntt_all_variants"],
                        env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode("utf-8", "replace")[-400:]
     assert r.returncode == 0 and " passed" in tail, tail
