@@ -642,6 +642,51 @@ def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
                 assert np.array_equal(got, want), (count, rep)
 
 
+def test_inplace_ntt_handoff_from_three_lanes_at_once(sealhip):
+    """The forward single-pass kernel's sibling hand-off (a cross-workgroup ticket per row, a bounded wait, a sticky fault
+    word) when several host threads drive ONE context at the same time: every thread has its own lane -- stream, ticket
+    buffer, fault word (round 3: per lane) -- and launches in-place transforms of different sizes back to back, integer
+    instances (57-bit primes: the canonical wrapper's approximate-quotient schedule and the reference's lazy sequence) and
+    FP64 ones (50-bit). Every result against the oracle; no launch may report a hand-off failure."""
+    import threading
+
+    logn, n = 15, 1 << 15
+    mods = O.get_primes(n, 57, 2) + O.get_primes(n, 50, 2) + O.get_primes(n, 58, 1)
+    k = 4
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, mods, 1, 0)
+    tabs = [O.Tables(logn, p) for p in mods[:k]]
+    errors = []
+
+    def work(tid):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            for it, count in enumerate((5, 1, 9, 2, 7, 3)[tid:] + (5, 1, 9, 2, 7, 3)[:tid]):
+                x = np.stack([rand_rows(rng, mods[:k], n) for _ in range(count)])
+                lazy = (it + tid) % 2 == 1
+                d = ctx.upload(x)
+                (ctx.ntt_negacyclic_harvey_lazy if lazy else ctx.ntt_negacyclic_harvey)(d, count, k)
+                got = d.download(x.shape)  # synchronises this thread's lane and reads its fault word
+                for c in (0, count - 1):
+                    e = x[c].copy()
+                    for i in range(k):
+                        if lazy:
+                            L.ref_ntt_forward_lazy(O.ptr(e[i]), C.byref(tabs[i].t), 0)
+                        else:
+                            L.ref_ntt_forward(O.ptr(e[i]), C.byref(tabs[i].t), 0)
+                    if not np.array_equal(got[c], e):
+                        errors.append((tid, it, count, c))
+        except Exception as ex:  # noqa: BLE001 -- reported by the asserting thread
+            errors.append((tid, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert ctx.lane_count() >= 3
+
+
 def test_cfg2_full_batch_1024_polynomials(sealhip):
     """BASELINE config 2 at its FULL batch: CKKS N = 2^14, 6 primes, forward + inverse NTT over 1024 key-level polynomials
     (6144 rows in one launch, the shape tools/bench_configs.py times). The golden digest polynomial of the survey sits at

@@ -62,8 +62,22 @@ def one(rng, it):
     g = ctx.upload(c2)
     ev.apply_galois_inplace(g, k, count, elt, dkey)
     got_g = g.download((count, 2, k, n))
+    # round 3: Evaluator::square as its own path, and the transparency flags written by the operations themselves
+    sqo = ctx.alloc(count * 3 * k * n)
+    flags = ctx.alloc((count + 1) // 2)
+    ctx.transparency_sink(flags, count)
+    try:
+        ev.square(ctx.upload(a), 2, k, count, sqo)
+        got_f = flags.download().view(np.uint32)[:count] != 0
+    finally:
+        ctx.transparency_sink(None, 0)
+    got_sq = sqo.download((count, 3, k, n))
+    assert np.array_equal(~got_f, ctx.is_transparent(sqo, 3, k, count)), ("transparency sink", it)
+    sqr = L.ref_bfv_square if scheme == 1 else L.ref_ckks_square
     for i in range(count):
         exp = np.zeros((3, k, n), dtype=np.uint64)
+        assert sqr(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(exp)) == 0
+        assert np.array_equal(got_sq[i], exp), ("square", it, i)
         assert mul(C.byref(ref.c), k, O.ptr(a[i]), 2, O.ptr(b[i]), 2, O.ptr(exp)) == 0
         assert np.array_equal(got[i], exp), ("multiply", it, i)
         assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp), 3, keys) == 0
