@@ -913,20 +913,28 @@ namespace
     }
 
     // mod_switch_to_next (evaluator.cpp:996-1036) / rescale_to_next (:1090-1126) on a device batch
-    void do_level_down(Engine &e, uint32_t k, const u64 *in, uint32_t size, size_t count, u64 *o, bool rescale)
+    // item_stride (words, 0 = back to back): distance between consecutive ciphertexts of `in` (the *_strided entries)
+    void do_level_down(Engine &e, uint32_t k, const u64 *in, uint32_t size, size_t count, u64 *o, bool rescale,
+                       size_t item_stride = 0)
     {
         check_level(e, k);
         if (k < 2)
             throw std::invalid_argument("end of modulus switching chain reached");
         if (rescale && e.scheme != 2)
             throw std::invalid_argument("unsupported operation for scheme type"); // evaluator.cpp:1108-1109
+        const std::size_t in_poly = static_cast<std::size_t>(k) * e.n, out_poly = static_cast<std::size_t>(k - 1) * e.n;
+        if (item_stride != 0 && item_stride < size * in_poly)
+            throw std::invalid_argument("item stride smaller than one ciphertext");
         if (rescale || e.scheme == 1)
-            op_mod_switch_scale(e, static_cast<int>(k), in, static_cast<int>(size), count, o);
-        else
+            op_mod_switch_scale(e, static_cast<int>(k), in, static_cast<int>(size), count, o, item_stride);
+        else if (item_stride == 0 || item_stride == size * in_poly)
             // mod_switch_drop_to_next (evaluator.cpp:894-957): keep the first k-1 rows of every polynomial
-            check_launch(launch_copy_rows(e, in, static_cast<std::size_t>(k) * e.n, o, static_cast<std::size_t>(k - 1) * e.n,
-                                          count * size, static_cast<int>(k - 1)),
-                         "mod_switch_drop");
+            check_launch(launch_copy_rows(e, in, in_poly, o, out_poly, count * size, static_cast<int>(k - 1)), "mod_switch_drop");
+        else
+            for (uint32_t comp = 0; comp < size; comp++)
+                check_launch(launch_copy_rows(e, in + comp * in_poly, item_stride, o + comp * out_poly, size * out_poly, count,
+                                              static_cast<int>(k - 1)),
+                             "mod_switch_drop");
     }
 } // namespace
 
@@ -1221,6 +1229,34 @@ long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, cons
         Engine &e = device_engine(ctx);
         SinkScope sink(e, count, false);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false);
+        sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
+    });
+}
+
+long sealhip_evaluator_mod_switch_to_next_strided(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                                  size_t ct_item_stride, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SinkScope sink(e, count, false);
+        do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false, ct_item_stride);
+        sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
+    });
+}
+
+long sealhip_evaluator_rescale_to_next_strided(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                               size_t ct_item_stride, size_t count, uint64_t *out)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(out);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        SinkScope sink(e, count, false);
+        do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), true, ct_item_stride);
         sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
 }

@@ -510,7 +510,8 @@ namespace sealhip
     // Evaluator::square as its own path (evaluator.cpp:560-770): the operand is lifted / transformed once
     void op_bfv_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out);
     void op_ckks_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out);
-    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out);
+    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out,
+                             std::size_t in_item_stride = 0);
     void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count);
     void op_rescale_special_inplace(Engine &e, int k, u64 *poly, std::size_t count);
     void op_apply_galois(Engine &e, int k, u64 *ct, std::size_t count, std::uint32_t elt, const KSwitchKey &key);

@@ -536,13 +536,36 @@ namespace sealhip
     // ------------------------------------------------------------------------------------------
     // mod_switch_scale_to_next (evaluator.cpp:829-892): BFV mod_switch_to_next / CKKS rescale_to_next
     // ------------------------------------------------------------------------------------------
-    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out)
+    namespace
+    {
+        void mod_switch_polys(Engine &e, int k, const u64 *ct, std::size_t in_stride, u64 *out, std::size_t out_stride,
+                              std::size_t npolys);
+    }
+    // in_item_stride (words, 0 = the ciphertexts are back to back): distance between consecutive ciphertexts of `ct` when they
+    // sit in a wider container -- the size-2 result of relinearize inside its size-3 product (the reference's objects are
+    // separate buffers; a contiguous batch needs the stride). Each component is then one strided pass.
+    void op_mod_switch_scale(Engine &e, int k, const u64 *ct, int size, std::size_t count, u64 *out, std::size_t in_item_stride)
     {
         if (k < 2)
             throw std::invalid_argument("end of modulus switching chain reached"); // evaluator.cpp:1005-1008
+        const std::size_t N = e.n;
+        const std::size_t in_poly = static_cast<std::size_t>(k) * N, out_poly = static_cast<std::size_t>(k - 1) * N;
+        if (in_item_stride == 0 || in_item_stride == size * in_poly)
+            return mod_switch_polys(e, k, ct, in_poly, out, out_poly, count * size);
+        if (in_item_stride < size * in_poly)
+            throw std::invalid_argument("item stride smaller than one ciphertext");
+        for (int comp = 0; comp < size; comp++)
+            mod_switch_polys(e, k, ct + comp * in_poly, in_item_stride, out + comp * out_poly, size * out_poly, count);
+    }
+
+    namespace
+    {
+    void mod_switch_polys(Engine &e, int k, const u64 *ct, std::size_t in_stride, u64 *out, std::size_t out_stride,
+                          std::size_t npolys)
+    {
         LevelTools &lt = e.level(k);
-        const std::size_t N = e.n, npolys = count * size;
-        const std::size_t in_stride = static_cast<std::size_t>(k) * N, out_stride = static_cast<std::size_t>(k - 1) * N;
+        const std::size_t N = e.n;
+        const std::size_t temp_stride = static_cast<std::size_t>(k - 1) * N;
         if (e.scheme == 1)
         {
             check(launch_divround_bfv(e, lt.d_rns, lt.h_rns, ct, in_stride, out, out_stride, npolys, k - 1), "divround");
@@ -558,20 +581,21 @@ namespace sealhip
             const std::size_t m = std::min(chunk, npolys - off);
             e.ws_reset();
             u64 *last = e.ws_alloc(N * m);
-            u64 *temp = e.ws_alloc(out_stride * m);
+            u64 *temp = e.ws_alloc(temp_stride * m);
             check(launch_copy_rows(e, ct + off * in_stride + static_cast<std::size_t>(k - 1) * N, in_stride, last, N, m, 1),
                   "copy(last)");
             RowMap one{};
             one.rows = 1;
             one.prime[0] = static_cast<unsigned short>(k - 1);
             check(launch_ntt(e, last, m, one, true, kNttCanonical), "intt(last)");
-            check(launch_rescale_pre(e, lt.d_rns, lt.h_rns, last, N, temp, out_stride, m), "rescale_pre");
+            check(launch_rescale_pre(e, lt.d_rns, lt.h_rns, last, N, temp, temp_stride, m), "rescale_pre");
             check(launch_ntt(e, temp, m * (k - 1), map_low, false, 0), "ntt(temp)");
-            check(launch_rescale_post(e, lt.d_rns, lt.h_rns, ct + off * in_stride, in_stride, temp, out_stride,
+            check(launch_rescale_post(e, lt.d_rns, lt.h_rns, ct + off * in_stride, in_stride, temp, temp_stride,
                                       out + off * out_stride, out_stride, m),
                   "rescale_post");
         }
     }
+    } // namespace
 
     // divide_and_round_q_last_ntt_inplace (rns.cpp:777-851), in place like the reference (last row clobbered)
     void op_divround_ntt_inplace(Engine &e, int k, u64 *data, std::size_t count)

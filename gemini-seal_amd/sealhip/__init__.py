@@ -107,6 +107,8 @@ SYMBOLS = {
     "sealhip_evaluator_rescale_to_next_host": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_mod_switch_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_rescale_to_next": [_vp, _u32, _vp, _u32, _sz, _vp],
+    "sealhip_evaluator_mod_switch_to_next_strided": [_vp, _u32, _vp, _u32, _sz, _sz, _vp],
+    "sealhip_evaluator_rescale_to_next_strided": [_vp, _u32, _vp, _u32, _sz, _sz, _vp],
     "sealhip_evaluator_apply_galois": [_vp, _u32, _vp, _sz, _u32, _vp],
     "sealhip_evaluator_transform_to_ntt": [_vp, _u32, _vp, _u32, _sz],
     "sealhip_evaluator_transform_from_ntt": [_vp, _u32, _vp, _u32, _sz],
@@ -649,11 +651,21 @@ class Evaluator:
         keys = (C.c_void_p * max(1, len(relin_keys)))(*[rk.handle for rk in relin_keys])
         _check(lib().sealhip_evaluator_relinearize(self.ctx.handle, k, _ptr(ct), size, count, keys, len(relin_keys)))
 
-    def mod_switch_to_next(self, ct, size, k, count, out):
-        _check(lib().sealhip_evaluator_mod_switch_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
+    def mod_switch_to_next(self, ct, size, k, count, out, item_stride=0):
+        """item_stride (words): the ciphertexts of `ct` sit that far apart (e.g. the size-2 result of relinearize inside its
+        size-3 product); 0 = back to back"""
+        if item_stride:
+            _check(lib().sealhip_evaluator_mod_switch_to_next_strided(self.ctx.handle, k, _ptr(ct), size, item_stride, count,
+                                                                     _ptr(out)))
+        else:
+            _check(lib().sealhip_evaluator_mod_switch_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
 
-    def rescale_to_next(self, ct, size, k, count, out):
-        _check(lib().sealhip_evaluator_rescale_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
+    def rescale_to_next(self, ct, size, k, count, out, item_stride=0):
+        if item_stride:
+            _check(lib().sealhip_evaluator_rescale_to_next_strided(self.ctx.handle, k, _ptr(ct), size, item_stride, count,
+                                                                  _ptr(out)))
+        else:
+            _check(lib().sealhip_evaluator_rescale_to_next(self.ctx.handle, k, _ptr(ct), size, count, _ptr(out)))
 
     def apply_galois_inplace(self, ct, k, count, galois_elt, galois_key):
         _check(lib().sealhip_evaluator_apply_galois(self.ctx.handle, k, _ptr(ct), count, galois_elt, galois_key.handle))

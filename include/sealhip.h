@@ -211,6 +211,14 @@ long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, cons
 /* Evaluator::rescale_to_next (evaluator.cpp:1090-1126), CKKS only */
 long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
                                        size_t count, uint64_t *out);
+/* The same two operations on ciphertexts that sit `ct_item_stride` words apart (>= size * k * N): the size-2 result of
+   relinearize inside its size-3 product, so that multiply -> relinearize -> mod_switch_to_next over a contiguous device batch
+   needs no compaction pass in between. The reference's ciphertexts are separate objects (ciphertext.h:709-721); a contiguous
+   batch takes the stride instead ("a contiguous batch with stride"). `out` is compact (size * (k-1) * N per item). */
+long sealhip_evaluator_mod_switch_to_next_strided(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                                  size_t ct_item_stride, size_t count, uint64_t *out);
+long sealhip_evaluator_rescale_to_next_strided(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
+                                               size_t ct_item_stride, size_t count, uint64_t *out);
 /* Evaluator::apply_galois_inplace (evaluator.cpp:1841-1943): ct is count x 2 x k x N */
 long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *ct, size_t count,
                                     uint32_t galois_elt, const sealhip_kswitch_key *galois_key);

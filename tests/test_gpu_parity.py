@@ -642,6 +642,40 @@ def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
                 assert np.array_equal(got, want), (count, rep)
 
 
+@pytest.mark.parametrize("scheme,logn,bits", [(1, 12, [36, 36, 37, 38]), (1, 15, [55] * 4), (2, 12, [40, 40, 40, 41]), (2, 15, [50] * 4)])
+def test_level_down_reads_ciphertexts_at_a_stride(sealhip, scheme, logn, bits):
+    """mod_switch_to_next / rescale_to_next (evaluator.cpp:829-1036, 1090-1126) on ciphertexts that sit inside a wider
+    container -- the size-2 result of relinearize in its size-3 product, the layout multiply -> relinearize leaves in a
+    contiguous batch: the strided entries equal the compact ones on the compacted copy, and the oracle; CKKS
+    mod_switch_to_next (drop) as well."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    k = len(kmods) - 1
+    ctx = sealhip.Context(scheme, logn, kmods, 1, 786433 if scheme == 1 else 0)
+    ev = sealhip.Evaluator(ctx)
+    ref = O.RefContext(scheme, logn, kmods, nsp=1, t=786433 if scheme == 1 else 0)
+    rng = np.random.default_rng(logn + scheme)
+    count = 5
+    wide = _rand_ct(rng, kmods[:k], 3, n, count)
+    compact = np.ascontiguousarray(wide[:, :2])
+    dw = ctx.upload(wide)
+    for fn in ([ev.mod_switch_to_next] if scheme == 1 else [ev.rescale_to_next, ev.mod_switch_to_next]):
+        o1, o2 = ctx.alloc(count * 2 * (k - 1) * n), ctx.alloc(count * 2 * (k - 1) * n)
+        fn(dw, 2, k, count, o1, item_stride=3 * k * n)
+        fn(ctx.upload(compact), 2, k, count, o2)
+        got = o1.download((count, 2, k - 1, n))
+        assert np.array_equal(got, o2.download(got.shape)), fn.__name__
+        if fn.__name__ == "rescale_to_next" or scheme == 1:
+            for c in range(count):
+                exp = np.zeros((2, k - 1, n), dtype=np.uint64)
+                assert L.ref_mod_switch_scale_to_next(C.byref(ref.c), k, O.ptr(compact[c]), 2, O.ptr(exp)) == 0
+                assert np.array_equal(got[c], exp), (fn.__name__, c)
+        else:
+            assert np.array_equal(got, compact[:, :, : k - 1])
+    with pytest.raises(ValueError):
+        ev.mod_switch_to_next(dw, 2, k, count, ctx.alloc(count * 2 * (k - 1) * n), item_stride=2 * k * n - 1)
+
+
 def test_inplace_ntt_handoff_from_three_lanes_at_once(sealhip):
     """The forward single-pass kernel's sibling hand-off (a cross-workgroup ticket per row, a bounded wait, a sticky fault
     word) when several host threads drive ONE context at the same time: every thread has its own lane -- stream, ticket
