@@ -33,11 +33,14 @@ namespace sealhip
     };
 
     // ---- residues as doubles (primes below 2^50). A product y*w with |y| < 2^53 and 0 <= w < p is formed exactly as
-    // h + l (h = the rounded product, l = fma(y, w, -h) its rounding error, both exact), the quotient estimate
-    // q = rint(h / p) is off by at most two, and r = (h - q*p) + l is exact again (|h - q*p| < 2.5p fits 53 bits and is a
-    // multiple of ulp(h) because q*p is formed inside the fma): r == y*w (mod p), |r| < 2.5p. Every operation is an
-    // exact integer computation as long as magnitudes stay below 2^53 = 8 * 2^50, which the callers' reduction
-    // schedules guarantee -- the transform is bit-for-bit the integer one after the final canonicalisation.
+    // h + l (h = the rounded product, l = fma(y, w, -h) its rounding error, both exact integers); with u = 2^-53 the
+    // quotient estimate q = rint(fl(h * fl(1/p))) is within 1/2 + |h/p| (2u + u^2) of h/p, h - q*p is an integer below 2^53
+    // in magnitude (so the fma forms it exactly) and r = (h - q*p) + l satisfies
+    //     r == y*w (mod p),   |r| <= (1/2 + 3 * 2^-53 |y|) p        (at most 3.5 p at |y| = 2^53)
+    // -- the rounding of h * (1/p) AND the exact error l both count (ntt_bounds.hpp section 4; round 2 had assumed
+    // (1/2 + 2^-52 |y|) p, which adversarial operands exceed: tests/bounds_check.cpp). Every operation is an exact integer
+    // computation as long as magnitudes stay below 2^53 = 8 * 2^50, which the callers' reduction schedules guarantee by a
+    // worst-case recurrence -- the transform is bit-for-bit the integer one after the final canonicalisation.
     // (v_fma_f64 issues at the rate of v_mad_u64_u32; the modular product takes 6 of them against 14.)
     constexpr double kTwo52 = 4503599627370496.0;
     __device__ __forceinline__ double fp_of(u64 bits)
