@@ -1069,6 +1069,16 @@ namespace sealhip
             asm volatile("" : "+v"(v));
             return v;
         }
+        // Round 3: the thread index itself is not kept either. These kernels run at the 128-register cap, and the one value
+        // every phase needs -- threadIdx.x -- was what the allocator spilled (1-6 dwords of scratch in eight inverse instances).
+        // The wave's base index is uniform (an SGPR), the lane id comes from v_mbcnt: two full-rate instructions wherever a
+        // phase starts, no register held across the rounds. (volatile: never merged with an earlier copy)
+        __device__ __forceinline__ int fresh_tid(int wave_base)
+        {
+            int lane;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+            return wave_base + lane;
+        }
 
         // arrangement 1 -> memory: pairs, consecutive lanes 16 bytes apart
         template <int T>
@@ -1130,7 +1140,8 @@ namespace sealhip
             constexpr int T = LOGN - 1;
             constexpr int N = 1 << LOGN;
             extern __shared__ u64 lds[];
-            const int tid = threadIdx.x;
+            const int tid = threadIdx.x; // (only the measurement hooks below use it: see fresh_tid)
+            const int wave_base = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) & ~63);
             int half, position;
             std::size_t poly;
             if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
@@ -1176,7 +1187,7 @@ namespace sealhip
             else if constexpr (REDUCE == 6)
             {
                 // kNttTopDone: the producer applied the top layer; this workgroup's half, arrangement 1, nothing else
-                const int jb1 = Arr<T, 1>::tid_index(fresh(tid));
+                const int jb1 = Arr<T, 1>::tid_index(fresh_tid(wave_base));
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
@@ -1186,9 +1197,9 @@ namespace sealhip
                 }
             }
             else if (half)
-                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
+                h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh_tid(wave_base), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             else
-                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh(tid), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
+                h_load_top<T, STRICT, 0, REDUCE>(x, srcp, tw, fresh_tid(wave_base), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             // The transform is in place and both workgroups of a row read BOTH halves: neither may store before
             // the other has finished loading. Ticket protocol (placement independent, bounded spin): every
             // wave bumps the row's counter once its loads have landed in registers; before its store phase
@@ -1205,23 +1216,23 @@ namespace sealhip
                 fp_reduce_all(x, two_p, neg_p);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
-            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
+            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh_tid(wave_base));
             RoundStage<T, 2, STRICT, false, 0>::load(w0, ws0, tw, jb2, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 1, 2>(x, lds, fresh(tid));
-            if (tid == 0 && tickets && !(flags & kNttDebugNoSignal))
+                h_exchange<T, 1, 2>(x, lds, fresh_tid(wave_base));
+            if (fresh_tid(wave_base) == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
-            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
+            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh_tid(wave_base));
             RoundStage<T, 3, STRICT, false, 0>::load(w0, ws0, tw, jb3, N);
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 2, 3>(x, lds, fresh(tid));
+                h_exchange<T, 2, 3>(x, lds, fresh_tid(wave_base));
             if (!NTT_EXP(flags, 0x100))
                 RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
-            const int jb4 = gbase + Arr<T, 4>::tid_index(fresh(tid));
+            const int jb4 = gbase + Arr<T, 4>::tid_index(fresh_tid(wave_base));
             u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
             if constexpr (FinalStage<T>::PIPE)
             {
@@ -1229,14 +1240,14 @@ namespace sealhip
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!NTT_EXP(flags, 0x200))
-                h_exchange<T, 3, 4>(x, lds, fresh(tid));
+                h_exchange<T, 3, 4>(x, lds, fresh_tid(wave_base));
             static_assert(!bounds::fp_fwd_reduce_before_layer(12) && !bounds::fp_fwd_reduce_before_layer(13) &&
                               !bounds::fp_fwd_reduce_before_layer(14),
                           "the final round runs without a reduction (the schedule reduces inside rounds 2 and 3)");
             NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             const auto wait_for_sibling = [&] {
-                if ((tid & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
+                if ((fresh_tid(wave_base) & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
                 {
                     unsigned spins = 0;
                     while (__hip_atomic_load(&tickets[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
@@ -1271,7 +1282,7 @@ namespace sealhip
             if constexpr (XCH)
             {
                 if (!NTT_EXP(flags, 0x200))
-                    h_exchange<T, 4, 1>(x, lds, fresh(tid));
+                    h_exchange<T, 4, 1>(x, lds, fresh_tid(wave_base));
                 wait_for_sibling();
                 if constexpr (REDUCE == 7)
                 {
@@ -1283,11 +1294,11 @@ namespace sealhip
                     u64 *ct_half = src.md.ct + (pl >> 1) * src.md.ct_stride + (((pl & 1) * map.rows + q) << LOGN) + gbase;
                     const u64 *c0_half =
                         (src.md.c0_src && !(pl & 1)) ? src.md.c0_src + (pl >> 1) * src.md.c0_stride + (q << LOGN) + gbase : nullptr;
-                    h_store_moddown<T>(x, fresh(tid), prod_half, ct_half, c0_half, src.md.c0_src == nullptr, ip, ips, P.p,
+                    h_store_moddown<T>(x, fresh_tid(wave_base), prod_half, ct_half, c0_half, src.md.c0_src == nullptr, ip, ips, P.p,
                                        (src.md.tflags && (pl & 1)) ? src.md.tflags + (pl >> 1) : nullptr);
                 }
                 else
-                    h_store_rows<T>(x, rowp + gbase, fresh(tid));
+                    h_store_rows<T>(x, rowp + gbase, fresh_tid(wave_base));
             }
             NTT_STAMP(4);
 #ifdef SEALHIP_NTT_EXPERIMENT
@@ -1337,6 +1348,16 @@ namespace sealhip
         // layer, so both outputs of layers 1, 5, 9, 13 are brought back to [-p/2, p/2]: 2p -> 4p -> 8p | 0.5p -> p -> 2p ->
         // 4p -> 8p | ...; a difference is at most 8p too, its product below (0.5 + 8p 2^-52) p <= 2.5p. Every magnitude stays
         // at or below 8p < 2^53: exact (devmath.hpp). The last layer's outputs are canonicalised by the store instead.
+        // p << shift as a value of its own at every use. The subtraction u - y + addend is a 64-bit v_sub / v_subb pair; the
+        // second reads the carry, so its other operand cannot be a scalar register and the compiler keeps the addend's high
+        // dword in a VECTOR register -- and, because the same shift recurs in layers far apart, kept it there (or in scratch:
+        // three spilled dwords in <16, 1, true>) across whole rounds. An opaque scalar copy per layer ends that live range.
+        __device__ __forceinline__ u64 lazy_addend(u64 neg_p, int shift)
+        {
+            u64 a = (0 - neg_p) << shift;
+            asm volatile("" : "+s"(a));
+            return a;
+        }
         template <int T>
         constexpr bool fp_inv_reduce_after(int layer)
         {
@@ -1403,7 +1424,7 @@ namespace sealhip
                 }
                 if constexpr (LZ == 1)
                     butterflies_inv_hs<UNIFORM, kIL, InvLazy<T>::mode(layer)>(u, y, w, ws, neg_p,
-                                                                             (0 - neg_p) << InvLazy<T>::shift(layer), rdp);
+                                                                             lazy_addend(neg_p, InvLazy<T>::shift(layer)), rdp);
                 else
                     butterflies_inv_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // BackwardLazy, ntt.cpp:265-272
 #pragma unroll
@@ -1467,7 +1488,7 @@ namespace sealhip
             for (int W = 0; W < f; W++)
             {
                 const int bit = 1 << W;
-                const u64 addend = LZ == 1 ? (0 - neg_p) << InvLazy<T>::shift(W) : two_p; // layer index = W
+                const u64 addend = LZ == 1 ? lazy_addend(neg_p, InvLazy<T>::shift(W)) : two_p; // layer index = W
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
                 {
@@ -1512,22 +1533,26 @@ namespace sealhip
                     FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p);
             }
         };
-        template <int T, int ST, int LZ>
+        // AHEAD: the next stage's twiddles are requested before this stage is computed (two stages of twiddles live: 48
+        // registers at f = 2). Off at f = 3 (they do not fit), in the lazy fused-tensor instances, which come out of their
+        // products at the register cap, and in the exact whole-row instance (the request then follows the stage: its latency is
+        // exposed once per stage; round 3: with this, fresh_tid and lazy_addend no single-pass kernel spills any more).
+        template <int T, int ST, int LZ, bool AHEAD = FinalStage<T>::PIPE>
         struct FirstPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
                                                        int N, u64 neg_p, u64 two_p)
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
-                if constexpr (ST + 1 < FinalStage<T>::NS && FinalStage<T>::PIPE)
+                if constexpr (ST + 1 < FinalStage<T>::NS && AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
                 FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ST + 1 < FinalStage<T>::NS && !FinalStage<T>::PIPE) // f = 3: two stages do not fit
+                if constexpr (ST + 1 < FinalStage<T>::NS && !AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FirstPipe<T, ST + 1, LZ>::run(x, next, tw, jb, N, neg_p, two_p);
+                    FirstPipe<T, ST + 1, LZ, AHEAD>::run(x, next, tw, jb, N, neg_p, two_p);
             }
         };
 
@@ -1716,7 +1741,7 @@ namespace sealhip
             constexpr int LOGR = WHOLE ? T : LOGN; // log2 of the row length
             constexpr int N = 1 << LOGR;
             extern __shared__ u64 lds[];
-            const int tid = threadIdx.x;
+            const int wave_base = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) & ~63); // (see fresh_tid)
             int half = 0, position;
             std::size_t poly;
             if constexpr (WHOLE)
@@ -1766,7 +1791,7 @@ namespace sealhip
                 // every coefficient of the half row first (16 x 16 bytes per lane in flight at once), the twiddles of
                 // the first stage with them
                 constexpr int LA = kInvLoadArr<T>;
-                const int jloc = Arr<T, 4>::tid_index(fresh(tid)), jl = Arr<T, LA>::tid_index(fresh(tid));
+                const int jloc = Arr<T, 4>::tid_index(fresh_tid(wave_base)), jl = Arr<T, LA>::tid_index(fresh_tid(wave_base));
                 u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (!DY && LA == 4)
                     FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N);
@@ -1807,25 +1832,26 @@ namespace sealhip
                 {
                     FirstStage<T, 0, LZ>::load(tg0, tw, gbase + jloc, N); // lands while the exchange runs
                     __builtin_amdgcn_sched_barrier(0);
-                    h_exchange<T, LA, 4>(x, lds, fresh(tid));
+                    h_exchange<T, LA, 4>(x, lds, fresh_tid(wave_base));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                FirstPipe<T, 0, LZ>::run(x, tg0, tw, gbase + jloc, N, neg_p, two_p);
+                FirstPipe<T, 0, LZ, FinalStage<T>::PIPE && !(DY && LZ == 1) && !(WHOLE && LZ == 0)>::run(x, tg0, tw, gbase + jloc, N, neg_p,
+                                                                                                      two_p);
             }
-            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh(tid));
+            const int jb3 = gbase + Arr<T, 3>::tid_index(fresh_tid(wave_base));
             u64 w0[kIL], ws0[kIL];
             const u64 rdp = LZ == 1 ? P.rdp : 0; // only the reducing layers of the lazy schedule read it
             RoundStageInv<T, 3, false, 0, LZ>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
-            h_exchange<T, 4, 3>(x, lds, fresh(tid));
+            h_exchange<T, 4, 3>(x, lds, fresh_tid(wave_base));
             RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp);
-            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh(tid));
+            const int jb2 = gbase + Arr<T, 2>::tid_index(fresh_tid(wave_base));
             RoundStageInv<T, 2, false, 0, LZ>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
-            h_exchange<T, 3, 2>(x, lds, fresh(tid));
+            h_exchange<T, 3, 2>(x, lds, fresh_tid(wave_base));
             RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp);
             RoundStageInv<T, 1, true, 0, LZ>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
-            h_exchange<T, 2, 1>(x, lds, fresh(tid));
+            h_exchange<T, 2, 1>(x, lds, fresh_tid(wave_base));
             if constexpr (WHOLE)
             {
                 RoundPipeInv<T, 1, true, LZ, 0, 3>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
@@ -1870,7 +1896,7 @@ namespace sealhip
             else
                 RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
             {
-                const int jb = Arr<T, 1>::tid_index(fresh(tid));
+                const int jb = Arr<T, 1>::tid_index(fresh_tid(wave_base));
 #pragma unroll
                 for (int s = 0; s < 32; s += 2)
                 {
