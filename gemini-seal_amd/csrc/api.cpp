@@ -795,6 +795,57 @@ long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, 
     });
 }
 
+/* SURVEY 8(e) "latency mode": the decomposition digits of ONE key switch split across devices (one process per GPU; the
+   caller sums the partials with an all-reduce -- RCCL over xGMI -- between the two calls). */
+long sealhip_switch_key_partial(sealhip_context *ctx, uint32_t k, const uint64_t *target, size_t count,
+                                const sealhip_kswitch_key *key, uint32_t digit_begin, uint32_t digit_end, uint64_t *partial)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(target);
+    REQUIRE_PTR(key);
+    REQUIRE_PTR(partial);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        KsSplit split;
+        split.j0 = static_cast<int>(digit_begin);
+        split.j1 = static_cast<int>(digit_end);
+        split.partial_out = reinterpret_cast<u64 *>(partial);
+        op_switch_key(e, static_cast<int>(k), nullptr, 2 * poly, reinterpret_cast<const u64 *>(target), poly, count, key->key,
+                      nullptr, 0, &split);
+    });
+}
+
+long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ct);
+    REQUIRE_PTR(partial_sum);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        check_level(e, k);
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        KsSplit split;
+        split.partial_sum = reinterpret_cast<u64 *>(partial_sum);
+        op_switch_key(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), 2 * poly, nullptr, poly, count, KSwitchKey{}, nullptr, 0,
+                      &split);
+    });
+}
+
+long sealhip_kswitch_digits(sealhip_context *ctx, uint32_t k, uint32_t *digits)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(digits);
+    return guarded([&] {
+        Engine &e = *ctx->engine;
+        check_level(e, k);
+        if (static_cast<int>(k) > e.k_first)
+            throw std::invalid_argument("key switching needs a ciphertext level");
+        *digits = static_cast<uint32_t>((static_cast<int>(k) + e.nsp - 1) / e.nsp); // keygenerator.cpp:334-336
+    });
+}
+
 namespace
 {
     // Transparency as a flag output (sealhip_transparency_sink): an Evaluator entry clears the flags of its batch, then either

@@ -463,7 +463,7 @@ namespace sealhip
     hipError_t launch_ks_mac(const Engine &e, const KsDev *d, const KsDev &h, const u64 *target,
                              std::size_t target_stride, const u64 *ext, std::size_t ext_stride,
                              std::size_t ext_digit_stride, const u64 *key, u64 *prod, std::size_t prod_stride,
-                             std::size_t count);
+                             std::size_t count, int j0 = 0, int j1 = -1); // digits [j0, j1) (default: all of the level)
     hipError_t launch_ks_moddown_pre(const Engine &e, const KsDev *d, const KsDev &h, const u64 *prod,
                                      std::size_t prod_stride, u64 *temp, std::size_t temp_stride, std::size_t npolys);
     // BFV only: steps 1-4 of the rescale + the add into the ciphertext in one kernel; top_deferred = the rows of prod
@@ -502,8 +502,20 @@ namespace sealhip
 
     // ---- composed operations (pipeline.cpp) ----
     // c0_src: see launch_ks_moddown_bfv -- the ciphertext is then write-only: (c0_src + result_0, result_1)
+    // SURVEY 8(e) latency mode: the digits of ONE key switch split across devices. partial_out: only the inner product over
+    // the digits [j0, j1) is formed, reduced to canonical residues and written there (count x 2 x (k + nsp) x N; ct unused).
+    // partial_sum: the element-wise sum of every device's partials (words below ranks * p < 2^63; clobbered): reduced, then
+    // the key switch continues from there (target, key unused). Modular sums are associative, so every later word is the one
+    // the unsplit operation produces.
+    struct KsSplit
+    {
+        int j0 = 0, j1 = 0;
+        u64 *partial_out = nullptr;
+        u64 *partial_sum = nullptr;
+    };
     void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
-                       std::size_t count, const KSwitchKey &key, const u64 *c0_src = nullptr, std::size_t c0_stride = 0);
+                       std::size_t count, const KSwitchKey &key, const u64 *c0_src = nullptr, std::size_t c0_stride = 0,
+                       const KsSplit *split = nullptr);
     void op_modup(Engine &e, int k, int bundle, u64 *ext, std::size_t count);
     void op_bfv_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);
     void op_ckks_multiply(Engine &e, int k, const u64 *a, int sa, const u64 *b, int sb, std::size_t count, u64 *out);

@@ -115,10 +115,10 @@ namespace sealhip
                                                                   std::size_t ext_digit_stride,
                                                                   const u64 *__restrict__ key,
                                                                   u64 *__restrict__ prod, std::size_t prod_stride,
-                                                                  std::size_t count, int logn)
+                                                                  std::size_t count, int logn, int j0, int j1)
         {
             const std::size_t N = static_cast<std::size_t>(1) << logn;
-            const int k = d->k, nsp = d->nsp, rows = k + nsp, nd = d->nd, n_total = d->n_total;
+            const int k = d->k, nsp = d->nsp, rows = k + nsp, n_total = d->n_total;
             const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
             const std::size_t c = i & (N - 1);
             const std::size_t rr = i >> logn;
@@ -132,7 +132,7 @@ namespace sealhip
             const u64 *pkey = key + static_cast<std::size_t>(rns_idx) * N + c;
             const std::size_t key_comp = static_cast<std::size_t>(n_total) * N;
             u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-            for (int j = 0; j < nd; j++)
+            for (int j = j0; j < j1; j++) // (all digits of the level, or one device's share of them: latency mode)
             {
                 const u64 x = j == my_digit ? target[item * target_stride + static_cast<std::size_t>(r) * N + c]
                                             : pext[static_cast<std::size_t>(j) * ext_digit_stride];
@@ -425,10 +425,15 @@ namespace sealhip
     hipError_t launch_ks_mac(const Engine &e, const KsDev *d, const KsDev &h, const u64 *target,
                              std::size_t target_stride, const u64 *ext, std::size_t ext_stride,
                              std::size_t ext_digit_stride, const u64 *key, u64 *prod, std::size_t prod_stride,
-                             std::size_t count)
+                             std::size_t count, int j0, int j1)
     {
         if (!count)
             return hipSuccess;
+        if (j1 < 0)
+            j1 = h.nd;
+        if (j0 < 0 || j0 > j1 || j1 > h.nd)
+            return hipErrorInvalidValue;
+        const bool all_digits = j0 == 0 && j1 == h.nd;
         const u64 *tg = target;
         const std::size_t lanes = (count * static_cast<std::size_t>(h.k + h.nsp)) << e.logn;
         ProfScope prof(e, "ks_mac", 0);
@@ -460,7 +465,7 @@ namespace sealhip
             d, e.d_primes, tg, target_stride, ext, ext_stride, ext_digit_stride, key, prod, prod_stride, count,    \
             e.logn, mac_group);                                                                                     \
         break;
-        switch (count >= 16 ? h.nd : 0)
+        switch (count >= 16 && all_digits ? h.nd : 0)
         {
             SEALHIP_KS_MAC(1)
             SEALHIP_KS_MAC(2)
@@ -481,7 +486,7 @@ namespace sealhip
         default: // small batches or more than 16 digits: one lane per (ciphertext, row, coefficient)
             ks_mac_kernel<<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(d, e.d_primes, tg, target_stride, ext, ext_stride,
                                                                         ext_digit_stride, key, prod, prod_stride, count,
-                                                                        e.logn);
+                                                                        e.logn, j0, j1);
         }
 #undef SEALHIP_KS_MAC
         return hipGetLastError();

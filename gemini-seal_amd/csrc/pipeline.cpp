@@ -112,14 +112,19 @@ namespace sealhip
     // switch_key_inplace (evaluator.cpp:2259-2368)
     // ------------------------------------------------------------------------------------------
     void op_switch_key(Engine &e, int k, u64 *ct, std::size_t ct_stride, const u64 *target, std::size_t target_stride,
-                       std::size_t count, const KSwitchKey &key, const u64 *c0_src, std::size_t c0_stride)
+                       std::size_t count, const KSwitchKey &key, const u64 *c0_src, std::size_t c0_stride, const KsSplit *split)
     {
         if (k > e.k_first)
             throw std::invalid_argument("key switching needs a ciphertext level");
         LevelTools &lt = e.level(k);
         const KsDev &h = lt.h_ks;
-        if (static_cast<int>(key.n_digits) < h.nd)
+        const bool finish = split && split->partial_sum;   // latency mode, after the all-reduce
+        const bool partial = split && split->partial_out;  // latency mode, before it
+        if (!finish && static_cast<int>(key.n_digits) < h.nd)
             throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        const int dj0 = partial ? split->j0 : 0, dj1 = partial ? split->j1 : h.nd;
+        if (dj0 < 0 || dj0 > dj1 || dj1 > h.nd)
+            throw std::invalid_argument("digit range out of bounds");
         const std::size_t N = e.n;
         const int rows = k + e.nsp, nd = h.nd;
         const bool ckks = e.scheme == 2;
@@ -143,16 +148,24 @@ namespace sealhip
             u64 *ext = e.ws_alloc(w_ext * m);
             u64 *prod = e.ws_alloc(w_prod * m);
             u64 *temp = e.ws_alloc(w_temp * m);
-            const u64 *tg = target + off * target_stride;
-            u64 *ctp = ct + off * ct_stride;
+            if (partial)
+                prod = split->partial_out + off * w_prod;
+            if (finish)
+                prod = split->partial_sum + off * w_prod;
+            const u64 *tg = finish ? nullptr : target + off * target_stride;
+            u64 *ctp = partial ? nullptr : ct + off * ct_stride;
             const u64 *c0p = c0_src ? c0_src + off * c0_stride : nullptr;
             const std::size_t ext_item = static_cast<std::size_t>(rows) * N;
             const std::size_t ext_digit = ext_item * m; // digit-major
 
+            if (finish)
+                // the summed canonical partials (below ranks * p < 2^63) back to canonical residues: from here on every word
+                // is what the unsplit inner product (:2341-2349) leaves
+                check(launch_poly_op(e, PolyOp::Mod63, prod, nullptr, 0, prod, m * 2 * rows, map_rows), "mod(partial sum)");
             // Step 1 (:2302-2307): CKKS bundles go back to coefficient form (canonical inverse NTT)
             const u64 *src = tg;
             std::size_t src_stride = target_stride;
-            if (ckks)
+            if (ckks && !finish)
             {
                 // (valid ciphertext rows are below p and the canonicalising top kernel follows: any representative will do)
                 if (ntt_can_gather(e)) // the inverse kernel reads the target rows where they are
@@ -196,9 +209,9 @@ namespace sealhip
                 if (bounds::fwd_lazy_admits(pmax)) // (inputs below 2p: the case the recurrence in ntt_bounds.hpp walks)
                     modup_mode = 0;
             }
-            if (!gather)
+            if (!gather && !finish)
                 check(launch_ks_modup(e, lt.d_ks, h, src, src_stride, ext, ext_item, ext_digit, m, -1), "modup");
-            for (int j = 0; j < nd; j++)
+            for (int j = dj0; j < dj1 && !finish; j++)
             {
                 RowMap mj = map_rows;
                 const int r0 = j * e.nsp, r1 = std::min(r0 + e.nsp, k);
@@ -231,7 +244,7 @@ namespace sealhip
             // STRICT transforms the coefficient-form BFV rows first
             const u64 *inb = tg;
             std::size_t inb_stride = target_stride;
-            if (strict_bfv)
+            if (strict_bfv && !finish)
             {
                 check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
                 check(launch_ntt(e, coeff, m * k, map_q, false, 0), "ntt(target)");
@@ -239,8 +252,11 @@ namespace sealhip
                 inb_stride = static_cast<std::size_t>(k) * N;
             }
             // Step 3b + 4 (:2326-2349): 128-bit inner product over the digits, reduced
-            check(launch_ks_mac(e, lt.d_ks, h, inb, inb_stride, ext, ext_item, ext_digit, key.d_data, prod, w_prod, m),
-                  "mac");
+            if (!finish)
+                check(launch_ks_mac(e, lt.d_ks, h, inb, inb_stride, ext, ext_item, ext_digit, key.d_data, prod, w_prod, m, dj0, dj1),
+                      "mac");
+            if (partial)
+                continue; // the reduced partial products leave here (all-reduce, then op_switch_key with partial_sum)
             if (!ckks && !e.unfused_rns)
             {
                 // BFV: every row of both products goes back to coefficient form in one launch (the reference does the

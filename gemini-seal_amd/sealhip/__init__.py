@@ -95,6 +95,9 @@ SYMBOLS = {
     "sealhip_modup_rns": [_vp, _u32, _u32, _vp, _sz],
     "sealhip_rescale_special_rns_inplace": [_vp, _u32, _vp, _sz],
     "sealhip_switch_key_inplace": [_vp, _u32, _vp, _vp, _sz, _vp],
+    "sealhip_switch_key_partial": [_vp, _u32, _vp, _sz, _vp, _u32, _u32, _vp],
+    "sealhip_switch_key_finish": [_vp, _u32, _vp, _vp, _sz],
+    "sealhip_kswitch_digits": [_vp, _u32, _vp],
     "sealhip_evaluator_multiply": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_square": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_relinearize": [_vp, _u32, _vp, _u32, _sz, C.POINTER(_vp), _u32],
@@ -619,6 +622,21 @@ class Context:
 
     def switch_key_inplace(self, k, ct, target, count, key):
         _check(lib().sealhip_switch_key_inplace(self.handle, k, _ptr(ct), _ptr(target), count, key.handle))
+
+    # ---- SURVEY 8(e) latency mode: the digits of one key switch split across devices
+    def kswitch_digits(self, k):
+        d = C.c_uint32()
+        _check(lib().sealhip_kswitch_digits(self.handle, k, C.byref(d)))
+        return d.value
+
+    def switch_key_partial(self, k, target, count, key, digit_begin, digit_end, partial):
+        """inner product of evaluator.cpp:2302-2349 over the digits [digit_begin, digit_end) -> count x 2 x (k+nsp) x N"""
+        _check(lib().sealhip_switch_key_partial(self.handle, k, _ptr(target), count, key.handle, digit_begin, digit_end,
+                                                _ptr(partial)))
+
+    def switch_key_finish(self, k, ct, partial_sum, count):
+        """the rest of the key switch (evaluator.cpp:2351-2366) on the element-wise sum of every device's partials"""
+        _check(lib().sealhip_switch_key_finish(self.handle, k, _ptr(ct), _ptr(partial_sum), count))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -189,6 +189,17 @@ long sealhip_rescale_special_rns_inplace(sealhip_context *ctx, uint32_t k, uint6
 /* switch_key_inplace: ct is count x 2 x k x N (updated in place), target count x k x N */
 long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, const uint64_t *target, size_t count,
                                 const sealhip_kswitch_key *key);
+/* switch_key_inplace in "latency mode" (SURVEY 8e): the d = ceil(k / nsp) decomposition digits (keygenerator.cpp:334-336;
+   sealhip_kswitch_digits) of ONE key switch shared out over several devices, the key replicated on each. Every device calls
+   _partial for its digits [digit_begin, digit_end): mod-up, forward transforms and the 128-bit inner product of
+   evaluator.cpp:2302-2349 over those digits only, reduced to canonical residues -> partial = count x 2 x (k + nsp) x N words.
+   The caller adds the partials of all devices element-wise (an all-reduce with SUM on 64-bit words: ranks * p < 2^63 cannot
+   wrap) and hands the sum to _finish on the device(s) that need the result: one more reduction, then :2351-2366 as in the
+   unsplit operation (partial_sum is clobbered). Modular sums are associative, so the result is word for word the unsplit one. */
+long sealhip_switch_key_partial(sealhip_context *ctx, uint32_t k, const uint64_t *target, size_t count,
+                                const sealhip_kswitch_key *key, uint32_t digit_begin, uint32_t digit_end, uint64_t *partial);
+long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count);
+long sealhip_kswitch_digits(sealhip_context *ctx, uint32_t k, uint32_t *digits);
 
 /* ---------------------------------------------------------------- L4: Evaluator operations (native/src/seal/evaluator.h)
    All are batched over `count` independent ciphertexts at level k. */

@@ -1406,19 +1406,27 @@ int ref_ckks_multiply(ref_context *c, size_t k, const uint64_t *a, size_t sa, co
     return 0;
 }
 
-/* evaluator.cpp:2259-2368 */
-int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key)
+/* evaluator.cpp:2259-2368, with the split SURVEY 8(e) "latency mode" describes: the inner product over the digits
+ * [j0, j1) only, its two 128-bit accumulators reduced to canonical residues and handed out (`partial_out`, 2 x rows x n) --
+ * or, on the other side of the all-reduce, the sum of such partials taken in (`partial_in`, every word below
+ * ranks * p < 2^63) and reduced once more before the reference's tail (:2351-2366) runs. Modular sums are associative: the
+ * canonical residue of the summed partials is the canonical residue of the whole 128-bit sum, so every later word is the one
+ * the unsplit function produces. Both NULL and [0, n_bundles): the function as the reference has it. */
+static int switch_key_core(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key, size_t j0,
+                           size_t j1, uint64_t *partial_out, const uint64_t *partial_in)
 {
     const size_t n = c->n, n_ct = k, n_all = c->k_first, n_total = c->n_key, nsp = n_total - n_all;
     const size_t n_bundles = (n_ct + nsp - 1) / nsp;
     const int is_ckks = c->scheme == REF_SCHEME_CKKS;
     const int strict = c->mode == REF_MODE_STRICT;
     const size_t rows = n_ct + nsp;
+    if (j1 > n_bundles || j0 > j1)
+        return -1;
     u128 *lazy[2];
     lazy[0] = (u128 *)calloc(rows * n, sizeof(u128));
     lazy[1] = (u128 *)calloc(rows * n, sizeof(u128));
     uint64_t *ext = (uint64_t *)malloc(sizeof(uint64_t) * rows * n);
-    for (size_t j = 0; j < n_bundles; j++)
+    for (size_t j = j0; j < j1 && !partial_in; j++)
     {
         size_t rns0 = j * nsp;
         size_t rns1 = rns0 + nsp < n_ct ? rns0 + nsp : n_ct;
@@ -1474,12 +1482,20 @@ int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_
             int is_sp = r >= n_ct;
             size_t rns_idx = is_sp ? n_all + r - n_ct : r;
             const u128 *acc = lazy[b] + r * n;
-            uint64_t *dst = ext + r * n;
-            for (size_t l = 0; l < n; l++)
-                dst[l] = ref_barrett_reduce_128((uint64_t)acc[l], (uint64_t)(acc[l] >> 64), &c->key_mod[rns_idx]);
+            uint64_t *dst = partial_out ? partial_out + ((size_t)b * rows + r) * n : ext + r * n;
+            if (partial_in) /* latency mode, after the all-reduce: the summed canonical partials, reduced */
+                for (size_t l = 0; l < n; l++)
+                    dst[l] = ref_barrett_reduce_63(partial_in[((size_t)b * rows + r) * n + l], &c->key_mod[rns_idx]);
+            else
+                for (size_t l = 0; l < n; l++)
+                    dst[l] = ref_barrett_reduce_128((uint64_t)acc[l], (uint64_t)(acc[l] >> 64), &c->key_mod[rns_idx]);
+            if (partial_out)
+                continue; /* latency mode, before the all-reduce: the reduced partial leaves here */
             if (is_sp)
                 ref_ntt_inverse_lazy(dst, &c->key_tables[rns_idx]);
         }
+        if (partial_out)
+            continue;
         /* :2361 */
         ref_rescale_special_rns_inplace(ext, is_ckks, n, n_ct, nsp, c->key_mod, n_total, c->key_tables, strict);
         /* :2363-2366 */
@@ -1491,6 +1507,25 @@ int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_
     free(lazy[1]);
     free(ext);
     return 0;
+}
+
+int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key)
+{
+    const size_t nsp = c->n_key - c->k_first;
+    return switch_key_core(c, k, ct, target, key, 0, (k + nsp - 1) / nsp, NULL, NULL);
+}
+
+/* SURVEY 8(e) latency mode: the digits [j0, j1) of one key switch -> 2 x (k + nsp) x n canonical partial products */
+int ref_switch_key_partial(ref_context *c, size_t k, const uint64_t *target, const uint64_t *key, size_t j0, size_t j1,
+                           uint64_t *partial)
+{
+    return switch_key_core(c, k, NULL, target, key, j0, j1, partial, NULL);
+}
+
+/* ... and the rest of the key switch on the element-wise SUM of every rank's partials (words below 2^63) */
+int ref_switch_key_finish(ref_context *c, size_t k, uint64_t *ct, const uint64_t *partial_sum)
+{
+    return switch_key_core(c, k, ct, NULL, NULL, 0, 0, NULL, partial_sum);
 }
 
 /* evaluator.cpp:772-827: the target is always the LAST polynomial (the iterator is never moved). */

@@ -174,6 +174,11 @@ int ref_ckks_square(ref_context *c, size_t k, const uint64_t *a, size_t sa, uint
 /* evaluator.cpp:2259-2368; ct = 2 polys (k rows) updated in place; target = k rows;
    key = digits x 2 x n_key x N (K1 layout, keygenerator.cpp:325-369) */
 int ref_switch_key_inplace(ref_context *c, size_t k, uint64_t *ct, const uint64_t *target, const uint64_t *key);
+/* SURVEY 8(e) "latency mode": the digits of ONE key switch split across devices -- partial inner products over the digits
+   [j0, j1) as canonical residues (2 x (k + nsp) x n words), summed by an all-reduce, then the rest of the key switch */
+int ref_switch_key_partial(ref_context *c, size_t k, const uint64_t *target, const uint64_t *key, size_t j0, size_t j1,
+                           uint64_t *partial);
+int ref_switch_key_finish(ref_context *c, size_t k, uint64_t *ct, const uint64_t *partial_sum);
 /* evaluator.cpp:772-827; ct has `size` polys, keys[i] is the key for RelinKeys::get_index(i+2) */
 int ref_relinearize(ref_context *c, size_t k, uint64_t *ct, size_t size, const uint64_t *const *keys);
 /* evaluator.cpp:829-892 (BFV mod_switch_to_next / CKKS rescale_to_next); out has `size` polys of k-1 rows */

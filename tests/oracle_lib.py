@@ -176,6 +176,8 @@ def lib():
     L.ref_bfv_square.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_ckks_square.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_switch_key_inplace.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_switch_key_partial.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p, szt, szt, C.c_void_p]
+    L.ref_switch_key_finish.argtypes = [C.POINTER(Context), szt, C.c_void_p, C.c_void_p]
     L.ref_relinearize.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.POINTER(C.c_void_p)]
     L.ref_mod_switch_scale_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]
     L.ref_mod_switch_drop_to_next.argtypes = [C.POINTER(Context), szt, C.c_void_p, szt, C.c_void_p]

@@ -676,6 +676,53 @@ def test_level_down_reads_ciphertexts_at_a_stride(sealhip, scheme, logn, bits):
         ev.mod_switch_to_next(dw, 2, k, count, ctx.alloc(count * 2 * (k - 1) * n), item_stride=2 * k * n - 1)
 
 
+@pytest.mark.parametrize("scheme,logn,bits,nsp", [(2, 15, [50] * 6, 1), (1, 15, [55] * 6, 1), (2, 12, [40, 40, 40, 41, 42], 2),
+                                                  (1, 12, [36, 36, 37, 38, 39], 1), (2, 15, [58, 56, 50, 50, 59], 1)])
+def test_latency_mode_key_switch_split_over_digit_groups(sealhip, scheme, logn, bits, nsp):
+    """SURVEY 8(e) latency mode on one device: the digits of a key switch (evaluator.cpp:2259-2368) are formed in two or
+    three groups as they would be on two or three GPUs (sealhip_switch_key_partial), the partial products are added word by
+    word -- what all_reduce(SUM) does -- and sealhip_switch_key_finish runs the rest. Result == the unsplit
+    sealhip_switch_key_inplace == the oracle, word for word; the partials equal the oracle's split as well."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    ctx = sealhip.Context(scheme, logn, kmods, nsp, 65537 if scheme == 1 else 0)
+    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=65537 if scheme == 1 else 0)
+    k = ctx.k_first
+    nd = ctx.kswitch_digits(k)
+    assert nd == (k + nsp - 1) // nsp
+    rng = np.random.default_rng(31 * logn + scheme)
+    count = 3
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(nd)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    ct = _rand_ct(rng, kmods[:k], 2, n, count)
+    target = _rand_ct(rng, kmods[:k], 1, n, count)[:, 0].copy()
+    one = ctx.upload(ct)
+    ctx.switch_key_inplace(k, one, ctx.upload(target), count, dkey)
+    want = one.download(ct.shape)
+    exp = ct.copy()
+    for c in range(count):
+        assert L.ref_switch_key_inplace(C.byref(ref.c), k, O.ptr(exp[c]), O.ptr(target[c]), O.ptr(key)) == 0
+    assert np.array_equal(want, exp), "unsplit key switch vs oracle"
+    rows = k + nsp
+    dtarget = ctx.upload(target)
+    for groups in (2, 3):
+        cuts = [(g * nd) // groups for g in range(groups + 1)]
+        total = np.zeros((count, 2, rows, n), dtype=np.uint64)
+        for g in range(groups):
+            part = ctx.alloc(count * 2 * rows * n)
+            ctx.switch_key_partial(k, dtarget, count, dkey, cuts[g], cuts[g + 1], part)
+            got_p = part.download(total.shape)
+            ep = np.zeros((2, rows, n), dtype=np.uint64)
+            assert L.ref_switch_key_partial(C.byref(ref.c), k, O.ptr(target[0]), O.ptr(key), cuts[g], cuts[g + 1], O.ptr(ep)) == 0
+            assert np.array_equal(got_p[0], ep), ("partial", groups, g)
+            total += got_p  # (below groups * p < 2^63)
+        split = ctx.upload(ct)
+        ctx.switch_key_finish(k, split, ctx.upload(total), count)
+        assert np.array_equal(split.download(ct.shape), want), ("finish", groups)
+    with pytest.raises(ValueError):
+        ctx.switch_key_partial(k, dtarget, count, dkey, 0, nd + 1, ctx.alloc(count * 2 * rows * n))
+
+
 def test_inplace_ntt_handoff_from_three_lanes_at_once(sealhip):
     """The forward single-pass kernel's sibling hand-off (a cross-workgroup ticket per row, a bounded wait, a sticky fault
     word) when several host threads drive ONE context at the same time: every thread has its own lane -- stream, ticket
@@ -2392,6 +2439,26 @@ def test_bench_rccl_path_with_one_rank(launcher):
     assert line["gather"]["bytes_per_rank"] == 16 * 2 * 7 * 32768 * 8
     assert line["verified_vs_oracle"] is True and line["verified_items"] == [0, 32, 63]
     assert line["key_replicated"] is True and line["roofline"]["kernel"] == "ntt_fwd_half"
+
+
+def test_latency_mode_tool_runs_its_all_reduce_on_rccl():
+    """tools/latency_mode.py (the digits of one key switch split over the ranks, partial products summed by
+    all_reduce over RCCL, the rest on every rank) as a child process under torch.distributed.run with one rank: the
+    collective executes on the nccl backend and the split key switch equals the unsplit one (evaluator.cpp:2259-2368)."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tool = os.path.join(os.path.dirname(HERE), "tools", "latency_mode.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29585", tool, "--config", "3", "--reps", "2"],
+                       env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode("utf-8", "replace")
+    assert r.returncode == 0, (out[-800:], r.stderr.decode("utf-8", "replace")[-800:])
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert line["split_equals_unsplit"] is True and line["ranks"] == 1 and line["digits"] == 7
 
 
 @pytest.mark.parametrize("config,batch", [(4, 9), (5, 3)])

@@ -133,6 +133,22 @@ def test_multi_rank_sharding_plan_gloo():
     assert "SHARD_OK" in out.stdout
 
 
+def test_latency_mode_digit_sharding_gloo():
+    """SURVEY 8(e) latency mode on CPU with two gloo ranks: the digits of one key switch sharded contiguously over the ranks,
+    partial inner products (the oracle's split of evaluator.cpp:2259-2368) summed by all_reduce(SUM) on 64-bit words, the
+    rest of the key switch on the sum == the unsplit key switch, for CKKS / BFV and 1, 2, 3 special primes."""
+    import subprocess
+    import sys
+
+    script = os.path.join(ROOT, "tests", "_gloo_latency_worker.py")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+         "127.0.0.1", "--master-port", "29575", script],
+        capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "LATENCY_OK" in out.stdout
+
+
 def test_bench_spawns_its_own_ranks_and_gathers_gloo():
     """`python bench.py --gpus 2` with no launcher around it must start its two ranks itself (a child
     torch.distributed.run, never an exec), run the per-rank setup (rank-dependent ciphertext seed, replicated key,
