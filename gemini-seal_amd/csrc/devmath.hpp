@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include "ntt_bounds.hpp"
 
 namespace sealhip
 {
@@ -471,6 +472,8 @@ namespace sealhip
     template <int NTERMS>
     struct DotAcc
     {
+        static_assert(bounds::dotacc_ok(NTERMS, bounds::kDotAccOperandBits),
+                      "carry-free accumulators: NTERMS products of 61-bit operands must fit (ntt_bounds.hpp section 5)");
         static constexpr int NM = (2 * NTERMS + 7) / 8;
         u64 l0 = 0, l1 = 0, h = 0;
         u64 m[NM] = {};

@@ -281,5 +281,35 @@ namespace sealhip
         {
             return p <= max_prime_of_bits(kFpPrimeBits);
         }
+        // =====================================================================================================
+        // 5. Carry-free 128-bit dot products of the BEHZ kernels (devmath.hpp DotAcc<NTERMS>): sum_i t_i c_i with every
+        // partial product in a 64-bit accumulator that is only assembled at the end. With operands below 2^bits
+        // (t = t1 2^32 + t0, t0 = t01 2^16 + t00; c = c1 2^32 + c0): l0 += t00 c0 and l1 += t01 c0 (below 2^48 each), h +=
+        // t1 c1 (below 2^(2 bits - 64)), and NM = (2 NTERMS + 7) / 8 middle accumulators that take the 2 NTERMS products
+        // t0 c1, t1 c0 (below 2^(bits)) round-robin -- at most ceil(2 NTERMS / NM) each. Every accumulator must stay below 2^64.
+        constexpr bool dotacc_ok(int nterms, int bits)
+        {
+            if (nterms < 1 || bits < 33 || bits > 64)
+                return false;
+            const u128 lim = kWord;
+            const int nm = (2 * nterms + 7) / 8;
+            const int per_m = (2 * nterms + nm - 1) / nm;
+            const u128 low = static_cast<u128>(nterms) << 48;                  // l0, l1
+            const u128 mid = static_cast<u128>(per_m) << bits;                 // t0 c1 < 2^32 2^(bits-32)
+            const u128 high = static_cast<u128>(nterms) << (2 * (bits - 32));  // t1 c1
+            return low <= lim && mid <= lim && high <= lim;
+        }
+        constexpr int kDotAccOperandBits = 61; // SEAL_MOD_BIT_COUNT_MAX: residues and constants of every prime the context admits
+        constexpr int dotacc_max_terms()
+        {
+            int n = 0;
+            for (int t = 1; t <= 4096; t++)
+                if (dotacc_ok(t, kDotAccOperandBits))
+                    n = t;
+                else
+                    break;
+            return n;
+        }
+        static_assert(dotacc_max_terms() >= 64, "DotAcc on 61-bit operands: at least 64 terms (the kernels use up to k + 2 <= 34)");
     } // namespace bounds
 } // namespace sealhip

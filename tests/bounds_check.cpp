@@ -323,9 +323,44 @@ static void inv_lazy_execution(int T, u64 p)
     CHECK(below_2p, "inverse lazy execution T=%d: outputs must be below 2p", T);
 }
 
+// ---- devmath.hpp DotAcc<NTERMS> executed on the largest operands: every accumulator tracked in 128 bits
+static void dotacc_execution()
+{
+    for (int n = 1; n <= 64; n++)
+    {
+        CHECK(dotacc_ok(n, kDotAccOperandBits), "DotAcc<%d> on 61-bit operands should be admitted", n);
+        const int nm = (2 * n + 7) / 8;
+        const u64 t = (u64(1) << 61) - 1, c = (u64(1) << 61) - 1; // all operands at the top of the admitted range
+        u128 l0 = 0, l1 = 0, h = 0, m[16] = {};
+        u128 exact = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const u64 t0 = t & 0xFFFFFFFFu, t1 = t >> 32, t00 = t0 & 0xFFFFu, t01 = t0 >> 16, c0 = c & 0xFFFFFFFFu, c1 = c >> 32;
+            l0 += static_cast<u128>(t00) * c0;
+            l1 += static_cast<u128>(t01) * c0;
+            m[(2 * i) % nm] += static_cast<u128>(t0) * c1;
+            m[(2 * i + 1) % nm] += static_cast<u128>(t1) * c0;
+            h += static_cast<u128>(t1) * c1;
+            exact += static_cast<u128>(t) * c;
+        }
+        bool fits = l0 < kWord && l1 < kWord && h < kWord;
+        u128 sum = (h << 64) + l0 + (l1 << 16);
+        for (int i = 0; i < nm; i++)
+        {
+            fits = fits && m[i] < kWord;
+            sum += m[i] << 32;
+        }
+        CHECK(fits, "DotAcc<%d>: an accumulator passes 2^64 on 61-bit operands", n);
+        CHECK(sum == exact, "DotAcc<%d>: assembled sum differs from the exact one", n);
+    }
+    // tight: one more operand bit and the middle accumulators (eight products each at NTERMS = 8) no longer fit
+    CHECK(!dotacc_ok(8, kDotAccOperandBits + 1), "DotAcc predicate not tight at 62 bits");
+}
+
 int main()
 {
     std::fesetround(FE_TONEAREST);
+    dotacc_execution();
     enumerate_predicates();
     regression_whole_row();
     fp_product_model();
