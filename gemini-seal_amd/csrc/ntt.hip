@@ -1032,8 +1032,16 @@ namespace sealhip
             return ls;
         }
         // -> false when the block has nothing to do; else the polynomial index and the position among the live slots
+        // poly_major = g > 0 (the key switch's digit launches, whose live rows all gather ONE source row): groups of g live
+        // positions interleaved item by item, so that g readers of a source row run next to each other on one XCD and the row is
+        // fetched from HBM n_live / g times instead of n_live times -- at the price of an XCD touching up to 2g twiddle tables
+        // instead of two. Round 3, config 3 (integer instances, seven readers per source row, 512 KB per table): forward
+        // transforms 17.34 ms per 1024 pairs at g = 1, 17.18 / 17.10 / 16.98 at g = 2 / 3 / 4, 17.13 at g = 7 (the tables start
+        // to thrash the 4 MB L2); step 44.98 -> 44.51 ms at g = 4. Config 4 (FP64, eleven readers): the transforms gain 2.5 % at
+        // g = 11 but the inner product, which reads what they wrote in the old order, loses as much: off there.
+        // SEALHIP_NTT_POLY_MAJOR (bit 0: FP64 launches, bit 1: integer; default 2) and SEALHIP_NTT_POLY_GROUP (default 4).
         __device__ __forceinline__ bool half_block_map(unsigned bid, std::size_t npolys, int n_live, std::size_t chunk,
-                                                       std::size_t &poly, int &position, int &half)
+                                                       std::size_t &poly, int &position, int &half, int poly_major = 0)
         {
             const unsigned xcd = bid & 7u;
             const std::size_t slot = bid >> 3;
@@ -1041,6 +1049,27 @@ namespace sealhip
             const std::size_t v = static_cast<std::size_t>(xcd) * chunk + (slot >> 1);
             if ((slot >> 1) >= chunk || v >= npolys * static_cast<std::size_t>(n_live))
                 return false;
+            if (poly_major)
+            {
+                // groups of g consecutive live positions interleaved item by item: v = (group * npolys + poly) * g + b
+                // (g = n_live: item-major; the last group may be shorter)
+                const int g = poly_major;
+                const std::size_t full = static_cast<std::size_t>(n_live / g) * npolys * g; // rows in complete groups
+                if (v < full)
+                {
+                    const std::size_t gp = v / g;
+                    position = static_cast<int>(gp / npolys) * g + static_cast<int>(v - gp * g);
+                    poly = gp % npolys;
+                }
+                else
+                {
+                    const int rem = n_live % g; // > 0 here
+                    const std::size_t u = v - full, gp = u / rem;
+                    position = (n_live / g) * g + static_cast<int>(u - gp * rem);
+                    poly = gp;
+                }
+                return true;
+            }
             poly = v % npolys;
             position = static_cast<int>(v / npolys);
             return true;
@@ -1144,7 +1173,8 @@ namespace sealhip
             const int wave_base = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) & ~63);
             int half, position;
             std::size_t poly;
-            if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
+            if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half,
+                                (flags & kNttPolyMajor) ? ((flags >> 16) & 0xFF) : 0))
                 return;
             const std::size_t row = poly * map.rows + live.slot[position];
             const unsigned short pid = map.prime[row % map.rows];
@@ -2145,6 +2175,18 @@ namespace sealhip
             unsigned *tickets = no_handoff ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
             if (e.ntt_suppress_signal)
                 flags |= kNttDebugNoSignal; // sealhip_debug_ntt_handoff: drive the time-out path
+            {
+                // (see half_block_map): bit 0 = FP64 digit launches, bit 1 = integer ones
+                static const int poly_major = [] {
+                    const char *env = std::getenv("SEALHIP_NTT_POLY_MAJOR");
+                    return env ? std::atoi(env) : 2;
+                }();
+                bool one_source = poly_major && all_gathered && src.reduce_mode <= 2 && live.n > 1;
+                for (int i = 1; one_source && i < live.n; i++) // every live row gathers the same source row (a key-switch digit)
+                    one_source = ((src.code[live.slot[i]] ^ src.code[live.slot[0]]) & ~kSrcReduce) == 0;
+                if (one_source)
+                    flags |= kNttPolyMajorRequest;
+            }
             if (!tickets && !no_handoff)
                 return hipErrorOutOfMemory;
 #ifdef SEALHIP_NTT_EXPERIMENT
@@ -2195,6 +2237,17 @@ namespace sealhip
                 else
                     for (std::size_t i = 0; fp && i < e.key_moduli.size(); i++)
                         fp = e.key_moduli[i] < bounds::kFpInputBound;
+            }
+            if (flags & kNttPolyMajorRequest)
+            {
+                static const int poly_major = std::getenv("SEALHIP_NTT_POLY_MAJOR") ? std::atoi(std::getenv("SEALHIP_NTT_POLY_MAJOR")) : 2;
+                static const int group = std::getenv("SEALHIP_NTT_POLY_GROUP") ? std::atoi(std::getenv("SEALHIP_NTT_POLY_GROUP")) : 4;
+                flags &= ~kNttPolyMajorRequest;
+                if (poly_major & (fp ? 1 : 2))
+                {
+                    const int g = group > 0 && group < live.n ? group : live.n;
+                    flags |= kNttPolyMajor | (g << 16);
+                }
             }
             if (flags & kNttAnyRep)
             {
