@@ -329,8 +329,13 @@ namespace sealhip
             x_hi = mulmod_lazy(u - v + P.two_p, P.inv_n_w, P.inv_n_w_shoup, P.p);
         }
 
-        // One lane per (polynomial, prime q, coefficient pair c / c + N/2): every input word is read exactly once.
-        template <bool DEFER>
+        // One lane per (polynomial, coefficient pair c / c + N/2), walking the k ciphertext primes: the special rows (and, with
+        // DEFER, their top inverse-NTT layer) are read and reduced ONCE per column pair -- round 3; one lane per (polynomial,
+        // prime, pair) had every q lane fetch and transform them again: 6 of 28 row passes per polynomial at config 3 -- every
+        // other input word exactly once.
+        // ONE: a single special prime (every BASELINE config): its reduced pair lives in two registers across the loop; several
+        // special primes re-read their rows per ciphertext prime (the lane's own addresses: L1 hits) as before.
+        template <bool DEFER, bool ONE>
         __global__ __launch_bounds__(kThreads) void ks_moddown_bfv_kernel(const KsDev *__restrict__ d,
                                                                           const PrimeDev *__restrict__ primes,
                                                                           const u64 *__restrict__ prod,
@@ -343,62 +348,67 @@ namespace sealhip
             const int k = d->k, nsp = d->nsp;
             const std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x;
             const std::size_t c = i & (half - 1);
-            const std::size_t rr = i >> (logn - 1);
-            const int q = static_cast<int>(rr % k);
-            const std::size_t poly = rr / k;
+            const std::size_t poly = i >> (logn - 1);
             if (poly >= npolys)
                 return;
-            const PrimeDev &Q = primes[d->row_prime[q]];
             const u64 *pp = prod + poly * prod_stride;
-            // steps 1-2 for this lane's prime (multi_special_primes.cpp:253-282)
-            u64 temp[2];
-            if (nsp == 1)
+            // steps 1-2, the part that does not depend on the ciphertext prime (multi_special_primes.cpp:253-273)
+            u64 sred[2] = {0, 0};
+            if constexpr (ONE)
             {
                 const PrimeDev &S = primes[d->row_prime[k]];
                 u64 sv[2];
                 row_pair<DEFER>(pp + static_cast<std::size_t>(k) * N, c, half, S, sv[0], sv[1]);
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                {
-                    const u64 v = neg_mod(barrett_reduce_63(sv[h], S.p, S.cr1), S.p); // :270-273
-                    temp[h] = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
-                }
+                    sred[h] = neg_mod(barrett_reduce_63(sv[h], S.p, S.cr1), S.p); // :270-273
             }
-            else
+            u64 nz = 0;
+            for (int q = 0; q < k; q++)
             {
-                u64 lo[2] = {0, 0}, hi[2] = {0, 0};
-                for (int j = 0; j < nsp; j++)
+                const PrimeDev &Q = primes[d->row_prime[q]];
+                u64 temp[2];
+                if constexpr (ONE)
                 {
-                    const PrimeDev &S = primes[d->row_prime[k + j]];
-                    u64 sv[2];
-                    row_pair<DEFER>(pp + static_cast<std::size_t>(k + j) * N, c, half, S, sv[0], sv[1]);
 #pragma unroll
                     for (int h = 0; h < 2; h++)
-                    {
-                        const u64 y = mulmod_shoup(sv[h], d->inv_hat[j], d->inv_hat_shoup[j], S.p); // :262-267
-                        mac128(lo[h], hi[h], y, d->neg_hat[q * nsp + j]);
-                    }
+                        temp[h] = barrett_reduce_128(sred[h], 0, Q.p, Q.cr0, Q.cr1);
                 }
-                temp[0] = barrett_reduce_128(lo[0], hi[0], Q.p, Q.cr0, Q.cr1);
-                temp[1] = barrett_reduce_128(lo[1], hi[1], Q.p, Q.cr0, Q.cr1);
-            }
-            // step 4 (:291-302) and the add into the ciphertext
-            u64 pv[2];
-            row_pair<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q, pv[0], pv[1]);
-            u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
-            u64 nz = 0;
+                else
+                {
+                    u64 lo[2] = {0, 0}, hi[2] = {0, 0};
+                    for (int j = 0; j < nsp; j++)
+                    {
+                        const PrimeDev &S = primes[d->row_prime[k + j]];
+                        u64 sv[2];
+                        row_pair<DEFER>(pp + static_cast<std::size_t>(k + j) * N, c, half, S, sv[0], sv[1]);
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-            {
-                const u64 v = mulmod_shoup(pv[h] + temp[h], d->invP[q], d->invP_shoup[q], Q.p);
-                u64 w;
-                if (!c0_src)
-                    w = add_mod(v, pc[h * half], Q.p);
-                else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
-                    w = (poly & 1) ? v
-                                   : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c + h * half], Q.p);
-                pc[h * half] = w;
-                nz |= w;
+                        for (int h = 0; h < 2; h++)
+                        {
+                            const u64 y = mulmod_shoup(sv[h], d->inv_hat[j], d->inv_hat_shoup[j], S.p); // :262-267
+                            mac128(lo[h], hi[h], y, d->neg_hat[q * nsp + j]);
+                        }
+                    }
+                    temp[0] = barrett_reduce_128(lo[0], hi[0], Q.p, Q.cr0, Q.cr1);
+                    temp[1] = barrett_reduce_128(lo[1], hi[1], Q.p, Q.cr0, Q.cr1);
+                }
+                // step 4 (:291-302) and the add into the ciphertext
+                u64 pv[2];
+                row_pair<DEFER>(pp + static_cast<std::size_t>(q) * N, c, half, Q, pv[0], pv[1]);
+                u64 *pc = ct + (poly >> 1) * ct_item_stride + ((poly & 1) * static_cast<std::size_t>(k) + q) * N + c;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    const u64 v = mulmod_shoup(pv[h] + temp[h], d->invP[q], d->invP_shoup[q], Q.p);
+                    u64 w;
+                    if (!c0_src)
+                        w = add_mod(v, pc[h * half], Q.p);
+                    else // apply_galois: the ciphertext is (c0_src, 0) and only written here (evaluator.cpp:1903-1935)
+                        w = (poly & 1) ? v
+                                       : add_mod(v, c0_src[(poly >> 1) * c0_stride + static_cast<std::size_t>(q) * N + c + h * half], Q.p);
+                    pc[h * half] = w;
+                    nz |= w;
+                }
             }
             if (poly & 1) // component 1 of ciphertext poly >> 1: what is_transparent looks at
                 note_nonzero(tflags, poly >> 1, nz);
@@ -509,14 +519,20 @@ namespace sealhip
     {
         if (!npolys)
             return hipSuccess;
-        const std::size_t lanes = (npolys * static_cast<std::size_t>(h.k)) << (e.logn - 1); // one lane per coefficient pair
+        const std::size_t lanes = npolys << (e.logn - 1); // one lane per (polynomial, coefficient pair)
         ProfScope prof(e, "ks_moddown_bfv", 0);
-        if (top_deferred)
-            ks_moddown_bfv_kernel<true><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride, e.lane().tsink_arm);
+#define SEALHIP_MODDOWN_BFV(DEFER_, ONE_)                                                                            \
+    ks_moddown_bfv_kernel<DEFER_, ONE_><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(                              \
+        d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride, e.lane().tsink_arm)
+        if (top_deferred && h.nsp == 1)
+            SEALHIP_MODDOWN_BFV(true, true);
+        else if (top_deferred)
+            SEALHIP_MODDOWN_BFV(true, false);
+        else if (h.nsp == 1)
+            SEALHIP_MODDOWN_BFV(false, true);
         else
-            ks_moddown_bfv_kernel<false><<<blocks_for(lanes), kThreads, 0, e.lane().stream>>>(
-                d, e.d_primes, prod, prod_stride, ct, ct_item_stride, npolys, e.logn, c0_src, c0_stride, e.lane().tsink_arm);
+            SEALHIP_MODDOWN_BFV(false, false);
+#undef SEALHIP_MODDOWN_BFV
         return hipGetLastError();
     }
 
