@@ -34,7 +34,8 @@ out += ["", "Bench line of the same build (`bench_with_traffic.jsonl`, traffic m
         "- forward NTT per row from the counters: read %.1f KB (x%.3f of 262.1), **written %.1f KB (x%.4f of 262.1)** -- round 2 wrote 317.5 KB "
         "(x1.21): the excess was the 16-byte nontemporal pieces at a 32-byte stride reaching the fabric as partial writes before "
         "their neighbours arrived; with the register transposition every store instruction covers contiguous memory and the "
-        "excess is gone (what is left of the read excess: twiddle tables and the sibling's half of in-place rows that missed L2)" % (
+        "excess is gone. Reads: below the algorithmic 262 KB on average since the key-switch digit launches run four readers of a source "
+        "row on one XCD (they find it in L2); the in-place launches read ~292 KB (twiddle tables, the sibling's half where it missed L2)" % (
             fw["read_bytes_per_row"] / 1e3, fw["read_bytes_per_row"] / 262144, fw["write_bytes_per_row"] / 1e3, fw["write_bytes_per_row"] / 262144),
         "- NTT-only section (the BASELINE `forward-NTT/s` metric, canonical `ntt_negacyclic_harvey`, %d rows per launch): %.2f M forward NTT/s = **%.3f** "
         "of the HBM roofline" % (b["ntt"]["rows"], b["ntt"]["forward_ntt_per_s"] / 1e6, b["ntt"]["hbm_roofline_frac"]),
