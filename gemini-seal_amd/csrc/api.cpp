@@ -817,7 +817,8 @@ long sealhip_switch_key_partial(sealhip_context *ctx, uint32_t k, const uint64_t
     });
 }
 
-long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count)
+long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count,
+                               uint32_t n_partials)
 {
     REQUIRE_PTR(ctx);
     REQUIRE_PTR(ct);
@@ -825,6 +826,13 @@ long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, u
     return guarded([&] {
         Engine &e = device_engine(ctx);
         check_level(e, k);
+        // the sum of n_partials canonical residues is reduced with barrett_reduce_63 (words below 2^63): refuse a world
+        // size that could pass it (61-bit key primes: more than 4 partials) instead of wrapping silently
+        if (n_partials < 1)
+            throw std::invalid_argument("n_partials: at least one partial was summed");
+        for (u64 p : e.key_moduli)
+            if (static_cast<unsigned __int128>(n_partials) * (p - 1) >= (static_cast<unsigned __int128>(1) << 63))
+                throw std::invalid_argument("n_partials * max(key prime) reaches 2^63: reduce the partials before summing more of them");
         const std::size_t poly = static_cast<std::size_t>(k) * e.n;
         KsSplit split;
         split.partial_sum = reinterpret_cast<u64 *>(partial_sum);
@@ -851,31 +859,44 @@ namespace
     // Transparency as a flag output (sealhip_transparency_sink): an Evaluator entry clears the flags of its batch, then either
     // lets the final kernel of the operation write them (fused: multiply, square, relinearize, apply_galois) or runs the
     // read pass over its result (the remaining entries).
+    // Order of effects: the constructor VALIDATES the capacity and nothing else, so an entry can build its
+    // scope before its first launch and a call rejected for any reason leaves both the data and the caller's flags as they
+    // were. The flags are cleared where they start to be written: by begin() (fused entries call it after their argument
+    // checks, right before the operation), by arm() (relinearize: before its last key switch) or by read_pass().
     struct SinkScope
     {
         Engine &e;
         Lane &l;
         bool on;
-        SinkScope(Engine &eng, size_t count, bool fused) : e(eng), l(eng.lane()), on(l.tsink != nullptr)
+        size_t count;
+        bool cleared = false;
+        SinkScope(Engine &eng, size_t n) : e(eng), l(eng.lane()), on(l.tsink != nullptr), count(n)
         {
-            if (!on)
-                return;
-            if (count > l.tsink_cap)
+            if (on && count > l.tsink_cap)
                 throw std::invalid_argument("the transparency sink is smaller than this batch");
-            if (count)
-                SEALHIP_CHECK(hipMemsetAsync(l.tsink, 0, count * sizeof(unsigned), l.stream));
-            l.tsink_base = 0;
-            l.tsink_cur = fused ? l.tsink : nullptr;
         }
-        void arm() // (relinearize: only its last key switch stores the final polynomial 1)
+        void clear()
         {
+            if (on && !cleared && count)
+                SEALHIP_CHECK(hipMemsetAsync(l.tsink, 0, count * sizeof(unsigned), l.stream));
+            cleared = true;
+            l.tsink_base = 0;
+        }
+        void begin() // fused entries (multiply, square, apply_galois): the operation's last kernel writes the flags
+        {
+            clear();
             if (on)
                 l.tsink_cur = l.tsink;
         }
-        void read_pass(const u64 *result, uint32_t size, size_t poly_words, size_t count)
+        void arm() // (relinearize: only its last key switch stores the final polynomial 1)
         {
-            if (on && size >= 2 && count)
-                check_launch(launch_nonzero_tail(e, result, poly_words * size, poly_words, count, l.tsink), "transparency");
+            begin();
+        }
+        void read_pass(const u64 *result, uint32_t size, size_t poly_words, size_t n)
+        {
+            clear();
+            if (on && size >= 2 && n)
+                check_launch(launch_nonzero_tail(e, result, poly_words * size, poly_words, n, l.tsink), "transparency");
         }
         ~SinkScope()
         {
@@ -884,15 +905,20 @@ namespace
         }
     };
 
-    // Evaluator::multiply (evaluator.cpp:235-527) on device batches
-    void do_multiply(Engine &e, uint32_t k, const u64 *a, uint32_t size_a, const u64 *b, uint32_t size_b, size_t count, u64 *out)
+    // SEAL_CIPHERTEXT_SIZE_MIN/MAX (util/defines.h:56-57) and the aliasing rule of the raw-buffer form
+    void check_multiply_args(Engine &e, uint32_t k, const u64 *a, uint32_t size_a, const u64 *b, uint32_t size_b, const u64 *out)
     {
         check_level(e, k);
-        // SEAL_CIPHERTEXT_SIZE_MIN/MAX (util/defines.h:56-57)
         if (size_a < 2 || size_b < 2 || size_a + size_b - 1 > 16)
             throw std::invalid_argument("encrypted1 or encrypted2 is not valid for encryption parameters");
         if (out == a || out == b)
             throw std::invalid_argument("out must not alias an operand");
+    }
+
+    // Evaluator::multiply (evaluator.cpp:235-527) on device batches
+    void do_multiply(Engine &e, uint32_t k, const u64 *a, uint32_t size_a, const u64 *b, uint32_t size_b, size_t count, u64 *out)
+    {
+        check_multiply_args(e, k, a, size_a, b, size_b, out);
         if (e.scheme == 1)
             op_bfv_multiply(e, static_cast<int>(k), a, static_cast<int>(size_a), b, static_cast<int>(size_b), count, out);
         else
@@ -999,7 +1025,10 @@ long sealhip_evaluator_multiply(sealhip_context *ctx, uint32_t k, const uint64_t
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, true);
+        check_multiply_args(e, k, reinterpret_cast<const u64 *>(a), size_a, reinterpret_cast<const u64 *>(b), size_b,
+                            reinterpret_cast<const u64 *>(out));
+        SinkScope sink(e, count);
+        sink.begin();
         do_multiply(e, k, reinterpret_cast<const u64 *>(a), size_a, reinterpret_cast<const u64 *>(b), size_b, count,
                     reinterpret_cast<u64 *>(out));
     });
@@ -1022,7 +1051,8 @@ long sealhip_evaluator_square(sealhip_context *ctx, uint32_t k, const uint64_t *
         if (out == a)
             throw std::invalid_argument("out must not alias the operand");
         const u64 *pa = reinterpret_cast<const u64 *>(a);
-        SinkScope sink(e, count, true);
+        SinkScope sink(e, count);
+        sink.begin();
         if (e.scheme == 1)
             op_bfv_square(e, static_cast<int>(k), pa, static_cast<int>(size_a), count, reinterpret_cast<u64 *>(out));
         else
@@ -1037,7 +1067,7 @@ long sealhip_evaluator_relinearize(sealhip_context *ctx, uint32_t k, uint64_t *c
     REQUIRE_PTR(ct);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_relinearize(e, k, reinterpret_cast<u64 *>(ct), size, count, relin_keys, n_relin_keys, &sink);
         if (size == 2) // nothing was done (evaluator.cpp:798-802): the flags describe the input
             sink.read_pass(reinterpret_cast<const u64 *>(ct), 2, static_cast<std::size_t>(k) * e.n, count);
@@ -1278,7 +1308,7 @@ long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, cons
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false);
         sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
@@ -1292,7 +1322,7 @@ long sealhip_evaluator_mod_switch_to_next_strided(sealhip_context *ctx, uint32_t
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), false, ct_item_stride);
         sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
@@ -1306,7 +1336,7 @@ long sealhip_evaluator_rescale_to_next_strided(sealhip_context *ctx, uint32_t k,
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), true, ct_item_stride);
         sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
@@ -1320,7 +1350,7 @@ long sealhip_evaluator_rescale_to_next(sealhip_context *ctx, uint32_t k, const u
     REQUIRE_PTR(out);
     return guarded([&] {
         Engine &e = device_engine(ctx);
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_level_down(e, k, reinterpret_cast<const u64 *>(ct), size, count, reinterpret_cast<u64 *>(out), true);
         sink.read_pass(reinterpret_cast<const u64 *>(out), size, static_cast<std::size_t>(k - 1) * e.n, count);
     });
@@ -1335,7 +1365,8 @@ long sealhip_evaluator_apply_galois(sealhip_context *ctx, uint32_t k, uint64_t *
     return guarded([&] {
         Engine &e = device_engine(ctx);
         check_level(e, k);
-        SinkScope sink(e, count, true);
+        SinkScope sink(e, count);
+        sink.begin();
         op_apply_galois(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), count, galois_elt, galois_key->key);
     });
 }
@@ -1367,7 +1398,7 @@ long sealhip_evaluator_negate(sealhip_context *ctx, uint32_t k, const uint64_t *
         check_level(e, k);
         if (size < 1)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         check_launch(launch_ct_linear(e, CtLinearOp::Negate, reinterpret_cast<const u64 *>(ct), static_cast<int>(size),
                                       nullptr, 0, 0, reinterpret_cast<u64 *>(out), count,
                                       e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
@@ -1392,7 +1423,7 @@ static long add_sub_entry(sealhip_context *ctx, uint32_t k, const uint64_t *a, u
         // encrypted1 first, evaluator.cpp:131-132; a raw buffer cannot grow)
         if (out == a && size_b > size_a)
             throw std::invalid_argument("in-place result needs a destination of max(size_a, size_b) polynomials");
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         check_launch(launch_ct_linear(e, sub ? CtLinearOp::Sub : CtLinearOp::Add, reinterpret_cast<const u64 *>(a),
                                       static_cast<int>(size_a), reinterpret_cast<const u64 *>(b), static_cast<int>(size_b), 0,
                                       reinterpret_cast<u64 *>(out), count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
@@ -1426,11 +1457,11 @@ long sealhip_evaluator_multiply_plain_ntt(sealhip_context *ctx, uint32_t k, uint
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (plain_stride != 0 && plain_stride < static_cast<size_t>(k) * e.n)
             throw std::invalid_argument("plain_stride is smaller than one plaintext");
+        SinkScope sink(e, count); // (capacity checked before ct is overwritten)
         check_launch(launch_ct_linear(e, CtLinearOp::MulPlain, reinterpret_cast<const u64 *>(ct), static_cast<int>(size),
                                       reinterpret_cast<const u64 *>(plain_ntt), 0, plain_stride, reinterpret_cast<u64 *>(ct),
                                       count, e.map_for(static_cast<int>(k), SEALHIP_BASE_Q)),
                      "multiply_plain_ntt");
-        SinkScope sink(e, count, false); // (clears, then reads the result: nothing in between)
         sink.read_pass(reinterpret_cast<const u64 *>(ct), size, static_cast<std::size_t>(k) * e.n, count);
     });
 }
@@ -1448,9 +1479,9 @@ long sealhip_evaluator_multiply_plain(sealhip_context *ctx, uint32_t k, uint64_t
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (plain_stride != 0 && plain_stride < e.n)
             throw std::invalid_argument("plain_stride is smaller than one plaintext");
+        SinkScope sink(e, count); // (capacity checked before ct is overwritten)
         op_multiply_plain(e, static_cast<int>(k), reinterpret_cast<u64 *>(ct), static_cast<int>(size), count,
                           reinterpret_cast<const u64 *>(plain), plain_stride);
-        SinkScope sink(e, count, false);
         sink.read_pass(reinterpret_cast<const u64 *>(ct), size, static_cast<std::size_t>(k) * e.n, count);
     });
 }
@@ -1524,7 +1555,7 @@ long sealhip_evaluator_rotate_vector(sealhip_context *ctx, uint32_t k, uint64_t 
     return guarded([&] {
         Engine &e = device_engine(ctx);
         // (the NAF fallback applies several automorphisms: the flags are read off the final ciphertext)
-        SinkScope sink(e, count, false);
+        SinkScope sink(e, count);
         do_rotate(e, k, reinterpret_cast<u64 *>(ct), count, steps, galois_elts, galois_keys, n_keys);
         sink.read_pass(reinterpret_cast<const u64 *>(ct), 2, static_cast<std::size_t>(k) * e.n, count);
     });

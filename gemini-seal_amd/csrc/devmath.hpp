@@ -328,6 +328,20 @@ namespace sealhip
     {
         return mullo1_acc(x, mulhi_c<true>(x, rdp), neg_p);
     }
+    // x below 2^7 p, p at least 2^45 (bounds::small_quot_admits) -> the representative in [0, 2p) of the same residue class,
+    // with the quotient estimated in single precision from the word's upper half: floor(fl(fl(x >> 32) * c)) is
+    // floor(x / p) or one less for c = fl((2^32 / p)(1 - 2^-20)) (ntt_bounds.hpp section 6 proves both directions;
+    // tests/bounds_check.cpp runs the same IEEE operations on adversarial words). 6 instructions against the 10 of barrett_lazy_hs.
+    __device__ __forceinline__ float small_quot_const(u64 p)
+    {
+        return static_cast<float>(4294967296.0 / static_cast<double>(p) * (1.0 - 0x1p-20));
+    }
+    __device__ __forceinline__ u64 reduce_small_quot(u64 x, float c, u64 neg_p)
+    {
+        const u32 q = static_cast<u32>(static_cast<float>(static_cast<u32>(x >> 32)) * c); // v_cvt_f32_u32, v_mul_f32, v_cvt_u32_f32
+        const u64 v = mad64<true>(q, static_cast<u32>(neg_p), x);                          // x + q * (2^64 - p), low word
+        return add_hi32(v, static_cast<u64>(q * static_cast<u32>(neg_p >> 32)));
+    }
     // forward lazy butterfly (ntt.cpp:245-252): X = u + v, Y = u - v + 2p with v = y*w - q*p.
     // X falls out of the multiply-accumulate chain (u is its initial accumulator); Y = (2u + 2p) - X.
     // APX: the quotient estimate without hi32(y0 * s0), i.e. floor(y s / 2^64) or one less: one multiplier instruction
@@ -353,11 +367,54 @@ namespace sealhip
         const u64 addend = static_cast<u64>(static_cast<u32>(B >> 32)) | (static_cast<u64>(cb) << 32);
         return mad64<SU>(x1, s1, addend);
     }
-    template <bool WU, bool APX = false>
+    // APX == 2 (round 4): the quotient from the three partial products that matter, with NO carry to recover:
+    //   q = y1*s1 + hi32(y0*s1) + hi32(y1*s0)   >=   floor(y s / 2^64) - 2
+    // (the low halves of the two cross products and hi32(y0*s0) are dropped: each loses less than one unit). The Shoup
+    // quotient is itself floor(y w / p) or one less, so the product lands in [0, 4p) and the caller passes 4p as the
+    // addend (growth 4p per layer: ntt_bounds.hpp section 2).
+    // Instruction count: v_mul_hi_u32, v_mad_u64_u32 (y1*s1 + t1), v_mul_hi_u32, v_mad_u64_u32 (t2*1 + .) = 4, against
+    // mul, mad + carry, v_cndmask, v_mov, mad = 5 -- PROVIDED the 64-bit addend (t1, 0) costs no move. A 64-bit operand is
+    // an even-aligned register pair, and zero-extending a 32-bit result normally costs the v_mov of the upper half. Here the
+    // upper halves are written ONCE per phase (ZeroHi::init, opaque to the compiler, which would otherwise fold the zero and
+    // re-materialise it per use) and v_mul_hi_u32 writes the lower half of the same pair in place: `with_low` tells the
+    // compiler that the upper half is unchanged, and its coalescer keeps the pair where it is (checked in the ISA: no
+    // v_mov between the v_mul_hi_u32 and the v_mad_u64_u32 that reads the pair).
+    template <int N>
+    struct ZeroHi
+    {
+        u64 z[N];
+        __device__ __forceinline__ void init()
+        {
+#pragma unroll
+            for (int j = 0; j < N; j++)
+            {
+                u32 h;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(h));
+                z[j] = static_cast<u64>(h) << 32;
+            }
+        }
+    };
+    __device__ __forceinline__ u64 with_low(u64 zp, u32 lo)
+    {
+        return (zp & 0xFFFFFFFF00000000ull) | lo;
+    }
+    template <bool SU>
+    __device__ __forceinline__ u64 mulhi_apx2(u64 x, u64 s, u64 &zp)
+    {
+        const u32 x0 = static_cast<u32>(x), x1 = static_cast<u32>(x >> 32);
+        const u32 s0 = static_cast<u32>(s), s1 = static_cast<u32>(s >> 32);
+        zp = with_low(zp, __umulhi(x0, s1));
+        u64 d, cy;
+        const u64 A = mad64<SU>(x1, s1, zp);
+        asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(cy) : "v"(__umulhi(x1, s0)), "v"(A));
+        return d;
+    }
+    template <bool WU, int APX = 0>
     __device__ __forceinline__ void butterfly_fwd_hs(u64 &xu, u64 &xy, u64 w, u64 wshoup, u64 neg_p, u64 two_p)
     {
         const u64 u = xu;
-        const u64 X = mullo2_acc<WU>(u, xy, w, APX ? mulhi_apx<WU>(xy, wshoup) : mulhi_c<WU>(xy, wshoup), neg_p);
+        static_assert(APX != 2, "level 2 takes a zero-high pair: butterfly_fwd_apx2");
+        const u64 X = mullo2_acc<WU>(u, xy, w, APX == 1 ? mulhi_apx<WU>(xy, wshoup) : mulhi_c<WU>(xy, wshoup), neg_p);
         xu = X;
         xy = (u << 1) + two_p - X;
     }
@@ -390,7 +447,17 @@ namespace sealhip
             asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "+s"(cy) : "v"(a), "v"(b));
         return d;
     }
-    template <bool WU, int IL, bool APX = false>
+    template <bool SU>
+    __device__ __forceinline__ u32 mulhi32v(u32 a, u32 b) // hi32(a*b), program-ordered like mad64v
+    {
+        u32 d;
+        if (SU)
+            asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b));
+        else
+            asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    template <bool WU, int IL, int APX = 0>
     __device__ __forceinline__ void butterflies_fwd_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
                                                        u64 neg_p, u64 two_p)
     {
@@ -399,9 +466,10 @@ namespace sealhip
         u64 A[IL], B[IL], E[IL], V[IL], q[IL], carry[IL];
         u32 cb[IL];
         u64 cy[IL] = {};
+        static_assert(APX != 2, "level 2 takes zero-high pairs: butterflies_fwd_apx2");
 #pragma unroll
         for (int j = 0; j < IL; j++) // 1: A = y1*s0 + hi32(y0*s0)   (APX: without the second term, see butterfly_fwd_hs)
-            A[j] = APX ? mul64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]), cy[j])
+            A[j] = APX == 1 ? mul64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]), cy[j])
                        : mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]),
                                     static_cast<u64>(__umulhi(static_cast<u32>(y[j]), static_cast<u32>(ws[j]))), cy[j]);
 #pragma unroll
@@ -446,6 +514,64 @@ namespace sealhip
         {
             const u64 X = add_hi32(V[j], E[j]);
             y[j] = (u[j] << 1) + two_p - X;
+            u[j] = X;
+        }
+    }
+    // level-2 forms of the two functions above (see mulhi_apx2): `zp` are zero-high pairs of the calling phase
+    template <bool WU>
+    __device__ __forceinline__ void butterfly_fwd_apx2(u64 &xu, u64 &xy, u64 w, u64 wshoup, u64 neg_p, u64 four_p, u64 &zp)
+    {
+        const u64 u = xu;
+        const u64 X = mullo2_acc<WU>(u, xy, w, mulhi_apx2<WU>(xy, wshoup, zp), neg_p);
+        xu = X;
+        xy = (u << 1) + four_p - X;
+    }
+    template <bool WU, int IL>
+    __device__ __forceinline__ void butterflies_fwd_apx2(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
+                                                         u64 neg_p, u64 four_p, u64 (&zp)[IL])
+    {
+        const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
+        u64 A[IL], E[IL], V[IL], q[IL];
+        u32 t1[IL], t2[IL];
+        u64 cy[IL] = {};
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 1: t1 = hi32(y0*s1), into the low half of the zero-high pair
+            t1[j] = mulhi32v<WU>(static_cast<u32>(y[j]), static_cast<u32>(ws[j] >> 32));
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 2: E = y0*w1
+            E[j] = mul64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j] >> 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 3: t2 = hi32(y1*s0)
+            t2[j] = mulhi32v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]));
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 4: E += y1*w0
+            E[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 5: A = y1*s1 + t1
+        {
+            zp[j] = with_low(zp[j], t1[j]);
+            A[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j] >> 32), zp[j], cy[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 6: V = u + y0*w0
+            V[j] = mad64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j]), u[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 7: q = A + t2  (t2 * 1 + A: a 32-bit addend needs no zero-extended pair this way)
+            asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(q[j]), "+s"(cy[j]) : "v"(t2[j]), "v"(A[j]));
+#pragma unroll
+        for (int j = 0; j < IL; j++) // 8..10: + q*(2^64 - p)
+            E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mad64v<true>(static_cast<u32>(q[j]), n0, V[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j] >> 32), n0, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+        {
+            const u64 X = add_hi32(V[j], E[j]);
+            y[j] = (u[j] << 1) + four_p - X;
             u[j] = X;
         }
     }

@@ -179,6 +179,8 @@ namespace sealhip
         {
             Lane *l = idle.back();
             idle.pop_back();
+            l->tsink = l->tsink_cur = l->tsink_arm = nullptr; // (give() cleared them; a lane is handed out without a sink)
+            l->tsink_cap = l->tsink_base = 0;
             return l;
         }
         auto l = std::make_unique<Lane>();
@@ -195,6 +197,14 @@ namespace sealhip
 
     void LanePool::give(Lane *lane)
     {
+        // The lane outlives the thread that held it, the transparency sink does not: sealhip_transparency_sink registers a
+        // raw device pointer of THAT thread (include/sealhip.h: "the calling thread's lane"). A thread that takes the lane
+        // later must not inherit it -- its first Evaluator call would clear and write flags in a buffer it never
+        // registered, possibly freed. No HIP call here: this runs from a thread_local destructor, possibly
+        // while the process is shutting down. A pending device fault stays sticky on purpose: work of the exiting thread
+        // may still be in flight on the lane's stream, and sealhip_synchronize (all lanes) is where it surfaces.
+        lane->tsink = lane->tsink_cur = lane->tsink_arm = nullptr;
+        lane->tsink_cap = lane->tsink_base = 0;
         std::lock_guard<std::mutex> lock(mu);
         idle.push_back(lane);
     }

@@ -74,9 +74,10 @@ namespace sealhip
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
     constexpr int kNttAnyRep = 8;    // inverse: the consumer canonicalises, any representative below 2p may be stored
     constexpr int kNttReduceOut = 0x10; // forward, single-pass kernel: one more conditional subtraction, outputs in [0, 2p)
-    constexpr int kNttApprox = 0x20;   // forward, with kNttAnyRep or a consumer that takes outputs below 5p: approximate quotient
+    constexpr int kNttApprox = 0x20;   // forward, with kNttAnyRep or a consumer that takes outputs below (2 + g) p: approximate quotient (ntt_bounds.hpp section 2)
     constexpr int kNttPolyMajor = 0x4000;        // forward half kernel: live positions grouped item by item (ntt.hip half_block_map; group size in bits 16-23)
     constexpr int kNttPolyMajorRequest = 0x8000; // (launcher-internal: resolved per arithmetic instance)
+    constexpr int kNttSmallQuot = 0x1000000;     // (launcher-internal) canonical approximate-quotient launch: single-precision quotient estimate in the store
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     // forward, single-pass kernel, with kNttReduceOut, in place: the producer of the rows has already applied the top layer
     // (gap N/2) -- bfv_lift2 does for the Bsk rows it writes. Each workgroup then loads its own half only: no second read of

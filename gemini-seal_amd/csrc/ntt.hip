@@ -398,6 +398,36 @@ namespace sealhip
 #endif
         constexpr int kIL = SEALHIP_NTT_IL; // butterflies advanced in lock step (devmath.hpp: butterflies_fwd_hs)
 
+        // STRICT == 2 (approximate Shoup quotient): which form (ntt_bounds.hpp section 2: bounds::kFwdApxLevel) -- 1: round 2's
+        // (hi32(y0*s0) dropped, product below 3p); 2: round 4's carry-free quotient (devmath.hpp mulhi_apx2, below 4p).
+        // The butterfly's second output is u - v + (that bound), so the bound is what the layers add.
+        template <int STRICT>
+        constexpr int kApx = STRICT == 2 ? bounds::kFwdApxLevel : 0;
+        using ZeroPairs = ZeroHi<4>; // devmath.hpp mulhi_apx2: written where a phase starts (four v_mov), used round-robin
+        // The final round at N = 2^15 runs at the register cap (two stages of prefetched twiddles, 48 registers): four more for
+        // zero-high pairs spill two coefficients. Its 32 butterflies (of 272) keep the level-1 quotient there -- a product
+        // below 3p under a schedule that allows 4p, so the bounds of level 2 cover it (ntt_bounds.hpp section 2).
+#ifndef SEALHIP_NTT_FINAL_ZP
+#define SEALHIP_NTT_FINAL_ZP 2
+#endif
+        constexpr int kFinalZeroPairs = SEALHIP_NTT_FINAL_ZP;
+        template <int T, int STRICT>
+        constexpr int kFinalApx = (kApx<STRICT> == 2 && (T - 12) == 2) ? 1 : kApx<STRICT>;
+        template <int STRICT>
+        __device__ __forceinline__ u64 fwd_addend(u64 two_p, u64 neg_p)
+        {
+            if constexpr (STRICT != 2)
+                return two_p;
+            else if constexpr (bounds::kFwdApxLevel == 2)
+            {
+                u64 a = two_p << 1; // 4p, opaque: left visible the compiler rewrites (u << 1) + (2p << 1) as (u + 2p) << 1, two
+                asm("" : "+s"(a));  // 64-bit instructions where v_lshl_add_u64 does it in one
+                return a;
+            }
+            else
+                return two_p - neg_p; // 3p
+        }
+
         // final round, one group at a time: the low f index bits of the 2^f registers that share the filler
         // slot bits G are finished (layers f-1 .. 0) and stored right away, which bounds the live twiddles
         // Measurement-only hooks (compiled with -DSEALHIP_NTT_EXPERIMENT, driven by SEALHIP_NTT_SKIP): drop the
@@ -512,7 +542,7 @@ namespace sealhip
         // (kStoreExchange), 2 transposed in registers and stored group by group (kStoreSwap)
         template <int T, int STRICT, int G, bool ROUT, int SX>
         __device__ __forceinline__ void h_final_group(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
-                                                      int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
+                                                      int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin, ZeroPairs &zp)
         {
             constexpr int f = T - 12;
 #pragma unroll
@@ -540,7 +570,10 @@ namespace sealhip
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
-                    butterfly_fwd_hs<false, STRICT == 2>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
+                    if constexpr (kFinalApx<T, STRICT> == 2)
+                        butterfly_fwd_apx2<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z[(((e >> (W + 1)) << W) | (e & (bit - 1))) & (kFinalZeroPairs - 1)]);
+                    else
+                        butterfly_fwd_hs<false, kFinalApx<T, STRICT>>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, fwd_addend<STRICT>(two_p, neg_p));
                 }
             }
 #pragma unroll
@@ -560,10 +593,20 @@ namespace sealhip
                 {
                     if constexpr (STRICT == 2)
                     {
-                        // canonical output of the approximate-quotient schedule (values below 50p, ntt_bounds.hpp section 2):
-                        // one Barrett step to [0, 2p), one conditional subtraction
-                        v.x = barrett_lazy_hs(v.x, rdp, neg_p);
-                        v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                        // canonical output of the approximate-quotient schedule (values below (2 + g log n) p <= 66p,
+                        // ntt_bounds.hpp section 2): one step to [0, 2p), one conditional subtraction. fin & 4: the step is
+                        // the single-precision quotient estimate (rdp then carries the bits of its constant), else Barrett
+                        if (fin & 4)
+                        {
+                            const float cq = __uint_as_float(static_cast<unsigned>(rdp));
+                            v.x = reduce_small_quot(v.x, cq, neg_p);
+                            v.y = reduce_small_quot(v.y, cq, neg_p);
+                        }
+                        else
+                        {
+                            v.x = barrett_lazy_hs(v.x, rdp, neg_p);
+                            v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                        }
                     }
                     else
                     {
@@ -602,18 +645,18 @@ namespace sealhip
         struct FinalGroups
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 *__restrict__ tw, u64 *__restrict__ rowp,
-                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
+                                                       int jb, int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin, ZeroPairs &zp)
             {
-                h_final_group<T, STRICT, G, ROUT, SX>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                h_final_group<T, STRICT, G, ROUT, SX>(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin, zp);
                 if ((G & 1) == 1)
                     __builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting every group's twiddle loads
-                FinalGroups<T, STRICT, G + 1, NG, ROUT, SX>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                FinalGroups<T, STRICT, G + 1, NG, ROUT, SX>::run(x, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin, zp);
             }
         };
         template <int T, int STRICT, int NG, bool ROUT, int SX>
         struct FinalGroups<T, STRICT, NG, NG, ROUT, SX>
         {
-            __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, bool)
+            __device__ static __forceinline__ void run(u64 (&)[32], const u64 *, u64 *, int, int, u64, u64, u64, u64, int, ZeroPairs &)
             {}
         };
 
@@ -653,7 +696,7 @@ namespace sealhip
 
         template <int T, int STRICT, int G, bool ROUT, int SX>
         __device__ __forceinline__ void h_final_group_regs(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb,
-                                                           int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
+                                                           int N, u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin, ZeroPairs &zp)
         {
             constexpr int f = T - 12;
 #pragma unroll
@@ -679,7 +722,10 @@ namespace sealhip
                         x[s] = x[s] >= two_p ? x[s] - two_p : x[s];
                     else if (gb == 0 && !(fin & 2)) // fin & 2: the consumer takes any representative and nothing can wrap
                         x[s] = barrett_lazy_hs(x[s], rdp, neg_p);
-                    butterfly_fwd_hs<false, STRICT == 2>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
+                    if constexpr (kFinalApx<T, STRICT> == 2)
+                        butterfly_fwd_apx2<false>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z[(((e >> (W + 1)) << W) | (e & (bit - 1))) & (kFinalZeroPairs - 1)]);
+                    else
+                        butterfly_fwd_hs<false, kFinalApx<T, STRICT>>(x[s], x[s | bit], Wv.x, Wv.y, neg_p, fwd_addend<STRICT>(two_p, neg_p));
                 }
             }
 #pragma unroll
@@ -699,10 +745,20 @@ namespace sealhip
                 {
                     if constexpr (STRICT == 2)
                     {
-                        // canonical output of the approximate-quotient schedule (values below 50p, ntt_bounds.hpp section 2):
-                        // one Barrett step to [0, 2p), one conditional subtraction
-                        v.x = barrett_lazy_hs(v.x, rdp, neg_p);
-                        v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                        // canonical output of the approximate-quotient schedule (values below (2 + g log n) p <= 66p,
+                        // ntt_bounds.hpp section 2): one step to [0, 2p), one conditional subtraction. fin & 4: the step is
+                        // the single-precision quotient estimate (rdp then carries the bits of its constant), else Barrett
+                        if (fin & 4)
+                        {
+                            const float cq = __uint_as_float(static_cast<unsigned>(rdp));
+                            v.x = reduce_small_quot(v.x, cq, neg_p);
+                            v.y = reduce_small_quot(v.y, cq, neg_p);
+                        }
+                        else
+                        {
+                            v.x = barrett_lazy_hs(v.x, rdp, neg_p);
+                            v.y = barrett_lazy_hs(v.y, rdp, neg_p);
+                        }
                     }
                     else
                     {
@@ -751,12 +807,12 @@ namespace sealhip
         struct StageRun
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 *__restrict__ rowp, int jb, int N,
-                                                       u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin)
+                                                       u64 p, u64 two_p, u64 neg_p, u64 rdp, int fin, ZeroPairs &zp)
             {
                 h_final_group_regs<T, STRICT, ST * FinalStage<T>::SG + I, ROUT, SX>(x, tg + I * FinalStage<T>::NTW, rowp, jb, N, p,
-                                                                               two_p, neg_p, rdp, fin);
+                                                                               two_p, neg_p, rdp, fin, zp);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    StageRun<T, STRICT, ROUT, SX, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    StageRun<T, STRICT, ROUT, SX, ST, I + 1>::run(x, tg, rowp, jb, N, p, two_p, neg_p, rdp, fin, zp);
             }
         };
         template <int T, int STRICT, bool ROUT, int SX, int ST>
@@ -764,16 +820,16 @@ namespace sealhip
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw,
                                                        u64 *__restrict__ rowp, int jb, int N, u64 p, u64 two_p, u64 neg_p,
-                                                       u64 rdp, int fin)
+                                                       u64 rdp, int fin, ZeroPairs &zp)
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS)
                     StageTw<T, ST + 1, 0, STRICT == 3>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                StageRun<T, STRICT, ROUT, SX, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                StageRun<T, STRICT, ROUT, SX, ST>::run(x, cur, rowp, jb, N, p, two_p, neg_p, rdp, fin, zp);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FinalPipe<T, STRICT, ROUT, SX, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin);
+                    FinalPipe<T, STRICT, ROUT, SX, ST + 1>::run(x, next, tw, rowp, jb, N, p, two_p, neg_p, rdp, fin, zp);
             }
         };
 
@@ -814,7 +870,7 @@ namespace sealhip
                 }
             }
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
-                                                       u64 neg_p)
+                                                       u64 neg_p, ZeroPairs &zp)
             {
                 if constexpr (STRICT == 3)
                 {
@@ -832,7 +888,13 @@ namespace sealhip
                     if (STRICT == 1)
                         u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
                 }
-                butterflies_fwd_hs<UNIFORM, kIL, STRICT == 2>(u, y, w, ws, neg_p, STRICT == 2 ? two_p - neg_p : two_p); // ForwardLazy, ntt.cpp:245-252
+                if constexpr (kApx<STRICT> == 2)
+                {
+                    static_assert(kIL == 4, "four zero-high pairs");
+                    butterflies_fwd_apx2<UNIFORM, kIL>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z);
+                }
+                else
+                    butterflies_fwd_hs<UNIFORM, kIL, kApx<STRICT>>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p)); // ForwardLazy, ntt.cpp:245-252
 #pragma unroll
                 for (int j = 0; j < kIL; j++)
                 {
@@ -846,7 +908,7 @@ namespace sealhip
         {
             static constexpr int NST = 4 * (16 / kIL);
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
-                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p)
+                                                       const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p, ZeroPairs &zp)
             {
                 u64 wn[kIL], wsn[kIL];
                 if constexpr (K + 1 < NST)
@@ -855,9 +917,9 @@ namespace sealhip
                 // (before on-chip layers 5 and 10 -- after round 2's first and round 3's second layer: see fp_reduce_all)
                 if constexpr (STRICT == 3 && K % (16 / kIL) == 0 && bounds::fp_fwd_reduce_before_layer(4 * (R - 1) + K / (16 / kIL)))
                     fp_reduce_all(x, two_p, neg_p);
-                RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p);
+                RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p, zp);
                 if constexpr (K + 1 < NST)
-                    RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p);
+                    RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, zp);
             }
         };
 
@@ -871,6 +933,9 @@ namespace sealhip
                                                    u64 aux_p = 0, u64 aux_cr1 = 0, const u64 *aux_top = nullptr)
         {
             const int jb = Arr<T, 1>::tid_index(tid);
+            ZeroPairs zp;
+            if constexpr (kApx<STRICT> == 2)
+                zp.init();
             u64x2 W1;
             if constexpr (STRICT == 3)
                 W1.x = ((twd_const_t)tw)[1];
@@ -997,7 +1062,10 @@ namespace sealhip
                         for (int j = 0; j < 4; j++)
                             u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
                     }
-                    butterflies_fwd_hs<true, 4, STRICT == 2>(u, y, w, ws, neg_p, STRICT == 2 ? two_p - neg_p : two_p);
+                    if constexpr (kApx<STRICT> == 2)
+                        butterflies_fwd_apx2<true, 4>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z);
+                    else
+                        butterflies_fwd_hs<true, 4, kApx<STRICT>>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p));
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         x[s + j] = HALF ? y[j] : u[j];
@@ -1244,8 +1312,11 @@ namespace sealhip
             RoundStage<T, 1, STRICT, true, 0>::load(w0, ws0, tw, gbase, N);
             if constexpr (FP)
                 fp_reduce_all(x, two_p, neg_p);
+            ZeroPairs zp; // (written again where each phase starts: four moves, and no register held across the exchanges)
+            if constexpr (kApx<STRICT> == 2)
+                zp.init();
             if (!NTT_EXP(flags, 0x100))
-                RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p);
+                RoundPipe<T, 1, STRICT, true>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, zp);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh_tid(wave_base));
             RoundStage<T, 2, STRICT, false, 0>::load(w0, ws0, tw, jb2, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
@@ -1253,15 +1324,19 @@ namespace sealhip
                 h_exchange<T, 1, 2>(x, lds, fresh_tid(wave_base));
             if (fresh_tid(wave_base) == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (kApx<STRICT> == 2)
+                zp.init();
             if (!NTT_EXP(flags, 0x100))
-                RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p);
+                RoundPipe<T, 2, STRICT, false>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, zp);
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh_tid(wave_base));
             RoundStage<T, 3, STRICT, false, 0>::load(w0, ws0, tw, jb3, N);
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 2, 3>(x, lds, fresh_tid(wave_base));
+            if constexpr (kApx<STRICT> == 2)
+                zp.init();
             if (!NTT_EXP(flags, 0x100))
-                RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p);
+                RoundPipe<T, 3, STRICT, false>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, zp);
             const int jb4 = gbase + Arr<T, 4>::tid_index(fresh_tid(wave_base));
             u64x2 tg0[FinalStage<T>::SG * FinalStage<T>::NTW];
             if constexpr (FinalStage<T>::PIPE)
@@ -1303,12 +1378,17 @@ namespace sealhip
             // ---- final round + store, group by group (arrangement 4: runs of 2^f consecutive coefficients per lane)
             const int Nx = NTT_EXP(flags, 0xF00) ? (N | ((flags & 0xF00) << 20)) : N;
             // bit 0: canonicalising wrapper; bit 1: leave the last layer's first operand unreduced (kNttAnyRep)
-            const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0);
+            // bit 2 (approximate-quotient canonical launches on primes of at least 45 bits, launch_half): the canonicalising
+            // step estimates its small quotient in single precision (devmath.hpp reduce_small_quot)
+            const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0) | ((flags & kNttSmallQuot) ? 4 : 0);
+            const u64 rdp_fin = (STRICT == 2 && (flags & kNttSmallQuot)) ? static_cast<u64>(__float_as_uint(small_quot_const(p))) : rdp;
             constexpr bool ROUT = REDUCE == 3 || REDUCE == 6; // kNttReduceOut launches (never gathered: no load treatment to combine with)
+            if constexpr (kFinalApx<T, STRICT> == 2)
+                zp.init();
             if constexpr (FinalStage<T>::PIPE)
-                FinalPipe<T, STRICT, ROUT, SX, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+                FinalPipe<T, STRICT, ROUT, SX, 0>::run(x, tg0, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp_fin, fin, zp);
             else
-                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT, SX>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp, fin);
+                FinalGroups<T, STRICT, 0, 1 << (5 - (T - 12)), ROUT, SX>::run(x, tw, rowp, jb4, Nx, p, two_p, neg_p, rdp_fin, fin, zp);
             if constexpr (XCH)
             {
                 if (!NTT_EXP(flags, 0x200))
@@ -2256,7 +2336,7 @@ namespace sealhip
                 static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
                 bool ok = !exact_only && (flags & (kNttCanonical | kNttStrict)) == 0;
                 for (int i = 0; ok && i < live.n; i++)
-                    ok = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
+                    ok = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
                 if (!ok)
                     flags &= ~kNttAnyRep;
             }
@@ -2279,20 +2359,26 @@ namespace sealhip
             bool apx = !no_apx && (flags & kNttApprox) != 0 && (flags & (kNttStrict | kNttCanonical | kNttReduceOut)) == 0 &&
                        red != 4 && red != 5 && red != 7;
             for (int i = 0; apx && i < live.n; i++)
-                apx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
+                apx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
             // The canonicalising wrapper (ntt.h:225-246) on primes with head-room: the canonical residue does not depend on
             // the representatives the layers pass on, so an in-place canonical transform runs the cheapest exact schedule --
-            // approximate quotient, no Barrett step in the last layer, values below (3 log n + 1) p (ntt_bounds.hpp section 2)
-            // -- and canonicalises with one Barrett step as it stores. SEALHIP_NTT_CANON_EXACT=1: the reference's sequence.
+            // approximate quotient, no Barrett step in the last layer, values below (4 + g log n) p for inputs below 4p
+            // (ntt_bounds.hpp section 2: fwd_canon_admits) -- and canonicalises with one reduction as it stores.
+            // SEALHIP_NTT_CANON_EXACT=1: the reference's sequence.
             static const bool canon_exact = std::getenv("SEALHIP_NTT_CANON_EXACT") != nullptr;
             bool capx = !no_apx && !canon_exact && !fp && red == 0 && (flags & kNttCanonical) != 0 &&
                         (flags & (kNttStrict | kNttReduceOut)) == 0;
-            for (int i = 0; capx && i < live.n; i++)
-                capx = bounds::fwd_lazy_admits(e.tables[map.prime[live.slot[i]]].p);
+            for (int i = 0; capx && i < live.n; i++) // (inputs below 4p, the range include/sealhip.h documents)
+                capx = bounds::fwd_canon_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
             if (capx)
             {
                 apx = true;
                 flags |= kNttAnyRep;
+                bool sq = std::getenv("SEALHIP_NTT_CANON_BARRETT") == nullptr; // (A/B: the Barrett step of round 3)
+                for (int i = 0; sq && i < live.n; i++)
+                    sq = bounds::small_quot_admits(e.tables[map.prime[live.slot[i]]].p, bounds::fwd_canon_output_mult(LOGN));
+                if (sq)
+                    flags |= kNttSmallQuot;
             }
             if (red == 7 && (!fp || !kStoreExchange<T, 3, 7>))
                 return hipErrorInvalidValue; // ntt_can_fuse_moddown said no: the caller runs moddown_post itself

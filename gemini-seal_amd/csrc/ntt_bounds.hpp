@@ -110,12 +110,30 @@ namespace sealhip
         // ARE the reference's result: the exact instances have no predicate. Shortcuts that change the
         // representative (only where the consumer reduces whatever it reads):
         //   kNttAnyRep   the last layer keeps its first operand unreduced (fin & 2);
-        //   kNttApprox   approximate Shoup quotient: v below 3p, y' = u - v + 3p, growth 3p per layer (STRICT = 2);
+        //   kNttApprox   approximate Shoup quotient (STRICT = 2): the product v lands below g p and y' = u - v + g p, so the
+        //                values grow by g p per layer. g = kFwdApxGrowth: 3 for round 2's form (hi32(y0 s0) dropped from the
+        //                exact quotient: one unit short at most), 4 for round 4's carry-free form (devmath.hpp mulhi_apx2:
+        //                q = y1 s1 + hi32(y0 s1) + hi32(y1 s0) drops the low halves of both cross products as well, three
+        //                units short of floor(y w / p) at most, quotient_shortfall below);
         //   unreduced gathered inputs (key-switch mod-up without the conditional subtraction): inputs below 2p not p.
         // All log n layers count (the top one is applied on load).
+#ifndef SEALHIP_NTT_APX
+#define SEALHIP_NTT_APX 2
+#endif
+        constexpr int kFwdApxLevel = SEALHIP_NTT_APX;
+        static_assert(kFwdApxLevel == 1 || kFwdApxLevel == 2, "approximate-quotient form");
+        // how far below floor(y w / p) the quotient estimate can fall, as the number of dropped terms that each lose less
+        // than one unit: Shoup's floor(w 2^64 / p) itself (1), hi32(y0 s0) (level 1 and 2: together with the floor of the
+        // sum of the cross products, 1), and at level 2 the low halves of the two cross products (1 more: the three dropped
+        // pieces sum to less than 3 * 2^32, i.e. lose at most 2 units of 2^32 after the floor).
+        constexpr int quotient_shortfall(int level)
+        {
+            return level == 0 ? 1 : (level == 1 ? 2 : 3);
+        }
+        constexpr int kFwdApxGrowth = quotient_shortfall(kFwdApxLevel) + 1; // v = y w - q p < (shortfall + 1) p
         constexpr u128 fwd_int_peak(int logn, u64 p, int in_mult, bool apx, bool skip_last_barrett)
         {
-            const u128 g = static_cast<u128>(apx ? 3 : 2) * p; // growth per layer = bound of the product
+            const u128 g = static_cast<u128>(apx ? kFwdApxGrowth : 2) * p; // growth per layer = bound of the product
             u128 bound = static_cast<u128>(in_mult) * p, peak = bound;
             for (int l = 0; l < logn; l++)
             {
@@ -128,30 +146,43 @@ namespace sealhip
             }
             return peak;
         }
-        // one predicate for both shortcuts together with unreduced inputs (the key-switch digit launches use all three)
-        constexpr int fwd_lazy_prime_bits()
+        // one predicate for both shortcuts together with unreduced inputs (the key-switch digit launches use all three),
+        // per ring size (the growth is per layer)
+        constexpr int fwd_lazy_prime_bits(int logn)
         {
             int bits = 0;
             for (int b = 1; b <= kMaxPrimeBits; b++)
-            {
-                bool ok = true;
-                for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
-                    ok = ok && fwd_int_peak(logn, max_prime_of_bits(b), 2, true, true) < kWord;
-                if (ok)
+                if (fwd_int_peak(logn, max_prime_of_bits(b), 2, true, true) < kWord)
                     bits = b;
-            }
             return bits;
         }
-        constexpr int kFwdLazyPrimeBits = fwd_lazy_prime_bits();
-        static_assert(kFwdLazyPrimeBits == 58, "kNttAnyRep / kNttApprox / unreduced mod-up: primes below 2^58");
-        constexpr bool fwd_lazy_admits(u64 p) // kNttAnyRep, kNttApprox, mod-up without the conditional subtraction
+        static_assert(kFwdApxLevel != 1 || (fwd_lazy_prime_bits(14) == 58 && fwd_lazy_prime_bits(16) == 58),
+                      "level 1: kNttAnyRep / kNttApprox / unreduced mod-up: primes below 2^58 (50p at log n = 16)");
+        static_assert(kFwdApxLevel != 2 || (fwd_lazy_prime_bits(14) == 58 && fwd_lazy_prime_bits(15) == 58 && fwd_lazy_prime_bits(16) == 57),
+                      "level 2: 58p / 62p below 2^64 for primes below 2^58 at log n = 14 / 15; 66p at log n = 16: below 2^57");
+        constexpr bool fwd_lazy_admits(u64 p, int logn) // kNttAnyRep, kNttApprox, mod-up without the conditional subtraction
         {
-            return p <= max_prime_of_bits(kFwdLazyPrimeBits);
+            return logn >= kMinHalfLogn && logn <= kMaxHalfLogn && p <= max_prime_of_bits(fwd_lazy_prime_bits(logn));
         }
-        // largest output of an approximate-quotient launch, in units of p (documentation + test): 50 with kNttAnyRep
+        // The canonicalising public entry (sealhip_ntt_negacyclic_harvey) documents operands below 4p (include/sealhip.h: what
+        // the reference's butterflies are written for), and it is handed caller-owned words: its cheap schedule (approximate
+        // quotient, no Barrett step in the last layer, one reduction in the store) is admitted on THAT range, not on the
+        // [0, 2p) of the internal launches: inputs below kCanonInMult p.
+        constexpr int kCanonInMult = 4;
+        constexpr int fwd_canon_output_mult(int logn)
+        {
+            return kCanonInMult + kFwdApxGrowth * logn;
+        }
+        constexpr bool fwd_canon_admits(u64 p, int logn)
+        {
+            return logn >= kMinHalfLogn && logn <= kMaxHalfLogn && fwd_lazy_admits(p, logn) &&
+                   fwd_int_peak(logn, p, kCanonInMult, true, true) < kWord;
+        }
+        // largest output of an approximate-quotient launch, in units of p (documentation + test): 2 + g log n with
+        // kNttAnyRep (50 / 66 at log n = 16), else 2 + g (the last layer's first operand is brought below 2p)
         constexpr int fwd_apx_output_mult(int logn, bool anyrep)
         {
-            return anyrep ? 2 + 3 * logn : 5;
+            return anyrep ? 2 + kFwdApxGrowth * logn : 2 + kFwdApxGrowth;
         }
 
         // =====================================================================================================
@@ -187,6 +218,14 @@ namespace sealhip
         constexpr bool tensor_admits_2p(u64 p)
         {
             return p <= max_prime_of_bits(kTensorPrimeBits2p);
+        }
+        // ... and on what an approximate-quotient forward launch WITHOUT kNttAnyRep stores (op_bfv_multiply's q rows when the
+        // tensor product is fused: the last layer keeps its Barrett step, outputs below (2 + g) p, section 2)
+        constexpr int kTensorPrimeBitsApx = tensor_prime_bits(fwd_apx_output_mult(kMaxHalfLogn, false));
+        static_assert(kTensorPrimeBitsApx == (kFwdApxLevel == 2 ? 57 : 58), "fused tensor product on approximate-quotient rows");
+        constexpr bool tensor_admits_apx(u64 p)
+        {
+            return p <= max_prime_of_bits(kTensorPrimeBitsApx);
         }
 
         // =====================================================================================================
@@ -311,5 +350,25 @@ namespace sealhip
             return n;
         }
         static_assert(dotacc_max_terms() >= 64, "DotAcc on 61-bit operands: at least 64 terms (the kernels use up to k + 2 <= 34)");
+
+        // =====================================================================================================
+        // 6. Small quotients estimated in single precision (devmath.hpp reduce_small_quot): for a word x below M p the
+        // quotient estimate is q' = trunc(fl(fl(x >> 32) * c)) with c = fl32(fl64(2^32 / p) (1 - 2^-20)); the reduced value
+        // x - q' p must land in [0, 2p), i.e. q' in {floor(x / p) - 1, floor(x / p)}.
+        //   * never too large: with e = 2^-24 the unit roundoff, fl(x >> 32) <= (x / 2^32)(1 + e), c <= (2^32 / p)(1 - 2^-20)
+        //     (1 + 2^-52)(1 + e), and the product rounds once more: q' <= (x / p)(1 - 2^-20)(1 + e)^3 (1 + 2^-52) < x / p.
+        //   * at most one short: fl(x >> 32) >= ((x - 2^32) / 2^32)(1 - e) drops the low half (less than 2^32 / p of
+        //     quotient), every rounding loses at most e relatively and the bias 2^-20: x / p - q'real < 2^32 / p +
+        //     M (2^-20 + 3 e + 2^-51) =: loss(M, p); trunc loses less than one more. loss < 1 makes q' >= floor(x / p) - 1.
+        // Admission: loss(M, p) <= 1/2 (a factor two of margin), which needs p >= 2^33 and M <= 2^18; the launchers ask for
+        // M <= 128 and p >= 2^45 (the hi word must also fit single precision's exponent range trivially, and M p < 2^64).
+        constexpr bool small_quot_admits(u64 p, int mult)
+        {
+            if (p < (u64(1) << 45) || mult < 1 || mult > 128 || static_cast<u128>(mult) * p > kWord)
+                return false;
+            const long double loss = 0x1p32L / static_cast<long double>(p) +
+                                     static_cast<long double>(mult) * (0x1p-20L + 3 * 0x1p-24L + 0x1p-51L);
+            return loss <= 0.5L;
+        }
     } // namespace bounds
 } // namespace sealhip

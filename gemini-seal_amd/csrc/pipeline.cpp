@@ -206,7 +206,7 @@ namespace sealhip
                 u64 pmax = 0;
                 for (int r = 0; r < rows; r++)
                     pmax = std::max(pmax, e.key_moduli[h.row_prime[r]]);
-                if (bounds::fwd_lazy_admits(pmax)) // (inputs below 2p: the case the recurrence in ntt_bounds.hpp walks)
+                if (bounds::fwd_lazy_admits(pmax, e.logn)) // (inputs below 2p: the case the recurrence in ntt_bounds.hpp walks)
                     modup_mode = 0;
             }
             if (!gather && !finish)
@@ -278,7 +278,7 @@ namespace sealhip
             for (int r = 0; fold_ok && r < k; r++)
             {
                 const u64 q = e.key_moduli[h.row_prime[r]];
-                fold_ok = p_special <= q || (p_special < 2 * q && bounds::fwd_lazy_admits(q));
+                fold_ok = p_special <= q || (p_special < 2 * q && bounds::fwd_lazy_admits(q, e.logn));
             }
             const bool fold_pre = fold_ok;
             // the gathered transform below reads the special row as pairs (c, c + N/2): it can apply the top inverse layer
@@ -417,8 +417,17 @@ namespace sealhip
             const bool defer = ntt_can_defer_top(e, k);
             bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
                                 std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
-            for (int r = 0; r < k; r++) // its Montgomery reduction lands below 2p for ciphertext primes under 2^59
+            // its Montgomery reduction lands below 2p on operands below 4p for ciphertext primes under 2^59 (the exact forward
+            // sequence), on operands below (2 + g) p -- what an approximate-quotient launch without kNttAnyRep stores --
+            // for primes under 2^57 (ntt_bounds.hpp section 3: tensor_admits_apx); the Bsk rows are stored below 2p
+            bool tensor_apx = true;
+            for (int r = 0; r < k; r++)
+            {
                 fused_tensor = fused_tensor && bounds::tensor_admits_4p(e.key_moduli[r]);
+                tensor_apx = tensor_apx && bounds::tensor_admits_apx(e.key_moduli[r]);
+            }
+            for (int j = 0; j < nB; j++)
+                fused_tensor = fused_tensor && bounds::tensor_admits_2p(e.tables[lt.map_qbsk.prime[k + j]].p);
             // the lift applies the forward transform's top layer to the Bsk rows it writes (kNttTopDone below)
             const bool lift_top = fused_tensor && bfv_lift_can_apply_top(e, h);
             for (int s = 0; s < sin; s++)
@@ -459,7 +468,8 @@ namespace sealhip
                 for (int s = 0; s < sin; s++)
                     for (int r = 0; r < kb; r++)
                         (r < k ? mb : mq).prime[s * kb + r] = kSkipRow;
-                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns, fused_tensor ? kNttApprox : (kNttAnyRep | kNttApprox)),
+                check(launch_ntt_gather(e, X, m * sin * kb, mq, ns,
+                                        fused_tensor ? (tensor_apx ? kNttApprox : 0) : (kNttAnyRep | kNttApprox)),
                       "ntt(X, gathered q rows)");
                 // (fused tensor product: the wrapped Bsk words are brought below 2p as they are stored -- the residue class
                 //  is all the dyadic product depends on)

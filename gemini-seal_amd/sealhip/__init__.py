@@ -96,7 +96,7 @@ SYMBOLS = {
     "sealhip_rescale_special_rns_inplace": [_vp, _u32, _vp, _sz],
     "sealhip_switch_key_inplace": [_vp, _u32, _vp, _vp, _sz, _vp],
     "sealhip_switch_key_partial": [_vp, _u32, _vp, _sz, _vp, _u32, _u32, _vp],
-    "sealhip_switch_key_finish": [_vp, _u32, _vp, _vp, _sz],
+    "sealhip_switch_key_finish": [_vp, _u32, _vp, _vp, _sz, _u32],
     "sealhip_kswitch_digits": [_vp, _u32, _vp],
     "sealhip_evaluator_multiply": [_vp, _u32, _vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_evaluator_square": [_vp, _u32, _vp, _u32, _sz, _vp],
@@ -634,9 +634,9 @@ class Context:
         _check(lib().sealhip_switch_key_partial(self.handle, k, _ptr(target), count, key.handle, digit_begin, digit_end,
                                                 _ptr(partial)))
 
-    def switch_key_finish(self, k, ct, partial_sum, count):
-        """the rest of the key switch (evaluator.cpp:2351-2366) on the element-wise sum of every device's partials"""
-        _check(lib().sealhip_switch_key_finish(self.handle, k, _ptr(ct), _ptr(partial_sum), count))
+    def switch_key_finish(self, k, ct, partial_sum, count, n_partials):
+        """the rest of the key switch (evaluator.cpp:2351-2366) on the element-wise sum of n_partials devices' partials"""
+        _check(lib().sealhip_switch_key_finish(self.handle, k, _ptr(ct), _ptr(partial_sum), count, n_partials))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -133,7 +133,10 @@ long sealhip_debug_rns_constants(sealhip_context *ctx, uint32_t k, uint32_t whic
    60-bit Bsk rows). The canonicalising entries return the residues those words reduce to; on rows whose prime
    is below 2^50 they are computed with exact double-precision butterflies, which for operands
    inside the ranges above is the same function -- for words outside them (>= 2^52) both the reference's output and this
-   one are meaningless, and they differ. */
+   one are meaningless, and they differ. Likewise the canonicalising forward entry on primes below 2^58 runs a cheaper
+   exact schedule (approximate Shoup quotients, one reduction in the store) that is proved for inputs below 4p
+   (csrc/ntt_bounds.hpp: fwd_canon_admits); SEALHIP_NTT_CANON_EXACT=1 runs the reference's own sequence instead, whose
+   deterministic wrap-around on larger words is then reproduced as well. */
 long sealhip_ntt_negacyclic_harvey_lazy(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k,
                                         uint32_t base);
 long sealhip_ntt_negacyclic_harvey(sealhip_context *ctx, uint64_t *data, size_t count, uint32_t k, uint32_t base);
@@ -195,10 +198,14 @@ long sealhip_switch_key_inplace(sealhip_context *ctx, uint32_t k, uint64_t *ct, 
    evaluator.cpp:2302-2349 over those digits only, reduced to canonical residues -> partial = count x 2 x (k + nsp) x N words.
    The caller adds the partials of all devices element-wise (an all-reduce with SUM on 64-bit words: ranks * p < 2^63 cannot
    wrap) and hands the sum to _finish on the device(s) that need the result: one more reduction, then :2351-2366 as in the
-   unsplit operation (partial_sum is clobbered). Modular sums are associative, so the result is word for word the unsplit one. */
+   unsplit operation (partial_sum is clobbered). Modular sums are associative, so the result is word for word the unsplit one.
+   n_partials = how many partials were summed (the world size of the all-reduce): _finish reduces with barrett_reduce_63 and
+   returns E_INVALIDARG when n_partials * max(key prime) could reach 2^63 (61-bit primes: more than 4). Measured with one
+   device only; the multi-device run is tools/latency_mode.py under torch.distributed. */
 long sealhip_switch_key_partial(sealhip_context *ctx, uint32_t k, const uint64_t *target, size_t count,
                                 const sealhip_kswitch_key *key, uint32_t digit_begin, uint32_t digit_end, uint64_t *partial);
-long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count);
+long sealhip_switch_key_finish(sealhip_context *ctx, uint32_t k, uint64_t *ct, uint64_t *partial_sum, size_t count,
+                               uint32_t n_partials);
 long sealhip_kswitch_digits(sealhip_context *ctx, uint32_t k, uint32_t *digits);
 
 /* ---------------------------------------------------------------- L4: Evaluator operations (native/src/seal/evaluator.h)

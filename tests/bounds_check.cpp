@@ -79,19 +79,37 @@ static void enumerate_predicates()
                         if (!apx && !skip && in_mult == 1)
                             continue; // the reference's own sequence: no predicate (its wrap-around is the result)
                         const u128 peak = fwd_int_peak(logn, p, in_mult, apx, skip);
-                        if (fwd_lazy_admits(p))
+                        if (fwd_lazy_admits(p, logn))
                             CHECK(peak < kWord, "forward logn=%d bits=%d in<%dp apx=%d skip=%d admitted but overflows", logn, bits,
                                   in_mult, apx, skip);
                         checked++;
                     }
         }
     {
-        // tight: one bit above the bound the full combination overflows at the largest ring
-        const u64 p = max_prime_of_bits(kFwdLazyPrimeBits + 1);
-        CHECK(fwd_int_peak(kMaxHalfLogn, p, 2, true, true) >= kWord, "forward lazy predicate is not tight");
-        CHECK(fwd_int_peak(kMaxHalfLogn, max_prime_of_bits(kFwdLazyPrimeBits), 2, true, true) / max_prime_of_bits(kFwdLazyPrimeBits) <
-                  static_cast<u128>(fwd_apx_output_mult(kMaxHalfLogn, true)) + 1,
-              "documented output bound 50p");
+        // the canonicalising entry's schedule on the documented input range [0, 4p)
+        for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+            for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+            {
+                const u64 p = max_prime_of_bits(bits);
+                if (fwd_canon_admits(p, logn))
+                {
+                    CHECK(fwd_int_peak(logn, p, kCanonInMult, true, true) < kWord, "canonical forward logn=%d bits=%d admitted but overflows", logn, bits);
+                    CHECK(fwd_int_peak(logn, p, kCanonInMult, true, true) <= static_cast<u128>(fwd_canon_output_mult(logn)) * p, "canonical output bound");
+                    if (bits >= 46)
+                        CHECK(small_quot_admits(p, fwd_canon_output_mult(logn)), "small quotient must cover the canonical store logn=%d bits=%d", logn, bits);
+                }
+                checked++;
+            }
+        // tight: one bit above the bound the full combination overflows, at every ring size
+        for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+        {
+            const int bits = fwd_lazy_prime_bits(logn);
+            CHECK(fwd_int_peak(logn, max_prime_of_bits(bits + 1), 2, true, true) >= kWord, "forward lazy predicate is not tight (log n %d)", logn);
+            CHECK(!fwd_lazy_admits(max_prime_of_bits(bits + 1), logn) && fwd_lazy_admits(max_prime_of_bits(bits), logn), "forward predicate edge");
+            CHECK(fwd_int_peak(logn, max_prime_of_bits(bits), 2, true, true) / max_prime_of_bits(bits) <
+                      static_cast<u128>(fwd_apx_output_mult(logn, true)) + 1,
+                  "documented output bound (2 + g log n) p");
+        }
     }
     // 1c. fused tensor product
     for (int bits = 20; bits <= kMaxPrimeBits; bits++)
@@ -99,6 +117,7 @@ static void enumerate_predicates()
         const u64 p = max_prime_of_bits(bits);
         CHECK(tensor_admits_4p(p) == tensor_redc_ok(p, 4, 2), "tensor 4p bits=%d", bits);
         CHECK(tensor_admits_2p(p) == tensor_redc_ok(p, 2, 2), "tensor 2p bits=%d", bits);
+        CHECK(tensor_admits_apx(p) == tensor_redc_ok(p, fwd_apx_output_mult(kMaxHalfLogn, false), 2), "tensor on approximate-quotient rows bits=%d", bits);
         if (tensor_admits_4p(p))
             CHECK(tensor_redc_ok(p, 4, 1), "one product must fit where two do");
         checked += 2;
@@ -323,6 +342,138 @@ static void inv_lazy_execution(int T, u64 p)
     CHECK(below_2p, "inverse lazy execution T=%d: outputs must be below 2p", T);
 }
 
+// ---- the approximate Shoup quotients of devmath.hpp (mulhi_apx: level 1, mulhi_apx2: level 2) as 32-bit limb arithmetic
+static u64 quotient_model(u64 y, u64 s, int level)
+{
+    const u64 y0 = y & 0xFFFFFFFFu, y1 = y >> 32, s0 = s & 0xFFFFFFFFu, s1 = s >> 32;
+    if (level == 0)
+        return static_cast<u64>((static_cast<u128>(y) * s) >> 64);
+    if (level == 1) // exact middle sum of the two cross products (carry kept), hi32(y0 s0) dropped
+        return static_cast<u64>(static_cast<u128>(y1) * s1 + ((static_cast<u128>(y1) * s0 + static_cast<u128>(y0) * s1) >> 32));
+    return y1 * s1 + ((y0 * s1) >> 32) + ((y1 * s0) >> 32); // level 2: no carry anywhere (the u64 sum cannot wrap: q <= y s / 2^64)
+}
+static void quotient_shortfall_check()
+{
+    std::mt19937_64 rng(4);
+    for (int level = 0; level <= 2; level++)
+    {
+        int worst = 0;
+        for (int bits = 30; bits <= kMaxPrimeBits; bits++)
+            for (int it = 0; it < 4000; it++)
+            {
+                const u64 p = (it % 7 == 0) ? max_prime_of_bits(bits) : ((u64(1) << (bits - 1)) | (rng() >> (65 - bits)) | 1);
+                u64 w = rng() % p, y = rng();
+                switch (it % 5) // adversarial limbs: all-ones halves make every dropped piece as large as it gets
+                {
+                case 0: w = p - 1; y = ~u64(0); break;
+                case 1: y |= 0xFFFFFFFFu; break;
+                case 2: y = (y << 32) | 0xFFFFFFFFu; break;
+                case 3: y >>= (it % 31); break;
+                default: break;
+                }
+                const u64 sh = static_cast<u64>((static_cast<u128>(w) << 64) / p);
+                const u64 q = quotient_model(y, sh, level);
+                const u128 prod = static_cast<u128>(y) * w;
+                const u128 qt = prod / p;
+                CHECK(q <= qt, "quotient level %d overestimates", level);
+                const int sf = static_cast<int>(qt - q);
+                worst = sf > worst ? sf : worst;
+                CHECK(sf <= quotient_shortfall(level), "quotient level %d: shortfall %d above the documented %d", level, sf,
+                      quotient_shortfall(level));
+                const u128 r = prod - static_cast<u128>(q) * p;
+                CHECK(r < static_cast<u128>(quotient_shortfall(level) + 1) * p, "quotient level %d: product not below (shortfall + 1) p", level);
+                // what the kernel computes mod 2^64 is that true value as long as it is below 2^64
+                if (r < kWord)
+                    CHECK(static_cast<u64>(y * w - q * p) == static_cast<u64>(r), "quotient level %d: wrapped product differs", level);
+            }
+        CHECK(worst >= quotient_shortfall(level) - 1, "quotient level %d: documented shortfall %d is not nearly reached (worst %d)", level,
+              quotient_shortfall(level), worst);
+    }
+}
+
+// ---- forward integer schedule with the approximate quotient executed on 64-bit words, true values shadowed in 128 bits:
+// inputs below 2p, log n layers of u' = u + v, y' = u - v + g p with v = y w - q p, no reduction anywhere (kNttAnyRep)
+static void fwd_apx_execution(int logn, u64 p)
+{
+    const int n = 1 << logn;
+    std::mt19937_64 rng(logn * 7 + 1);
+    std::vector<u64> x(n), shadow(n);
+    for (int i = 0; i < n; i++)
+    {
+        x[i] = (i % 3 == 0) ? 2 * p - 1 : rng() % (2 * p);
+        shadow[i] = x[i] % p;
+    }
+    const u64 g = static_cast<u64>(kFwdApxGrowth) * p;
+    u128 peak = 0;
+    bool wrapped = false;
+    for (int l = logn - 1; l >= 0; l--)
+    {
+        const int gap = 1 << l;
+        for (int blk = 0; blk < n; blk += 2 * gap)
+        {
+            const u64 w = (blk / (2 * gap)) % 5 == 0 ? p - 1 : rng() % p;
+            const u64 ws = static_cast<u64>((static_cast<u128>(w) << 64) / p);
+            for (int j = blk; j < blk + gap; j++)
+            {
+                const u64 u = x[j], y = x[j + gap];
+                const u64 q = quotient_model(y, ws, kFwdApxLevel);
+                const u128 v = static_cast<u128>(y) * w - static_cast<u128>(q) * p;
+                const u128 X = static_cast<u128>(u) + v;
+                const i128 Y = static_cast<i128>(u) - static_cast<i128>(v) + g;
+                wrapped = wrapped || v >= g || X >= kWord || Y < 0 || static_cast<u128>(Y) >= kWord;
+                peak = X > peak ? X : peak;
+                peak = static_cast<u128>(Y) > peak ? static_cast<u128>(Y) : peak;
+                x[j] = u + (y * w - q * p);               // what the kernel's multiply-accumulate chain leaves
+                x[j + gap] = (u << 1) + g - x[j];         // y' = 2u + g p - X
+                const u64 sv = static_cast<u64>(static_cast<u128>(shadow[j + gap]) * w % p), su = shadow[j];
+                shadow[j] = (su + sv) % p;
+                shadow[j + gap] = (su + p - sv) % p;
+            }
+        }
+    }
+    CHECK(!wrapped, "forward approximate execution logn=%d p=%llu wrapped", logn, p);
+    CHECK(peak <= fwd_int_peak(logn, p, 2, true, true), "forward approximate execution logn=%d above the recurrence", logn);
+    int bad = 0;
+    for (int i = 0; i < n; i++)
+        bad += x[i] % p != shadow[i] || x[i] >= static_cast<u128>(fwd_apx_output_mult(logn, true)) * p;
+    CHECK(bad == 0, "forward approximate execution logn=%d: %d words leave their residue class or the documented range", logn, bad);
+}
+
+// ---- devmath.hpp reduce_small_quot: the same IEEE single-precision operations (u32 -> float round to nearest, one
+// multiplication, truncation) on words that sit on and next to multiples of p
+static void small_quot_model()
+{
+    std::mt19937_64 rng(6);
+    int n = 0;
+    for (int bits = 45; bits <= 58; bits++)
+        for (int it = 0; it < 3000; it++)
+        {
+            const u64 p = (it % 5 == 0) ? max_prime_of_bits(bits) : ((u64(1) << (bits - 1)) | (rng() >> (65 - bits)) | 1);
+            for (int mult : { 2, 6, 50, 62, 66, 128 })
+            {
+                if (!small_quot_admits(p, mult))
+                    continue;
+                const float c = static_cast<float>(4294967296.0 / static_cast<double>(p) * (1.0 - 0x1p-20));
+                const u64 k = rng() % mult; // x = k p + d with d at the edges and in the middle
+                const u64 ds[6] = { 0, 1, p - 1, p / 2, rng() % p, (rng() % p) | 0xFFFFFFFFu };
+                for (u64 d : ds)
+                {
+                    if (d >= p)
+                        continue;
+                    const u64 x = k * p + d;
+                    const unsigned q = static_cast<unsigned>(static_cast<float>(static_cast<unsigned>(x >> 32)) * c);
+                    CHECK(q <= k && q + 1 >= k, "small quotient: p=%llu x=%llu estimate %u, true %llu", p, x, q, k);
+                    const u64 r = x - static_cast<u64>(q) * p;
+                    CHECK(r < 2 * p && r % p == d, "small quotient: reduced word out of [0, 2p) or off its class");
+                    n++;
+                }
+            }
+        }
+    CHECK(n > 100000, "small quotient model ran %d cases", n);
+    CHECK(!small_quot_admits((u64(1) << 45) - 1, 66) && small_quot_admits(u64(1) << 45, 66) && !small_quot_admits(max_prime_of_bits(58), 129),
+          "small quotient admission edges");
+}
+
 // ---- devmath.hpp DotAcc<NTERMS> executed on the largest operands: every accumulator tracked in 128 bits
 static void dotacc_execution()
 {
@@ -362,6 +513,10 @@ int main()
     std::fesetround(FE_TONEAREST);
     dotacc_execution();
     enumerate_predicates();
+    quotient_shortfall_check();
+    small_quot_model();
+    for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+        fwd_apx_execution(logn, max_prime_of_bits(fwd_lazy_prime_bits(logn)));
     regression_whole_row();
     fp_product_model();
     for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)

@@ -717,8 +717,12 @@ def test_latency_mode_key_switch_split_over_digit_groups(sealhip, scheme, logn, 
             assert np.array_equal(got_p[0], ep), ("partial", groups, g)
             total += got_p  # (below groups * p < 2^63)
         split = ctx.upload(ct)
-        ctx.switch_key_finish(k, split, ctx.upload(total), count)
+        ctx.switch_key_finish(k, split, ctx.upload(total), count, groups)
         assert np.array_equal(split.download(ct.shape), want), ("finish", groups)
+    # a world size whose sum of residues could pass 2^63 is refused, not wrapped (61-bit primes: more than 4 partials)
+    if max(kmods) * 1000 >= 1 << 63:
+        with pytest.raises(ValueError):
+            ctx.switch_key_finish(k, ctx.upload(ct), ctx.upload(total), count, 1000)
     with pytest.raises(ValueError):
         ctx.switch_key_partial(k, dtarget, count, dkey, 0, nd + 1, ctx.alloc(count * 2 * rows * n))
 
@@ -1031,6 +1035,56 @@ def test_transparency_is_a_flag_output_of_the_operations(sealhip, scheme, logn, 
     g2 = ctx.upload(a)
     ev.apply_galois_inplace(g2, k, count, ctx.galois_elt_from_step(1), dkey)
     assert np.array_equal(g2.download((count, 2, k, n)), ref_g)
+
+
+def test_transparency_sink_dies_with_its_thread(sealhip):
+    """ADVICE r03 (engine.cpp LanePool::give): a lane goes back to the pool when its thread exits, the sink the thread had
+    registered must not go with it. Thread A registers a 2-item sink and exits; thread B -- which gets A's lane from the idle
+    list -- runs a 6-item operation: no E_INVALIDARG from the stale capacity, and A's buffer keeps its sentinel."""
+    import threading
+
+    logn, n = 12, 4096
+    kmods = O.coeff_modulus_create(n, [40, 40, 41])
+    k, count = 2, 6
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(3)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    flags = ctx.alloc(1)
+    sentinel = np.array([0xA5A5A5A5A5A5A5A5], dtype=np.uint64)
+    flags.upload(sentinel)
+    err = []
+
+    def thread_a():
+        try:
+            ctx.transparency_sink(flags, 2)
+            ev.negate(ctx.upload(a[:2]), 2, k, 2, ctx.alloc(2 * 2 * k * n))
+            ctx.synchronize()
+            flags.upload(sentinel)  # what the sink wrote is not the point; what happens AFTER the thread is
+            ctx.synchronize()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    ta = threading.Thread(target=thread_a)
+    ta.start()
+    ta.join()
+    out = {}
+
+    def thread_b():
+        try:
+            o = ctx.alloc(count * 2 * k * n)
+            ev.negate(ctx.upload(a), 2, k, count, o)  # count > the dead thread's capacity of 2
+            out["neg"] = o.download((count, 2, k, n))
+        except Exception as e:
+            err.append(e)
+
+    tb = threading.Thread(target=thread_b)
+    tb.start()
+    tb.join()
+    assert not err, err
+    assert np.array_equal(flags.download(), sentinel), "a later thread wrote into the sink of a thread that has exited"
+    kk = np.array(kmods[:k], dtype=np.uint64).reshape(1, 1, k, 1)
+    assert np.array_equal(out["neg"], np.where(a == 0, a, kk - a))
 
 
 def test_f1_transparent_mod63_and_native_rotate(sealhip):

@@ -50,7 +50,7 @@ def main():
         bench.fill_mod_rows(target, kmods[:k])
         bench.fill_mod_rows(key, kmods)
         dkey = S.KSwitchKeys(ctx, key, n_digits=nd, from_host=False)
-        part = torch.empty((m, 2, k + 1, n), dtype=torch.int64, device=dev)
+        part = torch.empty((m, 2, k + ctx.nsp, n), dtype=torch.int64, device=dev)  # (k + nsp rows per component)
         unsplit = ct.clone()
         ctx.switch_key_inplace(k, unsplit, target, m, dkey)
     j0, j1 = bench.shard_range(nd, rank, world)
@@ -60,7 +60,7 @@ def main():
         stream.synchronize()  # the collective runs on its own stream
         dist.all_reduce(part, op=dist.ReduceOp.SUM)  # words below world * p < 2^63
         torch.cuda.current_stream().synchronize()
-        ctx.switch_key_finish(k, dst, part, m)
+        ctx.switch_key_finish(k, dst, part, m, world)
 
     work = ct.clone()
     split_once(work)
