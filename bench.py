@@ -6,7 +6,7 @@ A step = Evaluator::multiply + Evaluator::relinearize over one batch of independ
 ciphertexts that are already resident in HBM (config 3 of BASELINE.json: N=2^15, {55}x8 primes, k=7,
 |Bsk|=8, 7 key digits, t=786433, PARITY mode = bit-exact with the reference).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--config 3|4|5] [--force-dist]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config 3|4|5] [--mode parity|strict] [--force-dist]
 
 --config selects the BASELINE.json line (default 3, the one the metric is quoted on; the driver's command is
 unchanged): 4 = CKKS N=2^15, 12 primes, Evaluator::rotate_vector over the rank's share of the 8192 ciphertexts with the
@@ -20,9 +20,17 @@ contiguously over ranks with NO data-path collective (weak scaling: every rank o
 Collectives: the timing barrier / max-over-ranks, and after the timed region the final gather SURVEY 8(e) names
 (every rank's output slice to rank 0 over RCCL/xGMI), timed separately and checked by digest.
 
-The timed path verifies itself: after the timed region ciphertext pairs 0, B/2 (inside the middle arena chunk)
-and B-1 are pulled back to the host and compared word for word with the CPU oracle's multiply+relinearize of
-the same inputs (`verified_items`); a mismatch fails the run.
+--mode strict times SEALHIP_MODE_STRICT (SURVEY F4 "report both modes": Harvey-corrected forward butterflies and NTT'd
+in-bundle BFV rows, the mode whose BFV results decrypt; evaluator.cpp:235-272 is what a user calls either way) with the
+same schema, `config.mode` = "STRICT", verified against the oracle's STRICT restatement.
+
+The timed path verifies itself: after the timed region at least 256 items of the batch (seeded pseudo-random picks plus
+items 0, B/2, B-1 and the first and last item of every arena chunk the operations walked the batch in) are pulled
+back to the host and compared word for word with the CPU oracle's result for the same inputs, on the thread pool the CPU
+baseline uses (`verified_count`, `verified_items`); a mismatch fails the run.
+
+`pcie_inclusive` (N = 1): the same step through the library's host-pointer entries on separately allocated pageable host
+ciphertexts (what a std::vector<seal::Ciphertext> is), H2D and D2H included -- reported next to `value`, never as it.
 
 Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
 """
@@ -287,12 +295,12 @@ class OracleOp:
     thing the CPU baseline times. `run(a, b, reps)` -> the result words after applying the step `reps` times (the in-place
     rotate of config 4 is applied once per step, so the timed output is the (warmup + steps)-fold rotation)."""
 
-    def __init__(self, O, cfg, key_host, galois_elt=None):
+    def __init__(self, O, cfg, key_host, galois_elt=None, strict=False):
         self.O, self.L, self.cfg = O, O.lib(), cfg
         self.n = 1 << cfg["logn"]
         kmods = O.coeff_modulus_create(self.n, cfg["bits"])
         assert kmods == cfg["primes"], "hard-wired primes differ from CoeffModulus::Create"
-        self.ref = O.RefContext(cfg["scheme"], cfg["logn"], kmods, nsp=NSP, t=cfg["t"])
+        self.ref = O.RefContext(cfg["scheme"], cfg["logn"], kmods, nsp=NSP, t=cfg["t"], mode=1 if strict else 0)
         self.k = self.ref.k_first
         self.key = key_host
         self.keys = (C.c_void_p * 1)(key_host.ctypes.data)
@@ -319,7 +327,17 @@ class OracleOp:
         return ms
 
 
-def cpu_baseline(O, how, cfg, total_ops, galois_elt):
+def usable_cpus():
+    """CPUs this process may really use: min(logical CPUs, scheduler affinity, cgroup CPU quota)."""
+    import math
+
+    info = cpu_info()
+    usable = [c for c in (info["logical_cpus"], info["affinity_cpus"],
+                          math.ceil(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else None) if c]
+    return max(1, min(usable) if usable else 1)
+
+
+def cpu_baseline(O, how, cfg, total_ops, galois_elt, strict=False):
     """Times the CPU oracle (oracle/sealref.c, digest-identical to the reference) on a bounded sample of the SAME
     workload: one worker thread per CPU this process may use -- min(logical CPUs, scheduler affinity, cgroup CPU quota);
     threads beyond the quota only get throttled -- each running the config's step on its own ciphertexts (the
@@ -331,9 +349,7 @@ def cpu_baseline(O, how, cfg, total_ops, galois_elt):
 
     L = O.lib()
     info = cpu_info()
-    usable = [c for c in (info["logical_cpus"], info["affinity_cpus"],
-                          math.ceil(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else None) if c]
-    threads = max(1, min(usable) if usable else 1)
+    threads = usable_cpus()
     per_thread = max(1, int(round(total_ops / threads)))
     n, kmods = 1 << cfg["logn"], cfg["primes"]
     k = len(kmods) - NSP
@@ -343,7 +359,7 @@ def cpu_baseline(O, how, cfg, total_ops, galois_elt):
         return np.stack([rng.integers(0, p, size=n, dtype=np.uint64) for p in mods])
 
     key = np.stack([rows(kmods * 2).reshape(2, len(kmods), n) for _ in range(k)])
-    op = OracleOp(O, cfg, key, galois_elt)
+    op = OracleOp(O, cfg, key, galois_elt, strict)
     work = [(rows(kmods[:k] * 2).reshape(2, k, n), rows(kmods[:k] * 2).reshape(2, k, n)) for _ in range(threads)]
 
     def run(item, reps=per_thread):
@@ -403,7 +419,9 @@ class EngineWorkload:
         # one explicit stream for torch's fills/copies AND the engine's launches: everything below is ordered on it
         self.stream = torch.cuda.Stream(device=self.dev)
         self.n, self.kmods = 1 << cfg["logn"], cfg["primes"]
-        self.ctx = S.Context(cfg["scheme"], cfg["logn"], self.kmods, NSP, cfg["t"], device=local_rank)
+        self.strict = args.mode == "strict"
+        self.ctx = S.Context(cfg["scheme"], cfg["logn"], self.kmods, NSP, cfg["t"],
+                             mode=S.MODE_STRICT if self.strict else S.MODE_PARITY, device=local_rank)
         self.ctx.set_stream(self.stream.cuda_stream)
         self.ev = S.Evaluator(self.ctx)
         self.S = S
@@ -428,9 +446,31 @@ class EngineWorkload:
             torch.manual_seed(99)  # the relinearisation / Galois key is replicated on every GPU
             fill_mod_rows(self.key, self.kmods)
             self.rk = S.KSwitchKeys(self.ctx, self.key, n_digits=k, from_host=False)
-            # the inputs of the items the checker leg verifies (config 4 rotates in place: keep what they were)
-            self.items = sorted({0, B // 2, B - 1})
-            self.saved_a = {i: host_u64(self.a[i]) for i in self.items}
+        self.want_items = 0 if args.no_verify else max(3, args.verify_items)
+        self.items, self.saved_a, self.chunks, self.saved_at = [], {}, [], 0
+
+    def choose_items(self):
+        """Which items the checker leg verifies: 0, B/2, B-1, the first and last item of every arena chunk the operations of
+        a step walk the batch in (the launch geometry is position dependent: chunked launches, XCD-aware block maps, item
+        groups), and seeded pseudo-random picks up to --verify-items. Called after the first warm-up step (the chunk
+        plan is what the library reports, sealhip_debug_chunk_log) and before the timed region; config 4 rotates in place,
+        so the inputs of the chosen items are kept."""
+        B = self.B
+        picks = {0, B // 2, B - 1}
+        self.chunks = sorted({c for cnt, c in self.ctx.chunk_log() if cnt == B and 0 < c < B})
+        for c in self.chunks:
+            for edge in range(c, B, c):
+                picks.update((edge - 1, edge))
+        rng = np.random.default_rng(20261005 + B)
+        for i in rng.permutation(B):
+            if len(picks) >= min(B, self.want_items):
+                break
+            picks.add(int(i))
+        self.items = sorted(picks)
+        self.saved_at = self.steps_done
+        if self.cfg["op"] == "rotate":
+            with torch.cuda.stream(self.stream):
+                self.saved_a = {i: host_u64(self.a[i]) for i in self.items}
 
     def step(self):
         op, k, B = self.cfg["op"], self.k, self.B
@@ -464,18 +504,81 @@ class EngineWorkload:
             return cheap_digest(self.key[0, 0, :1])
 
     def verify(self, O):
-        """The timed path's own output for items 0, B/2, B-1 against the CPU oracle, word for word."""
+        """The timed path's own output for the chosen items against the CPU oracle, word for word, on one worker thread
+        per usable CPU (the oracle is thread-safe across calls, like the reference). -> list of items that differ."""
+        from concurrent.futures import ThreadPoolExecutor
+
         with torch.cuda.stream(self.stream):
-            op = OracleOp(O, self.cfg, host_u64(self.key), self.elt)
-            oks = []
-            for i in self.items:
-                got = host_u64(self.results()[i])
-                if self.cfg["op"] == "rotate":
-                    exp = op.run(self.saved_a[i], None, reps=self.steps_done)
-                else:
-                    exp = op.run(self.saved_a[i], host_u64(self.b[i]))
-                oks.append(bool(np.array_equal(got, exp)))
-        return oks
+            op = OracleOp(O, self.cfg, host_u64(self.key), self.elt, self.strict)
+            rotate = self.cfg["op"] == "rotate"
+            res = self.results()
+
+            def fetch(i):
+                got = host_u64(res[i])
+                a = self.saved_a[i] if rotate else host_u64(self.a[i])
+                b = None if rotate else host_u64(self.b[i])
+                return i, got, a, b
+
+            def check(job):
+                i, got, a, b = job
+                exp = op.run(a, b, reps=self.steps_done - self.saved_at) if rotate else op.run(a, b)
+                return i, bool(np.array_equal(got[: exp.shape[0]], exp))
+
+            bad = []
+            with ThreadPoolExecutor(max_workers=usable_cpus()) as ex:
+                # (fetched in slices so that a few hundred 5 MB items never sit in host memory all at once)
+                for lo in range(0, len(self.items), 64):
+                    jobs = [fetch(i) for i in self.items[lo:lo + 64]]
+                    bad += [i for i, ok in ex.map(check, jobs) if not ok]
+        return bad
+
+    def pcie_inclusive(self, pairs):
+        """SURVEY 8(d) "report separately with H2D/D2H included": the same step through the library's host-pointer entries
+        (csrc/hostbatch.cpp: gather threads, pinned double-buffered staging, H2D / compute / D2H on three streams) on
+        `pairs` SEPARATELY ALLOCATED pageable host ciphertexts -- what a std::vector<seal::Ciphertext> is
+        (ciphertext.h:709-721). Results are checked against the device-resident path on the same inputs."""
+        op, k, n, ev = self.cfg["op"], self.k, self.n, self.ev
+        P = min(pairs, self.B)
+        if P <= 0:
+            return None
+        with torch.cuda.stream(self.stream):
+            ha = [host_u64(self.a[i]).copy() for i in range(P)]
+            hb = None if op == "rotate" else [host_u64(self.b[i]).copy() for i in range(P)]
+            if op == "rotate":  # the device path on a copy of the same inputs
+                ref = self.a[:P].clone()
+                ev.rotate_vector_inplace(ref, k, P, 1, {self.elt: self.rk})
+                ref = host_u64(ref)
+            else:
+                ref = host_u64(self.results()[:P])
+        self.ctx.synchronize()
+        kk = k - 1 if op == "mul_relin_modswitch" else k
+        ho = None if op == "rotate" else [np.zeros((2, k, n), dtype=np.uint64) for _ in range(P)]
+        ho2 = [np.zeros((2, kk, n), dtype=np.uint64) for _ in range(P)] if op == "mul_relin_modswitch" else None
+
+        def run(work):
+            if op == "rotate":
+                ev.rotate_vector_host(work, k, 1, {self.elt: self.rk})
+            else:
+                ev.multiply_host(ha, 2, hb, 2, k, ho, relin_keys=[self.rk])
+                if op == "mul_relin_modswitch":
+                    ev.mod_switch_to_next_host(ho, 2, k, ho2)
+
+        first = [x.copy() for x in ha] if op == "rotate" else None
+        run(first)  # staging buffers, arena; also the run that is compared
+        got = first if op == "rotate" else (ho2 if ho2 else ho)
+        ok = all(np.array_equal(got[i], ref[i][:2] if op != "rotate" else ref[i]) for i in range(P))
+        reps, t0 = 2, time.perf_counter()
+        for _ in range(reps):
+            run([x.copy() for x in ha] if op == "rotate" else None)
+        dt = (time.perf_counter() - t0) / reps
+        in_bytes = P * 2 * k * n * 8 * (1 if op == "rotate" else 2)
+        out_bytes = P * 2 * kk * n * 8
+        return {"value": P / dt, "unit": self.cfg["unit"], "units": P, "seconds_per_call": dt,
+                "boundary": "sealhip_evaluator_*_host: %d separately allocated pageable host ciphertext%s in, results out "
+                            "(gather threads + pinned double-buffered staging + H2D / compute / D2H streams inside the "
+                            "library)" % (P, "s" if op == "rotate" else " pairs"),
+                "h2d_GBps": in_bytes / dt / 1e9, "d2h_GBps": out_bytes / dt / 1e9, "matches_device_path": bool(ok),
+                "note": "PCIe-inclusive rate, reported next to `value` (inputs resident in HBM), never as it"}
 
 
 class StubWorkload:
@@ -525,6 +628,13 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="BASELINE.json line: 3 = BFV multiply+relinearize (the metric's config, default), 4 = CKKS "
                          "rotate_vector, 5 = BFV N=2^16 multiply+relinearize+mod_switch_to_next")
+    ap.add_argument("--mode", choices=("parity", "strict"), default="parity",
+                    help="parity (default): bit-exact with the reference as built, SURVEY F2/F3 included; strict: "
+                         "SEALHIP_MODE_STRICT, the mode whose BFV results decrypt (SURVEY B.6) -- same schema")
+    ap.add_argument("--verify-items", type=int, default=256,
+                    help="items of the batch checked word for word against the CPU oracle after the timed region")
+    ap.add_argument("--pcie-pairs", type=int, default=256,
+                    help="separately allocated pageable host ciphertexts in the PCIe-inclusive section (0: skip)")
     ap.add_argument("--batch", type=int, default=None,
                     help="independent ciphertexts (pairs) per GPU; default per config: 4096 / 1024 / 256 "
                          "(SEALHIP_BENCH_BATCH overrides the default)")
@@ -561,6 +671,9 @@ def main(argv=None):
     cfg = CONFIGS[args.config]
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if not args.stub and args.gpus > torch.cuda.device_count():  # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py: --gpus %d but this node shows %d HIP device(s): nothing was launched"
+                         % (args.gpus, torch.cuda.device_count()))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing above has touched the GPU
     if args.measure_traffic and args.gpus == 1 and not args.stub:
@@ -589,6 +702,10 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         w.step()
+        if not args.stub and not w.items:
+            w.choose_items()  # after the first step: the arena chunks are known (and the in-place config keeps its inputs)
+    if not args.stub and not w.items:
+        w.choose_items()
     barrier_sync()
     if not args.stub:
         w.ctx.profile_enable(True)
@@ -626,6 +743,30 @@ def main(argv=None):
                 "rows_per_launch": rows_per_launch, "algorithmic_bytes_per_launch": alg_bytes,
                 "launches": v["launches"], "share_of_step_kernel_time": v["ms"] / total_ms}
 
+    def valu_ceiling(r):
+        """SURVEY 8(d) "secondary limiter": what the transform's own arithmetic allows on THIS device -- the rate of a
+        kernel that executes nothing but the butterfly sequence of the launches' instance (sealhip_debug_butterfly_rate:
+        same instructions, operands in registers, same occupancy), divided by the N/2 log2 N butterflies of a row. The
+        integer instances are bound by it (vector-ALU issue under the package power cap), not by HBM."""
+        if args.stub or not r or not r.get("achieved"):
+            return
+        try:
+            fp = all(p < (1 << 50) for p in w.kmods[:k]) and cfg["scheme"] == 2
+            kind = 3 if fp else (0 if args.mode == "strict" else 2)
+            rate = w.ctx.butterfly_rate(kind, 0)
+            rate_exact = rate if fp else w.ctx.butterfly_rate(0, 0)
+        except Exception:
+            return
+        per_row = (n // 2) * cfg["logn"]
+        rows_s = rate / per_row
+        r["bound"] = "hbm" if fp else "valu"
+        r["valu_ceiling"] = {
+            "butterfly": {3: "FP64 (primes below 2^50)", 2: "integer, approximate Shoup quotient level 2", 0: "integer, exact Shoup quotient"}[kind],
+            "butterflies_per_s": rate, "butterflies_per_s_reference_sequence": rate_exact,
+            "butterflies_per_row": per_row, "rows_per_s": rows_s, "as_frac_of_hbm": rows_s * 16 * n / 1e9 / HBM_PEAK_GBS,
+            "note": "measured in this run on this device: a kernel of nothing but the instance's butterflies, operands in registers"}
+        r["alu_ceiling_frac"] = r["frac"] / r["valu_ceiling"]["as_frac_of_hbm"]
+
     roof, traffic_rec = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if prof and os.path.exists(tpath):
@@ -647,6 +788,7 @@ def main(argv=None):
         if traffic_rec and roof.get("rows_per_launch") and roof["kernel"] in traffic_rec:
             roof["traffic"] = traffic_rec[roof["kernel"]]["hbm_bytes_per_row_per_launch"] * roof["rows_per_launch"]
             roof["traffic_source"] = "profiles/traffic.json (%s)" % traffic_rec.get("measured", "rocprofv3 --pmc")
+        valu_ceiling(roof)
 
     # ---- the pipeline-level roofline and the top kernels against their own algorithmic bytes
     pipeline, kernels = None, None
@@ -705,8 +847,20 @@ def main(argv=None):
             "forward_ntt_per_s_kernel_time": ntt_rows / ntt_kernel_s,
             "hbm_roofline_frac": (ntt_rows * 16 * n / ntt_kernel_s) / 1e9 / HBM_PEAK_GBS,
             "rows": P * k, "reps": reps, "n": n,
+            "rows_note": "%d polynomials x the k = %d first-level primes of this config per launch (the key level has one "
+                         "more prime; the rate is per row)" % (P, k),
         }
+        if roof and roof.get("valu_ceiling"):
+            ntt["alu_ceiling_frac"] = ntt["hbm_roofline_frac"] / roof["valu_ceiling"]["as_frac_of_hbm"]
         del x
+
+    # ---- PCIe-inclusive rate of the same step (N = 1): host-pointer entries on separately allocated pageable ciphertexts
+    pcie = None
+    if not args.stub and world == 1 and args.pcie_pairs > 0:
+        try:
+            pcie = w.pcie_inclusive(args.pcie_pairs)
+        except MemoryError:
+            pcie = None
 
     # ---- the final gather (N > 1, or --force-dist): every rank's result slice to rank 0 over RCCL, timed on its own
     gather = gather_payload(w.result_slice(min(B, args.gather_cts)), cheap_digest, force=args.force_dist)
@@ -714,21 +868,24 @@ def main(argv=None):
     rank_digests = gather_digests(cheap_digest(w.result_slice(min(B, 4))))
 
     # ---- checker leg: the timed path's output against the CPU oracle, then the CPU baseline (rank 0, N = 1)
-    verified, items, cpu = None, [], None
+    verified, items, cpu, bad_items = None, [], None, []
     if not args.stub and not (args.no_verify and (args.no_cpu_baseline or world > 1)):
         O, how = load_oracle()
         if not args.no_verify:
             items = w.items
-            verified = all_ranks_true(all(w.verify(O)))
+            bad_items = w.verify(O)
+            verified = all_ranks_true(not bad_items)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(O, how, cfg, args.cpu_ops, w.elt)
+            cpu = cpu_baseline(O, how, cfg, args.cpu_ops, w.elt, args.mode == "strict")
             cpu["gpu_over_cpu_%dthreads_measured" % cpu["cores"]] = value / cpu["value"]
             cpu["gpu_over_cpu_1thread"] = value / cpu["value_1thread"]
             cpu["gpu_over_cpu_all_physical_cores_projected"] = value / cpu["projected_all_physical_cores_linear"]
 
     if rank == 0:
         line = {
-            "metric": "stub rank-logic rehearsal (NOT the engine)" if args.stub else cfg["metric"],
+            "metric": "stub rank-logic rehearsal (NOT the engine)" if args.stub else (
+                cfg["metric"].replace("bit-exact PARITY mode", "STRICT mode: the results that decrypt, SURVEY B.6")
+                if args.mode == "strict" else cfg["metric"]),
             "value": value,
             "unit": cfg["unit"],
             "n_gpus": world,
@@ -741,7 +898,7 @@ def main(argv=None):
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": args.config,
-                       "ciphertexts_per_gpu": B, "global_batch": world * B, "mode": "PARITY",
+                       "ciphertexts_per_gpu": B, "global_batch": world * B, "mode": args.mode.upper(),
                        "parallelism": "dp%d (independent ciphertexts sharded, no data-path collective)" % world},
             "roofline": roof,
             "pipeline_roofline": pipeline,
@@ -749,7 +906,10 @@ def main(argv=None):
             "cpu_baseline": cpu,
             "ntt": ntt,
             "kernel_time_shares": shares,
+            "pcie_inclusive": pcie,
+            "verified_count": len(items),
             "verified_items": items,
+            "verified_chunk_sizes": getattr(w, "chunks", []),
             "verified_vs_oracle": verified,
             "gather": gather,
             "rccl_ranks_seen": gather["ranks_seen"] if gather else (1 if world == 1 else 0),
@@ -764,7 +924,8 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if verified is False:
-        raise SystemExit("bench.py: the timed path's output differs from the CPU oracle (items %s)" % items)
+        raise SystemExit("bench.py: the timed path's output differs from the CPU oracle (items %s of the %d checked on rank %d)"
+                         % (bad_items, len(items), rank))
 
 
 KERNEL_TAGS = (("ntt_fwd_half_kernel", "ntt_fwd_half"), ("ntt_inv_half_kernel", "ntt_inv_half"), ("ntt_inv_top_kernel", "ntt_inv_top"),

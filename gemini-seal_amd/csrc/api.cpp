@@ -371,6 +371,39 @@ long sealhip_debug_ntt_handoff(sealhip_context *ctx, uint32_t spin_limit, int32_
     });
 }
 
+long sealhip_debug_chunk_log(sealhip_context *ctx, size_t *count_chunk_pairs, size_t capacity_pairs, size_t *written)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(count_chunk_pairs);
+    REQUIRE_PTR(written);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        auto &log = e.lane().chunk_log;
+        std::size_t n = 0;
+        for (; n < log.size() && n < capacity_pairs; n++)
+        {
+            count_chunk_pairs[2 * n] = log[n].first;
+            count_chunk_pairs[2 * n + 1] = log[n].second;
+        }
+        *written = n;
+        log.clear();
+    });
+}
+
+long sealhip_debug_butterfly_rate(sealhip_context *ctx, uint32_t kind, uint32_t prime_index, double *butterflies_per_s)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(butterflies_per_s);
+    return guarded([&] {
+        Engine &e = device_engine(ctx);
+        e.sync_and_check(true);
+        const hipError_t err = ntt_butterfly_rate(e, static_cast<int>(kind), static_cast<int>(prime_index), butterflies_per_s);
+        if (err == hipErrorInvalidValue)
+            throw std::invalid_argument("butterfly_rate: kind 0..5, a prime of the context (kind 3: one below 2^50)");
+        SEALHIP_CHECK(err);
+    });
+}
+
 long sealhip_malloc(sealhip_context *ctx, size_t bytes, void **dptr)
 {
     REQUIRE_PTR(ctx);

@@ -338,7 +338,12 @@ namespace sealhip
     }
     __device__ __forceinline__ u64 reduce_small_quot(u64 x, float c, u64 neg_p)
     {
-        const u32 q = static_cast<u32>(static_cast<float>(static_cast<u32>(x >> 32)) * c); // v_cvt_f32_u32, v_mul_f32, v_cvt_u32_f32
+        // v_cvt_f32_u32, v_mul_f32, v_cvt_u32_f32. (The conversion is spelled as the instruction: from `(float)(u32)(x >> 32)`
+        // the compiler sometimes builds the generic 64-bit integer -> float sequence, seven instructions, for a value it could
+        // see was below 2^32.)
+        float hf;
+        asm("v_cvt_f32_u32 %0, %1" : "=v"(hf) : "v"(static_cast<u32>(x >> 32)));
+        const u32 q = static_cast<u32>(hf * c);
         const u64 v = mad64<true>(q, static_cast<u32>(neg_p), x);                          // x + q * (2^64 - p), low word
         return add_hi32(v, static_cast<u64>(q * static_cast<u32>(neg_p >> 32)));
     }
@@ -376,7 +381,7 @@ namespace sealhip
     // mul, mad + carry, v_cndmask, v_mov, mad = 5 -- PROVIDED the 64-bit addend (t1, 0) costs no move. A 64-bit operand is
     // an even-aligned register pair, and zero-extending a 32-bit result normally costs the v_mov of the upper half. Here the
     // upper halves are written ONCE per phase (ZeroHi::init, opaque to the compiler, which would otherwise fold the zero and
-    // re-materialise it per use) and v_mul_hi_u32 writes the lower half of the same pair in place: `with_low` tells the
+    // re-materialise it per use; two v_mov per phase) and v_mul_hi_u32 writes the lower half of the same pair in place: `with_low` tells the
     // compiler that the upper half is unchanged, and its coalescer keeps the pair where it is (checked in the ISA: no
     // v_mov between the v_mul_hi_u32 and the v_mad_u64_u32 that reads the pair).
     template <int N>
@@ -526,40 +531,52 @@ namespace sealhip
         xu = X;
         xy = (u << 1) + four_p - X;
     }
+    // (two pairs serve the IL = 4 butterflies: slots 0, 1 take them first, slots 2, 3 once those quotients have read them --
+    //  four pairs held through a whole round cost four registers in kernels that run at the 128-register cap)
     template <bool WU, int IL>
     __device__ __forceinline__ void butterflies_fwd_apx2(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
-                                                         u64 neg_p, u64 four_p, u64 (&zp)[IL])
+                                                         u64 neg_p, u64 four_p, u64 (&zp)[2])
     {
+        static_assert(IL == 4, "two zero-high pairs, each used by two of the four butterflies");
         const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
         u64 A[IL], E[IL], V[IL], q[IL];
         u32 t1[IL], t2[IL];
         u64 cy[IL] = {};
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 1: t1 = hi32(y0*s1), into the low half of the zero-high pair
+        for (int j = 0; j < 2; j++) // t1 = hi32(y0*s1), into the low half of the zero-high pair
             t1[j] = mulhi32v<WU>(static_cast<u32>(y[j]), static_cast<u32>(ws[j] >> 32));
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 2: E = y0*w1
+        for (int j = 0; j < IL; j++) // E = y0*w1
             E[j] = mul64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j] >> 32), cy[j]);
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 3: t2 = hi32(y1*s0)
+        for (int j = 0; j < IL; j++) // t2 = hi32(y1*s0)
             t2[j] = mulhi32v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j]));
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 4: E += y1*w0
-            E[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
-#pragma unroll
-        for (int j = 0; j < IL; j++) // 5: A = y1*s1 + t1
+        for (int j = 0; j < 2; j++) // A = y1*s1 + t1
         {
             zp[j] = with_low(zp[j], t1[j]);
             A[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j] >> 32), zp[j], cy[j]);
         }
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 6: V = u + y0*w0
+        for (int j = 2; j < 4; j++)
+            t1[j] = mulhi32v<WU>(static_cast<u32>(y[j]), static_cast<u32>(ws[j] >> 32));
+#pragma unroll
+        for (int j = 0; j < IL; j++) // E += y1*w0
+            E[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
+#pragma unroll
+        for (int j = 2; j < 4; j++)
+        {
+            zp[j - 2] = with_low(zp[j - 2], t1[j]);
+            A[j] = mad64v<WU>(static_cast<u32>(y[j] >> 32), static_cast<u32>(ws[j] >> 32), zp[j - 2], cy[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++) // V = u + y0*w0
             V[j] = mad64v<WU>(static_cast<u32>(y[j]), static_cast<u32>(w[j]), u[j], cy[j]);
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 7: q = A + t2  (t2 * 1 + A: a 32-bit addend needs no zero-extended pair this way)
+        for (int j = 0; j < IL; j++) // q = A + t2  (t2 * 1 + A: a 32-bit addend needs no zero-extended pair this way)
             asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(q[j]), "+s"(cy[j]) : "v"(t2[j]), "v"(A[j]));
 #pragma unroll
-        for (int j = 0; j < IL; j++) // 8..10: + q*(2^64 - p)
+        for (int j = 0; j < IL; j++) // + q*(2^64 - p)
             E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);
 #pragma unroll
         for (int j = 0; j < IL; j++)
@@ -574,6 +591,12 @@ namespace sealhip
             y[j] = (u[j] << 1) + four_p - X;
             u[j] = X;
         }
+    }
+    // lazy product with the level-2 quotient: x*y - q*p in [0, 4p) (any 64-bit x, y < p)
+    template <bool WU>
+    __device__ __forceinline__ u64 mulmod_lazy_apx2(u64 x, u64 y, u64 yshoup, u64 neg_p, u64 &zp)
+    {
+        return mullo2_acc<WU>(0, x, y, mulhi_apx2<WU>(x, yshoup, zp), neg_p);
     }
     // ---------------------------------------------------------------------------------------------
     // Carry-free 128-bit dot product  sum_i t_i * c_i  for operands below 2^61 (SEAL_MOD_BIT_COUNT_MAX,
@@ -684,6 +707,70 @@ namespace sealhip
         for (int j = 0; j < IL; j++)
             q[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j] >> 32),
                               static_cast<u64>(static_cast<u32>(B[j] >> 32)) | (static_cast<u64>(cb[j]) << 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mad64v<true>(static_cast<u32>(q[j]), n0, V[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<true>(static_cast<u32>(q[j] >> 32), n0, E[j], cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            y[j] = add_hi32(V[j], E[j]);
+    }
+    // MODE 1 (lazy sum) of butterflies_inv_hs with the level-2 quotient (mulhi_apx2): x' = u + y unreduced,
+    // y' = (u - y + addend) * w in [0, 4p). Only where the schedule's bound on the layer's outputs is the SUM's (at least
+    // 4p: every MODE 1 layer, ntt_bounds.hpp section 1), so the schedule and its admission predicate are unchanged.
+    template <bool WU, int IL>
+    __device__ __forceinline__ void butterflies_inv_apx2(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
+                                                         u64 neg_p, u64 addend, u64 (&zp)[2])
+    {
+        static_assert(IL == 4, "two zero-high pairs, each used by two of the four butterflies");
+        const u32 n0 = static_cast<u32>(neg_p), n1 = static_cast<u32>(neg_p >> 32);
+        u64 dlt[IL], A[IL], E[IL], V[IL], q[IL];
+        u32 t1[IL], t2[IL];
+        u64 cy[IL] = {};
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+        {
+            dlt[j] = u[j] - y[j] + addend;
+            u[j] = u[j] + y[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            t1[j] = mulhi32v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(ws[j] >> 32));
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mul64v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(w[j] >> 32), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            t2[j] = mulhi32v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j]));
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+        {
+            zp[j] = with_low(zp[j], t1[j]);
+            A[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j] >> 32), zp[j], cy[j]);
+        }
+#pragma unroll
+        for (int j = 2; j < 4; j++)
+            t1[j] = mulhi32v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(ws[j] >> 32));
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            E[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(w[j]), E[j], cy[j]);
+#pragma unroll
+        for (int j = 2; j < 4; j++)
+        {
+            zp[j - 2] = with_low(zp[j - 2], t1[j]);
+            A[j] = mad64v<WU>(static_cast<u32>(dlt[j] >> 32), static_cast<u32>(ws[j] >> 32), zp[j - 2], cy[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            V[j] = mul64v<WU>(static_cast<u32>(dlt[j]), static_cast<u32>(w[j]), cy[j]);
+#pragma unroll
+        for (int j = 0; j < IL; j++)
+            asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(q[j]), "+s"(cy[j]) : "v"(t2[j]), "v"(A[j]));
 #pragma unroll
         for (int j = 0; j < IL; j++)
             E[j] = mad64v<true>(static_cast<u32>(q[j]), n1, E[j], cy[j]);

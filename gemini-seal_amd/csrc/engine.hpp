@@ -254,6 +254,9 @@ namespace sealhip
         std::size_t ws_bytes = 0, ws_used = 0;
         std::size_t ws_floor = 0; // bytes at the front of the arena held by an enclosing operation
         std::size_t ws_budget = 0; // cap of this lane's arena, fixed at first use (pipeline.cpp)
+        // (batch size, items per arena chunk) of the last operations that walked a batch in chunks (pipeline.cpp plan_chunk;
+        // sealhip_debug_chunk_log): lets a caller that verifies its results pick the items at the chunk boundaries
+        std::vector<std::pair<std::size_t, std::size_t>> chunk_log;
         std::recursive_mutex busy; // held for the duration of an operation (a graph may be launched from another thread)
         ~Lane();
     };
@@ -369,6 +372,8 @@ namespace sealhip
 
     // ---- launchers (each enqueues on e.stream) ----
     hipError_t ntt_init_kernels();
+    // measured arithmetic ceiling of a butterfly sequence (ntt.hip butterfly_rate_kernel): butterflies per second
+    hipError_t ntt_butterfly_rate(const Engine &e, int kind, int prime_id, double *butterflies_per_s);
     hipError_t launch_ntt(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, bool inverse, int flags);
     // forward transform whose input rows are gathered from elsewhere (only when ntt_can_gather(e))
     bool ntt_can_gather(const Engine &e);

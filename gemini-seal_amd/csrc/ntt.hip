@@ -403,7 +403,7 @@ namespace sealhip
         // The butterfly's second output is u - v + (that bound), so the bound is what the layers add.
         template <int STRICT>
         constexpr int kApx = STRICT == 2 ? bounds::kFwdApxLevel : 0;
-        using ZeroPairs = ZeroHi<4>; // devmath.hpp mulhi_apx2: written where a phase starts (four v_mov), used round-robin
+        using ZeroPairs = ZeroHi<2>; // devmath.hpp mulhi_apx2: written where a phase starts (two v_mov), each used by two of the four lock-step butterflies
         // The final round at N = 2^15 runs at the register cap (two stages of prefetched twiddles, 48 registers): four more for
         // zero-high pairs spill two coefficients. Its 32 butterflies (of 272) keep the level-1 quotient there -- a product
         // below 3p under a schedule that allows 4p, so the bounds of level 2 cover it (ntt_bounds.hpp section 2).
@@ -411,8 +411,11 @@ namespace sealhip
 #define SEALHIP_NTT_FINAL_ZP 2
 #endif
         constexpr int kFinalZeroPairs = SEALHIP_NTT_FINAL_ZP;
+#ifndef SEALHIP_NTT_FINAL_APX_F2
+#define SEALHIP_NTT_FINAL_APX_F2 1
+#endif
         template <int T, int STRICT>
-        constexpr int kFinalApx = (kApx<STRICT> == 2 && (T - 12) == 2) ? 1 : kApx<STRICT>;
+        constexpr int kFinalApx = (kApx<STRICT> == 2 && (T - 12) == 2) ? SEALHIP_NTT_FINAL_APX_F2 : kApx<STRICT>;
         template <int STRICT>
         __device__ __forceinline__ u64 fwd_addend(u64 two_p, u64 neg_p)
         {
@@ -890,7 +893,7 @@ namespace sealhip
                 }
                 if constexpr (kApx<STRICT> == 2)
                 {
-                    static_assert(kIL == 4, "four zero-high pairs");
+                    static_assert(kIL == 4, "two zero-high pairs for four lock-step butterflies");
                     butterflies_fwd_apx2<UNIFORM, kIL>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z);
                 }
                 else
@@ -1312,7 +1315,7 @@ namespace sealhip
             RoundStage<T, 1, STRICT, true, 0>::load(w0, ws0, tw, gbase, N);
             if constexpr (FP)
                 fp_reduce_all(x, two_p, neg_p);
-            ZeroPairs zp; // (written again where each phase starts: four moves, and no register held across the exchanges)
+            ZeroPairs zp; // (written again where each phase starts: two moves, and no register held across the exchanges)
             if constexpr (kApx<STRICT> == 2)
                 zp.init();
             if (!NTT_EXP(flags, 0x100))
@@ -1437,6 +1440,13 @@ namespace sealhip
         // on all but two of the T on-chip layers; those two (the middle one and the last) reduce with barrett_lazy
         // instead. Values entering layer l are below 2^shift(l) * p; the difference operand gets that bound added.
         // (the schedule, its worst-case recurrence and the admission predicate live in ntt_bounds.hpp)
+        // Round 4: the MODE 1 layers of the lazy schedule (all but two) take the level-2 quotient (devmath.hpp mulhi_apx2,
+        // butterflies_inv_apx2): their products land below 4p, which is what the unreduced sum of such a layer is bounded by
+        // anyway, so shift(), mode() and the admission predicate are what they were (ntt_bounds.hpp section 1).
+#ifndef SEALHIP_NTT_INV_APX2
+#define SEALHIP_NTT_INV_APX2 1
+#endif
+        constexpr bool kInvApx2 = SEALHIP_NTT_INV_APX2 != 0;
         template <int T>
         struct InvLazy
         {
@@ -1508,7 +1518,7 @@ namespace sealhip
             }
             static constexpr int layer = (T - 12) + 4 * (3 - R) + (W - 1); // 0-based on-chip layer index
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL], u64 two_p,
-                                                       u64 neg_p, u64 rdp)
+                                                       u64 neg_p, u64 rdp, ZeroPairs &zp)
             {
                 if constexpr (LZ == 2)
                 {
@@ -1532,7 +1542,9 @@ namespace sealhip
                     u[j] = x[slot(j)];
                     y[j] = x[slot(j) | bit];
                 }
-                if constexpr (LZ == 1)
+                if constexpr (LZ == 1 && InvLazy<T>::mode(layer) == 1 && kInvApx2)
+                    butterflies_inv_apx2<UNIFORM, kIL>(u, y, w, ws, neg_p, lazy_addend(neg_p, InvLazy<T>::shift(layer)), zp.z);
+                else if constexpr (LZ == 1)
                     butterflies_inv_hs<UNIFORM, kIL, InvLazy<T>::mode(layer)>(u, y, w, ws, neg_p,
                                                                              lazy_addend(neg_p, InvLazy<T>::shift(layer)), rdp);
                 else
@@ -1551,15 +1563,15 @@ namespace sealhip
             static constexpr int NST = NLAYERS * (16 / kIL); // (NLAYERS = 3: the whole-row form applies the round's last layer itself)
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64 (&w)[kIL], const u64 (&ws)[kIL],
                                                        const u64 *__restrict__ tw, int jb, int N, u64 two_p, u64 neg_p,
-                                                       u64 rdp)
+                                                       u64 rdp, ZeroPairs &zp)
             {
                 u64 wn[kIL], wsn[kIL];
                 if constexpr (K + 1 < NST)
                     RoundStageInv<T, R, UNIFORM, K + 1, LZ>::load(wn, wsn, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                RoundStageInv<T, R, UNIFORM, K, LZ>::run(x, w, ws, two_p, neg_p, rdp);
+                RoundStageInv<T, R, UNIFORM, K, LZ>::run(x, w, ws, two_p, neg_p, rdp, zp);
                 if constexpr (K + 1 < NST)
-                    RoundPipeInv<T, R, UNIFORM, LZ, K + 1, NLAYERS>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, rdp);
+                    RoundPipeInv<T, R, UNIFORM, LZ, K + 1, NLAYERS>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, rdp, zp);
             }
         };
 
@@ -1954,17 +1966,24 @@ namespace sealhip
             RoundStageInv<T, 3, false, 0, LZ>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 4, 3>(x, lds, fresh_tid(wave_base));
-            RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp);
+            ZeroPairs zp; // (devmath.hpp mulhi_apx2; written again where each phase starts)
+            if constexpr (LZ == 1 && kInvApx2)
+                zp.init();
+            RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp, zp);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh_tid(wave_base));
             RoundStageInv<T, 2, false, 0, LZ>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 3, 2>(x, lds, fresh_tid(wave_base));
-            RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp);
+            if constexpr (LZ == 1 && kInvApx2)
+                zp.init();
+            RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp, zp);
             RoundStageInv<T, 1, true, 0, LZ>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh_tid(wave_base));
+            if constexpr (LZ == 1 && kInvApx2)
+                zp.init();
             if constexpr (WHOLE)
             {
-                RoundPipeInv<T, 1, true, LZ, 0, 3>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
+                RoundPipeInv<T, 1, true, LZ, 0, 3>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp, zp);
                 // the row's top layer: slot bit 4 of arrangement 1 is index bit T - 1
                 if constexpr (FP)
                 {
@@ -2004,7 +2023,7 @@ namespace sealhip
                 }
             }
             else
-                RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp);
+                RoundPipeInv<T, 1, true, LZ>::run(x, w0, ws0, tw, gbase, N, two_p, neg_p, rdp, zp);
             {
                 const int jb = Arr<T, 1>::tid_index(fresh_tid(wave_base));
 #pragma unroll
@@ -2623,6 +2642,158 @@ namespace sealhip
                 return err;
         }
         return hipSuccess;
+    }
+
+    // ---- the arithmetic ceiling of a butterfly sequence, measured on the device it runs on (sealhip_debug_butterfly_rate;
+    // bench.py's roofline.valu_ceiling). Nothing but the butterflies of the single-pass kernels' rounds: the same lock-step
+    // sequences, 32 values and four per-lane twiddles in registers, no loads, no exchanges, the same launch bounds (two
+    // workgroups of 512 lanes per CU). KIND 0: the reference's lazy butterfly (exact Shoup quotient), 1 / 2: the approximate
+    // quotients of levels 1 / 2, 3: the FP64 butterfly, 4: the lazy-sum inverse butterfly with the level-2 quotient,
+    // 5: the inverse butterfly with the reference's sequence.
+    namespace
+    {
+        template <int KIND>
+        __global__ __launch_bounds__(512, 4) void butterfly_rate_kernel(u64 *__restrict__ sink, PrimeDev P, int iters)
+        {
+            u64 x[16], w[kIL], ws[kIL]; // (16 values: the sequence is what is measured, and nothing may spill)
+            const u64 seed = (static_cast<u64>(blockIdx.x) * 512 + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+            constexpr bool FP = KIND == 3;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                const u64 v = (seed + static_cast<u64>(i) * 0xBF58476D1CE4E5B9ull) % P.p;
+                x[i] = FP ? fp_bits(fp_from_u64(v)) : v;
+            }
+#pragma unroll
+            for (int j = 0; j < kIL; j++)
+            {
+                const u64 wv = (seed ^ (0x94D049BB133111EBull * (j + 1))) % P.p;
+                w[j] = FP ? fp_bits(fp_from_u64(wv)) : wv;
+                ws[j] = static_cast<u64>((static_cast<unsigned __int128>(wv) << 64) / P.p);
+            }
+            const u64 neg_p = FP ? fp_bits(P.pinv_d) : 0 - P.p, two_p = FP ? fp_bits(P.p_d) : P.two_p;
+            ZeroPairs zp;
+            zp.init();
+            u64 four_p = two_p << 1; // (opaque like fwd_addend's: one v_lshl_add_u64 per second output)
+            asm("" : "+s"(four_p));
+            for (int it = 0; it < iters; it++)
+            {
+#pragma unroll
+                for (int W = 3; W >= 0; W--)
+                {
+#pragma unroll
+                    for (int c = 0; c < 8; c += kIL)
+                    {
+                        u64 u[kIL], y[kIL];
+                        const int bit = 1 << W;
+#pragma unroll
+                        for (int j = 0; j < kIL; j++)
+                        {
+                            const int sl = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
+                            u[j] = x[sl];
+                            y[j] = x[sl | bit];
+                        }
+                        if constexpr (KIND == 3)
+                        {
+#pragma unroll
+                            for (int j = 0; j < kIL; j++)
+                                fp_butterfly_fwd(u[j], y[j], w[j], fp_of(two_p), fp_of(neg_p));
+                        }
+                        else if constexpr (KIND == 0)
+                            butterflies_fwd_hs<false, kIL, 0>(u, y, w, ws, neg_p, two_p);
+                        else if constexpr (KIND == 1)
+                            butterflies_fwd_hs<false, kIL, 1>(u, y, w, ws, neg_p, two_p - neg_p);
+                        else if constexpr (KIND == 2)
+                            butterflies_fwd_apx2<false, kIL>(u, y, w, ws, neg_p, four_p, zp.z);
+                        else if constexpr (KIND == 4)
+                            butterflies_inv_apx2<false, kIL>(u, y, w, ws, neg_p, four_p, zp.z);
+                        else
+                            butterflies_inv_hs<false, kIL, 0>(u, y, w, ws, neg_p, two_p);
+#pragma unroll
+                        for (int j = 0; j < kIL; j++)
+                        {
+                            const int sl = (((c + j) >> W) << (W + 1)) | ((c + j) & (bit - 1));
+                            x[sl] = u[j];
+                            x[sl | bit] = y[j];
+                        }
+                    }
+                }
+                if constexpr (FP)
+                    if ((it & 1) == 1) // (one reduction of every value per eight layers: a little more than the real schedule's)
+                    {
+#pragma unroll
+                        for (int i = 0; i < 16; i++)
+                            x[i] = fp_bits(fp_reduce(fp_of(x[i]), fp_of(two_p), fp_of(neg_p)));
+                    }
+            }
+            u64 acc = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                acc ^= x[i];
+            if (acc == 0x0123456789ABCDEFull) // (never: keeps the arithmetic alive)
+                sink[0] = acc;
+        }
+    } // namespace
+
+    hipError_t ntt_butterfly_rate(const Engine &e, int kind, int prime_id, double *butterflies_per_s)
+    {
+        if (kind < 0 || kind > 5 || prime_id < 0 || prime_id >= static_cast<int>(e.tables.size()))
+            return hipErrorInvalidValue;
+        PrimeDev P{};
+        hipError_t err = hipMemcpy(&P, e.d_primes + prime_id, sizeof(P), hipMemcpyDeviceToHost);
+        if (err != hipSuccess)
+            return err;
+        if (kind == 3 && P.fwd_d == nullptr)
+            return hipErrorInvalidValue; // no FP64 instance for this prime
+        u64 *sink = nullptr;
+        if ((err = hipMalloc(&sink, 8)) != hipSuccess)
+            return err;
+        hipStream_t st = e.lane().stream;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        const unsigned blocks = 256u * 2u * 4u; // four rounds of resident workgroups per CU slot
+        const int iters = 800;
+        // the transforms' occupancy: their 68 KB of LDS admit two workgroups (four waves per SIMD) per CU; this kernel uses
+        // none and fewer registers, so it asks for the same amount to run under the same cap
+        const std::size_t lds = static_cast<std::size_t>(hpad(1 << 13)) * 8;
+        const void *fns[6] = { reinterpret_cast<const void *>(&butterfly_rate_kernel<0>), reinterpret_cast<const void *>(&butterfly_rate_kernel<1>),
+                               reinterpret_cast<const void *>(&butterfly_rate_kernel<2>), reinterpret_cast<const void *>(&butterfly_rate_kernel<3>),
+                               reinterpret_cast<const void *>(&butterfly_rate_kernel<4>), reinterpret_cast<const void *>(&butterfly_rate_kernel<5>) };
+        if ((err = hipFuncSetAttribute(fns[kind], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))) != hipSuccess)
+        {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+            (void)hipFree(sink);
+            return err;
+        }
+        const auto launch = [&](int n) {
+            switch (kind)
+            {
+            case 0: butterfly_rate_kernel<0><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            case 1: butterfly_rate_kernel<1><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            case 2: butterfly_rate_kernel<2><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            case 3: butterfly_rate_kernel<3><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            case 4: butterfly_rate_kernel<4><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            default: butterfly_rate_kernel<5><<<blocks, 512, lds, st>>>(sink, P, n); break;
+            }
+        };
+        launch(iters / 8); // warm-up (clocks, code)
+        (void)hipEventRecord(a, st);
+        launch(iters);
+        launch(iters);
+        (void)hipEventRecord(b, st);
+        err = hipStreamSynchronize(st);
+        float ms = 0;
+        if (err == hipSuccess)
+            err = hipEventElapsedTime(&ms, a, b);
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        (void)hipFree(sink);
+        if (err != hipSuccess)
+            return err;
+        *butterflies_per_s = 2.0 * blocks * 512.0 * iters * 32.0 / (ms / 1e3);
+        return hipGetLastError();
     }
 
     hipError_t ntt_init_kernels()

@@ -47,7 +47,12 @@ namespace sealhip
         // ntt_inv_top_kernel; T = log n for the whole-row form, whose layer T - 1 is BackwardLazyLast with n^-1 folded in).
         // Layer l reduces its sum with barrett_lazy (MODE 2, -> [0, 2p)) only for l == r1 and l == T - 1; elsewhere the sum
         // is left as it is (MODE 1). Values entering layer l are below 2^shift(l) * p; the difference operand gets exactly
-        // that bound added so that it stays non-negative. The product is a Shoup product of a 64-bit word: below 2p.
+        // that bound added so that it stays non-negative. The product is a Shoup product of a 64-bit word: below 2p with the
+        // exact quotient (the two reducing layers, and the first f = log n - 13 layers, which run at the register cap), below
+        // kInvLazyProductMult p = 4p with the level-2 quotient (section 2: quotient_shortfall) that every other MODE 1 layer
+        // uses since round 4. A MODE 1 layer's outputs are bounded by its unreduced sum, 2^(shift + 1) p >= 4p, so the
+        // recurrence below takes the maximum of the two and finds the schedule unchanged.
+        constexpr int kInvLazyProductMult = 4;
         constexpr int inv_lazy_r1(int T)
         {
             return (T - 1) / 2;
@@ -76,8 +81,10 @@ namespace sealhip
                 const u128 diff = 2 * claimed;      // u - y + claimed < 2 * claimed
                 peak = sum > peak ? sum : peak;
                 peak = diff > peak ? diff : peak;
-                // outputs: the product is below 2p; the sum is reduced to below 2p (MODE 2) or kept (MODE 1)
-                bound = inv_lazy_mode(T, l) == 2 ? static_cast<u128>(2) * p : sum;
+                // outputs: a reducing layer (MODE 2) leaves sum and product (exact quotient) below 2p; a MODE 1 layer keeps
+                // the sum and may leave its product anywhere below 4p (level-2 quotient)
+                const u128 prod = static_cast<u128>(kInvLazyProductMult) * p;
+                bound = inv_lazy_mode(T, l) == 2 ? static_cast<u128>(2) * p : (sum > prod ? sum : prod);
             }
             return peak;
         }

@@ -52,6 +52,10 @@ namespace sealhip
             const std::size_t budget = workspace_budget_bytes(e);
             std::size_t chunk = budget / (bytes_per_item ? bytes_per_item : 1);
             chunk = std::max<std::size_t>(1, std::min(chunk, count));
+            auto &log = e.lane().chunk_log;
+            if (log.size() >= 64)
+                log.erase(log.begin());
+            log.emplace_back(count, chunk);
             e.ws_reserve(e.lane().ws_floor + chunk * bytes_per_item + static_cast<std::size_t>(n_buffers) * 256);
             return chunk;
         }

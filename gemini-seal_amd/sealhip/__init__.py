@@ -122,6 +122,8 @@ SYMBOLS = {
     "sealhip_evaluator_multiply_plain": [_vp, _u32, _vp, _u32, _sz, _vp, _sz],
     "sealhip_is_transparent": [_vp, _u32, _vp, _u32, _sz, _vp],
     "sealhip_transparency_sink": [_vp, _vp, _sz],
+    "sealhip_debug_butterfly_rate": [_vp, _u32, _u32, _vp],
+    "sealhip_debug_chunk_log": [_vp, _vp, _sz, _vp],
     "sealhip_modulo_poly_coeffs_63": [_vp, _vp, _sz, _u32, _u32, _vp],
     "sealhip_evaluator_rotate_vector": [_vp, _u32, _vp, _sz, _i32, C.POINTER(_u32), C.POINTER(_vp), _u32],
     "sealhip_decryptor_dot_product_ct_sk": [_vp, _u32, _vp, _u32, _sz, _vp, _i32, _vp],
@@ -627,6 +629,19 @@ class Context:
     def kswitch_digits(self, k):
         d = C.c_uint32()
         _check(lib().sealhip_kswitch_digits(self.handle, k, C.byref(d)))
+        return d.value
+
+    def chunk_log(self):
+        """[(batch size, items per arena chunk), ...] of this thread's last operations (sealhip_debug_chunk_log); clears it"""
+        buf = (C.c_size_t * 128)()
+        n = C.c_size_t(0)
+        _check(lib().sealhip_debug_chunk_log(self.handle, buf, 64, C.byref(n)))
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(n.value)]
+
+    def butterfly_rate(self, kind, prime_index=0):
+        """butterflies per second of one butterfly sequence on this device (sealhip_debug_butterfly_rate)"""
+        d = C.c_double(0.0)
+        _check(lib().sealhip_debug_butterfly_rate(self.handle, kind, prime_index, C.byref(d)))
         return d.value
 
     def switch_key_partial(self, k, target, count, key, digit_begin, digit_end, partial):

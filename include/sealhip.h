@@ -112,6 +112,20 @@ long sealhip_profile_fetch(sealhip_context *ctx, char *json, size_t capacity);
    out. Used by the tests to prove that the failure surfaces at every host-visible synchronisation point. */
 long sealhip_debug_ntt_handoff(sealhip_context *ctx, uint32_t spin_limit, int32_t suppress_signal);
 
+/* How the calling thread's last operations walked their batches: operations whose temporaries do not fit the lane's arena for
+   the whole batch process it in chunks of items. Writes up to capacity_pairs (batch size, items per
+   chunk) pairs, oldest first, and clears the log (at most the last 64 operations are kept). bench.py uses it to verify the
+   first and last item of every chunk of the timed batch against the oracle. */
+long sealhip_debug_chunk_log(sealhip_context *ctx, size_t *count_chunk_pairs, size_t capacity_pairs, size_t *written);
+
+/* Measurement hook (bench.py roofline.valu_ceiling): the rate at which this device executes nothing but the butterflies of
+   the single-pass NTT kernels (same instruction sequences, values and twiddles in registers, same launch bounds) on the
+   prime `prime_index` (numbering of sealhip_debug_ntt_table). kind: 0 the reference's lazy forward butterfly
+   (ntt.cpp:245-252, exact Shoup quotient), 1 / 2 the approximate-quotient forms (csrc/ntt_bounds.hpp section 2), 3 the
+   FP64 butterfly (primes below 2^50), 4 / 5 the inverse butterfly (lazy sums with the level-2 quotient / ntt.cpp:265-272).
+   A row of N coefficients is N/2 log2 N butterflies: rate / that = the transform's arithmetic ceiling in rows per second. */
+long sealhip_debug_butterfly_rate(sealhip_context *ctx, uint32_t kind, uint32_t prime_index, double *butterflies_per_s);
+
 /* Introspection of the precomputed tables (works on host-only contexts; used by the CPU tests).
    kind: 0 root_powers, 1 scaled_root_powers, 2 inv_root_powers (reference order, n^-1 merged),
    3 scaled_inv_root_powers; prime_index: 0..n_key-1 key primes, n_key.. = 60-bit auxiliary primes

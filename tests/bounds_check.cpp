@@ -299,6 +299,7 @@ static void fp_forward_execution(int logn, u64 pu, int pattern)
 }
 
 // ---- inverse integer lazy-sum schedule executed on 64-bit words with a 128-bit shadow of every true value
+static u64 quotient_model(u64 y, u64 s, int level);
 static void inv_lazy_execution(int T, u64 p)
 {
     const int n = 1 << T;
@@ -328,9 +329,12 @@ static void inv_lazy_execution(int T, u64 p)
                 if (inv_lazy_mode(T, l) == 2) // barrett_lazy: x - floor(x * floor(2^64 / p) / 2^64) * p
                     s = s - static_cast<u64>((static_cast<u128>(s) * static_cast<u64>(kWord / p)) >> 64) * p;
                 const u64 d = static_cast<u64>(diff);
-                const u64 q = static_cast<u64>((static_cast<u128>(d) * ws) >> 64);
+                // MODE 1 layers: the level-2 quotient (product below 4p); reducing layers: the exact one (below 2p)
+                const u64 q = quotient_model(d, ws, inv_lazy_mode(T, l) == 1 ? 2 : 0);
                 x[j] = s;
-                x[j + gap] = d * w - q * p; // lazy Shoup product, below 2p
+                x[j + gap] = d * w - q * p;
+                wrapped = wrapped || static_cast<u128>(d) * w - static_cast<u128>(q) * p >=
+                                         static_cast<u128>(inv_lazy_mode(T, l) == 1 ? kInvLazyProductMult : 2) * p;
             }
         }
     }
