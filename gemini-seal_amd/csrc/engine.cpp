@@ -60,8 +60,7 @@ namespace sealhip
         e->k_first = n_key - nsp;
         e->t = scheme == 1 ? t : 0;
         e->mode_strict = strict;
-        e->use_half_kernel = std::getenv("SEALHIP_NTT_TWO_PASS") == nullptr;
-        e->unfused_rns = std::getenv("SEALHIP_RNS_UNFUSED") != nullptr;
+        e->use_half_kernel = true;
         e->device = device;
         e->key_moduli.assign(key_moduli, key_moduli + n_key);
         for (int i = 0; i < n_key; i++)

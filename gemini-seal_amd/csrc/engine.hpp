@@ -13,6 +13,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "devmath.hpp"
@@ -69,6 +70,23 @@ namespace sealhip
         } md;
     };
     constexpr unsigned short kSrcReduce = 0x4000, kSrcSecond = 0x8000; // kSrcReduce: informational (rows that need it)
+
+    // A/B knobs (SEALHIP_NTT_NO_TICKET, _GATHER_TICKET, _POLY_MAJOR, _POLY_GROUP, _WHOLE_ROW, _CANON_BARRETT,
+    // SEALHIP_KS_MAC_GROUP, _KS_MODDOWN_UNFUSED, _KS_MODDOWN_STORE_UNFUSED, SEALHIP_LIFT_TOP_OFF) exist in the measurement-only
+    // build (`make exp`, -DSEALHIP_NTT_EXPERIMENT) alone: the shipping library reads none of them, so no environment variable
+    // can re-open a race or switch a proved path off. What the shipping library does read: the resource knobs
+    // SEALHIP_WORKSPACE_MB / SEALHIP_HOST_CHUNK / SEALHIP_HOST_THREADS and the switches that run the REFERENCE'S OWN operation
+    // sequences instead of the proved shortcuts: SEALHIP_NTT_EXACT_FWD, SEALHIP_NTT_EXACT_INV, SEALHIP_NTT_CANON_EXACT,
+    // SEALHIP_NTT_NO_FP64.
+    inline const char *exp_env(const char *name)
+    {
+#ifdef SEALHIP_NTT_EXPERIMENT
+        return std::getenv(name);
+#else
+        (void)name;
+        return nullptr;
+#endif
+    }
 
     constexpr int kNttCanonical = 1; // fuse the canonicalising wrapper (ntt.h:236-245 / :328-333)
     constexpr int kNttStrict = 2;    // Harvey-corrected forward butterflies
@@ -278,8 +296,7 @@ namespace sealhip
         std::size_t n = 0;
         u64 t = 0;
         bool mode_strict = false;
-        bool unfused_rns = false;    // SEALHIP_RNS_UNFUSED=1: step-by-step BEHZ kernels (also used for k > 32)
-        bool use_half_kernel = true; // single-pass forward NTT for logn >= 14 (SEALHIP_NTT_TWO_PASS=1 disables)
+        bool use_half_kernel = true; // single-pass NTT kernels for logn >= 14 (the tiled one-pass kernel serves logn <= 13)
         int device = -1; // -1: host-only
         std::vector<u64> key_moduli, aux_primes;
         std::vector<HostNttTables> tables; // per prime id
@@ -394,7 +411,7 @@ namespace sealhip
     // out[I] = sum_{i1+i2=I} a[i1] (.) b[i2]  over rows of `map` (evaluator.cpp:376-420 / 493-520)
     hipError_t launch_tensor_product(const Engine &e, const u64 *a, int sa, std::size_t a_stride, const u64 *b, int sb,
                                      std::size_t b_stride, u64 *out, std::size_t out_stride, std::size_t count,
-                                     const RowMap &map);
+                                     const RowMap &map, bool square = false);
     hipError_t launch_fill_rows(const Engine &e, u64 *dst, const u64 *row_values, int rows, std::size_t count);
     hipError_t launch_copy_rows(const Engine &e, const u64 *src, std::size_t src_poly_stride, u64 *dst,
                                 std::size_t dst_poly_stride, std::size_t npolys, int rows);

@@ -452,7 +452,7 @@ namespace sealhip
         // (profiles/r02/ks_mac_group.txt: config 4, 69 MB of key: 9.15 -> 7.96 ms per step; config 5, 251 MB: 9.38 -> 7.66;
         // config 3, 29 MB: 3.68 -> 3.60 at 16, but 3.9-4.1 at 32)
         static const std::size_t forced = [] {
-            const char *env = std::getenv("SEALHIP_KS_MAC_GROUP");
+            const char *env = exp_env("SEALHIP_KS_MAC_GROUP"); // (measurement-only build)
             return env ? static_cast<std::size_t>(std::strtoull(env, nullptr, 10)) : std::size_t(0);
         }();
         const std::size_t key_bytes = (2ull * h.nd * (h.k + h.nsp)) << (e.logn + 3);

@@ -6,14 +6,12 @@
 // Shape of the computation: integer, HBM-streaming, ALU-heavy (one Shoup butterfly = one
 // 64x64->hi64 and two 64x64->lo64 products built from v_mad_u64_u32); no MFMA.
 //
-// Decomposition: a row of N = 2^logn coefficients is transformed in one pass (logn <= 13) or two
-// passes. A pass gives each workgroup a TILE of 2^t coefficients that is closed under the
-// butterflies of the pass: the tile is staged HBM -> LDS with 16-byte coalesced loads, then the
-// threads run register-resident radix-16 rounds (16 coefficients = 4 index bits per thread, up to
-// 4 butterfly layers per LDS round trip), and the tile is stored back with 16-byte coalesced
-// stores. The two-pass split for logn > 13 is the classic "strided columns, then contiguous rows":
-//   strided pass   : tile = {top active bits} x {2^c contiguous coefficients}, global bits [b_lo, logn)
-//   contiguous pass: tile = 2^t contiguous coefficients, global bits [0, b_lo)
+// Decomposition: a row of N = 2^logn coefficients is transformed in ONE launch: for logn <= 13 by the
+// tiled kernel (ntt_pass_kernel: the row is a TILE of 2^t coefficients staged HBM -> LDS with 16-byte
+// coalesced loads, the threads run register-resident radix-16 rounds -- 16 coefficients = 4 index bits per
+// thread, up to 4 butterfly layers per LDS round trip -- and the tile is stored back with 16-byte coalesced
+// stores), for logn 14..16 by the single-pass half-row kernels further down. (The two-launch "strided
+// columns, then contiguous rows" split of round 1 for logn > 13 was removed in round 4 with its switch.)
 // Bit-exactness: every butterfly is exactly the reference's radix-2 lazy butterfly,
 // only the schedule differs, so the 64-bit words (including the wrap-around behaviour for 60-bit
 // primes) are identical. Twiddle of the butterfly on global bit b whose lower element
@@ -2167,7 +2165,7 @@ namespace sealhip
                     // whole-row form (see the kernel): standalone floating-point transforms (the top layer is not left to a
                     // consumer). Bit log n of SEALHIP_NTT_WHOLE_ROW (default: 2^14 and 2^15).
                     static const unsigned long whole_mask = [] {
-                        const char *env = std::getenv("SEALHIP_NTT_WHOLE_ROW");
+                        const char *env = exp_env("SEALHIP_NTT_WHOLE_ROW");
                         return env ? std::strtoul(env, nullptr, 0) : ((1ul << 14) | (1ul << 15));
                     }();
                     if (!dyadic && !(flags & kNttDeferTop) && ((whole_mask >> LOGN) & 1))
@@ -2258,15 +2256,16 @@ namespace sealhip
             const std::size_t blocks = chunk * 16;
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
-            // SEALHIP_NTT_NO_TICKET=1 is a measurement-only switch (A/B of the hand-off cost); it re-opens the race
-            static const bool no_ticket = std::getenv("SEALHIP_NTT_NO_TICKET") != nullptr;
+            // SEALHIP_NTT_NO_TICKET=1 (A/B of the hand-off cost) re-opens the race: read by the measurement-only build alone
+            // (engine.hpp exp_env); in the shipping library this is the constant false
+            static const bool no_ticket = exp_env("SEALHIP_NTT_NO_TICKET") != nullptr;
             // (kNttTopDone: no workgroup reads the other's half, nothing to hand off)
             const bool top_done = (flags & kNttTopDone) != 0;
             if (top_done && ((flags & (kNttReduceOut | kNttStrict | kNttCanonical)) != kNttReduceOut || src.base[0]))
                 return hipErrorInvalidValue;
             // a launch whose live rows are all gathered from another buffer writes no row that anybody reads: nothing to
             // hand off either (SEALHIP_NTT_GATHER_TICKET=1 keeps the hand-off, for A/B)
-            static const bool gather_ticket = std::getenv("SEALHIP_NTT_GATHER_TICKET") != nullptr;
+            static const bool gather_ticket = exp_env("SEALHIP_NTT_GATHER_TICKET") != nullptr;
             bool all_gathered = src.base[0] != nullptr && !gather_ticket;
             for (int i = 0; all_gathered && i < live.n; i++)
                 all_gathered = src.code[live.slot[i]] != kSkipRow;
@@ -2277,7 +2276,7 @@ namespace sealhip
             {
                 // (see half_block_map): bit 0 = FP64 digit launches, bit 1 = integer ones
                 static const int poly_major = [] {
-                    const char *env = std::getenv("SEALHIP_NTT_POLY_MAJOR");
+                    const char *env = exp_env("SEALHIP_NTT_POLY_MAJOR");
                     return env ? std::atoi(env) : 2;
                 }();
                 bool one_source = poly_major && all_gathered && src.reduce_mode <= 2 && live.n > 1;
@@ -2339,8 +2338,8 @@ namespace sealhip
             }
             if (flags & kNttPolyMajorRequest)
             {
-                static const int poly_major = std::getenv("SEALHIP_NTT_POLY_MAJOR") ? std::atoi(std::getenv("SEALHIP_NTT_POLY_MAJOR")) : 2;
-                static const int group = std::getenv("SEALHIP_NTT_POLY_GROUP") ? std::atoi(std::getenv("SEALHIP_NTT_POLY_GROUP")) : 4;
+                static const int poly_major = exp_env("SEALHIP_NTT_POLY_MAJOR") ? std::atoi(exp_env("SEALHIP_NTT_POLY_MAJOR")) : 2;
+                static const int group = exp_env("SEALHIP_NTT_POLY_GROUP") ? std::atoi(exp_env("SEALHIP_NTT_POLY_GROUP")) : 4;
                 flags &= ~kNttPolyMajorRequest;
                 if (poly_major & (fp ? 1 : 2))
                 {
@@ -2393,7 +2392,7 @@ namespace sealhip
             {
                 apx = true;
                 flags |= kNttAnyRep;
-                bool sq = std::getenv("SEALHIP_NTT_CANON_BARRETT") == nullptr; // (A/B: the Barrett step of round 3)
+                bool sq = exp_env("SEALHIP_NTT_CANON_BARRETT") == nullptr; // (A/B: the Barrett step of round 3)
                 for (int i = 0; sq && i < live.n; i++)
                     sq = bounds::small_quot_admits(e.tables[map.prime[live.slot[i]]].p, bounds::fwd_canon_output_mult(LOGN));
                 if (sq)
@@ -2590,23 +2589,12 @@ namespace sealhip
             ps.flags = flags & kNttStrict;
             make_rounds(ps, lo, hi, inverse);
         };
-        if (logn <= kTileBitsMax)
-        {
-            plan.npass = 1;
-            init(plan.pass[0], logn, 0, 0, 0, logn - 1);
-        }
-        else
-        {
-            const int cbits = (logn + 1) / 2; // contiguous pass: global bits [0, cbits)
-            const int sbits = logn - cbits;   // strided pass:    global bits [cbits, logn)
-            const int t = kTileBitsMax;
-            NttPass strided{}, contiguous{};
-            init(strided, t, t - sbits, cbits, t - sbits, t - 1);
-            init(contiguous, t, 0, 0, 0, cbits - 1);
-            plan.npass = 2;
-            plan.pass[0] = inverse ? contiguous : strided;
-            plan.pass[1] = inverse ? strided : contiguous;
-        }
+        // (round 4: the two-pass split for logn > 13 -- strided columns, then contiguous rows -- went with its switch
+        //  SEALHIP_NTT_TWO_PASS: rings of 2^14 .. 2^16 are served by the single-pass kernels below, nothing else reached it)
+        if (logn > kTileBitsMax)
+            throw std::logic_error("plan_ntt: rings above 2^13 take the single-pass kernels");
+        plan.npass = 1;
+        init(plan.pass[0], logn, 0, 0, 0, logn - 1);
         plan.pass[plan.npass - 1].flags |= flags & kNttCanonical; // wrapper fused into the last store
         return plan;
     }
@@ -2816,12 +2804,12 @@ namespace sealhip
 
     bool ntt_can_defer_top(const Engine &e, int k)
     {
-        return e.use_half_kernel && e.logn >= 14 && e.logn <= 16 && k <= 32 && !e.unfused_rns;
+        return e.use_half_kernel && e.logn >= 14 && e.logn <= 16 && k <= 32;
     }
 
     bool ntt_can_fuse_moddown(const Engine &e, int k, u64 p_special)
     {
-        static const bool off = std::getenv("SEALHIP_KS_MODDOWN_STORE_UNFUSED") != nullptr;
+        static const bool off = exp_env("SEALHIP_KS_MODDOWN_STORE_UNFUSED") != nullptr;
         if (off || !fp64_enabled() || !ntt_can_gather(e) || e.logn < 15 || (SEALHIP_NTT_STORE_EXCHANGE & 1) == 0 ||
             p_special >= kFpPrimeBound)
             return false;

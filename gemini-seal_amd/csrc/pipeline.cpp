@@ -261,7 +261,7 @@ namespace sealhip
                       "mac");
             if (partial)
                 continue; // the reduced partial products leave here (all-reduce, then op_switch_key with partial_sum)
-            if (!ckks && !e.unfused_rns)
+            if (!ckks)
             {
                 // BFV: every row of both products goes back to coefficient form in one launch (the reference does the
                 // special rows first, :2351-2355, and the others inside rescale_special_rns_inplace, :286-289 -- the
@@ -278,7 +278,7 @@ namespace sealhip
             // The gathered transform is handed the integer P - r < P instead of the residue (-(s mod P)) mod q_i: the same
             // word wherever P <= q_i; where q_i < P < 2 q_i it is an unreduced input below 2 q_i, which the lazy forward
             // transform takes as it is only while nothing can wrap (ntt_bounds.hpp section 2, inputs below 2p).
-            bool fold_ok = ckks && e.nsp == 1 && ntt_can_gather(e) && std::getenv("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
+            bool fold_ok = ckks && e.nsp == 1 && ntt_can_gather(e) && exp_env("SEALHIP_KS_MODDOWN_UNFUSED") == nullptr;
             for (int r = 0; fold_ok && r < k; r++)
             {
                 const u64 q = e.key_moduli[h.row_prime[r]];
@@ -419,8 +419,7 @@ namespace sealhip
             // With the single-pass kernels and two size-2 operands the tensor product (step 4) is formed by the inverse
             // NTT while it loads its rows (no separate pass over 7 rows per prime; launch_intt_tensor)
             const bool defer = ntt_can_defer_top(e, k);
-            bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows &&
-                                std::getenv("SEALHIP_TENSOR_UNFUSED") == nullptr;
+            bool fused_tensor = gather && defer && sa == 2 && sb == 2 && dest * kb <= kMaxRows;
             // its Montgomery reduction lands below 2p on operands below 4p for ciphertext primes under 2^59 (the exact forward
             // sequence), on operands below (2 + g) p -- what an approximate-quotient launch without kNttAnyRep stores --
             // for primes under 2^57 (ntt_bounds.hpp section 3: tensor_admits_apx); the Bsk rows are stored below 2p
@@ -512,7 +511,7 @@ namespace sealhip
             // step (4) (:376-420)
             // (square: both operands are the same two transformed polynomials; the kernel then forms x_0 x_1 once and adds it
             //  to itself, :650-651)
-            check(launch_tensor_product(e, X, sa, w_x, sq ? X : X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk), "tensor");
+            check(launch_tensor_product(e, X, sa, w_x, sq ? X : X + sa * poly_x, sb, w_x, D, w_d, m, lt.map_qbsk, sq), "tensor");
             // step (5) (:423-424); with the single-pass kernels the top inverse layer and the canonicalisation are
             // applied by the consumer while it loads (saves one read+write pass over D)
             if (defer)
@@ -546,11 +545,18 @@ namespace sealhip
         op_bfv_multiply(e, k, a, 2, nullptr, 2, count, out);
     }
 
-    // ckks_square (evaluator.cpp:704-770): size != 2 -> ckks_multiply (:720-724); else the tensor kernel's square form
-    // (a == b: x_0^2, x_0 x_1 + x_0 x_1, x_1^2 -- five row passes per prime instead of seven)
+    // ckks_square (evaluator.cpp:704-770) is its own path, like bfv_square: a size-2 operand goes through the tensor
+    // kernel's square form -- c_0 = x_0^2, c_1 = x_0 x_1 added to itself (:752-758), c_2 = x_1^2: two polynomials read and
+    // three written (five row passes per prime instead of seven), three products per coefficient instead of four; other
+    // sizes go through ckks_multiply like the reference (:720-724). Parity: ref_ckks_square (oracle/sealref.c).
     void op_ckks_square(Engine &e, int k, const u64 *a, int sa, std::size_t count, u64 *out)
     {
-        op_ckks_multiply(e, k, a, sa, a, sa, count, out);
+        if (sa != 2)
+            return op_ckks_multiply(e, k, a, sa, a, sa, count, out);
+        LevelTools &lt = e.level(k);
+        const std::size_t poly = static_cast<std::size_t>(k) * e.n;
+        SinkArm arm(e, sink_at(e, 0));
+        check(launch_tensor_product(e, a, 2, 2 * poly, a, 2, 2 * poly, out, 3 * poly, count, lt.map_q, true), "tensor (square)");
     }
 
     // ckks_multiply (evaluator.cpp:447-527)

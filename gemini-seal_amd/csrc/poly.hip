@@ -64,7 +64,7 @@ namespace sealhip
         __global__ __launch_bounds__(kThreads) void tensor_product_kernel(
             const u64 *__restrict__ a, int sa, std::size_t a_stride, const u64 *__restrict__ b, int sb,
             std::size_t b_stride, u64 *__restrict__ out, std::size_t out_stride, const PrimeDev *__restrict__ primes,
-            RowMap map, int logn, std::size_t npairs_per_item, std::size_t count, unsigned *__restrict__ tflags)
+            RowMap map, int logn, std::size_t npairs_per_item, std::size_t count, unsigned *__restrict__ tflags, int square)
         {
             const std::size_t total = npairs_per_item * count;
             const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
@@ -78,9 +78,10 @@ namespace sealhip
                 const u64 *pa = a + item * a_stride + off;
                 const u64 *pb = b + item * b_stride + off;
                 u64 *po = out + item * out_stride + off;
-                if (sa == 2 && sb == 2 && a == b)
+                if (square)
                 {
-                    // Evaluator::square (evaluator.cpp:644-657, :752-760): x_0^2, x_0 x_1 added to itself, x_1^2
+                    // Evaluator::square on a size-2 operand (bfv_square evaluator.cpp:644-657, ckks_square :752-760): x_0^2, x_0 x_1
+                    // added to itself, x_1^2 -- two polynomials read instead of four, three products instead of four
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(pa);
                     const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(pa + poly_words);
                     ulonglong2 c0, c1, c2;
@@ -389,14 +390,17 @@ namespace sealhip
 
     hipError_t launch_tensor_product(const Engine &e, const u64 *a, int sa, std::size_t a_stride, const u64 *b, int sb,
                                      std::size_t b_stride, u64 *out, std::size_t out_stride, std::size_t count,
-                                     const RowMap &map)
+                                     const RowMap &map, bool square)
     {
+        if (square && (sa != 2 || sb != 2 || a != b))
+            return hipErrorInvalidValue; // the square form is that of ONE size-2 operand
         const std::size_t pairs = (static_cast<std::size_t>(map.rows) << e.logn) / 2;
         if (pairs * count == 0)
             return hipSuccess;
         ProfScope prof(e, "tensor_product", 0);
         tensor_product_kernel<<<grid_for(pairs * count), kThreads, 0, e.lane().stream>>>(
-            a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count, e.lane().tsink_arm);
+            a, sa, a_stride, b, sb, b_stride, out, out_stride, e.d_primes, map, e.logn, pairs, count, e.lane().tsink_arm,
+            square ? 1 : 0);
         return hipGetLastError();
     }
 

@@ -854,8 +854,8 @@ namespace sealhip
 
     bool bfv_lift_can_apply_top(const Engine &e, const RnsDev &h)
     {
-        static const bool off = std::getenv("SEALHIP_LIFT_TOP_OFF") != nullptr;
-        return !off && !e.unfused_rns && !e.mode_strict && h.redc_small && h.k >= 1 && h.k <= 16 && e.logn >= 14;
+        static const bool off = exp_env("SEALHIP_LIFT_TOP_OFF") != nullptr; // (measurement-only build)
+        return !off && !e.mode_strict && h.redc_small && h.k >= 1 && h.k <= 16 && e.logn >= 14;
     }
 
     hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
@@ -867,7 +867,7 @@ namespace sealhip
             return hipErrorInvalidValue;
         const unsigned grid = blocks_for(count, top_layer ? e.logn - 1 : e.logn);
         ProfScope prof(e, "bfv_lift", 0);
-        if (h.k <= 32 && !e.unfused_rns)
+        if (h.k <= 32)
         {
 #define SEALHIP_LIFT2(KM) lift2_launch<KM>(e, d, in, in_stride, out, out_stride, count, grid, top_layer)
             switch (h.redc_small ? h.k : 0)
@@ -931,7 +931,7 @@ namespace sealhip
         // notes non-zero words as it stores them; the step-by-step kernels are followed by the read pass instead
         unsigned *tflags = e.lane().tsink_arm;
         ProfScope prof(e, "bfv_floor_sk", 0);
-        if (h.k <= 32 && !e.unfused_rns)
+        if (h.k <= 32)
         {
 #define SEALHIP_FLOOR2(KM)                                                                                          \
     do                                                                                                               \

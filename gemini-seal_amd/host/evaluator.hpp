@@ -2,8 +2,10 @@
 //
 // seal::Evaluator is non-virtual and non-copyable (native/src/seal/evaluator.h:1316-1322), so this is not a
 // subclass: it is a class with the same method names and argument meaning for the hot-path operations
-// (evaluator.h:246-298 multiply/square, :344-371 relinearize, :396-430 mod_switch_to_next, :565-583
-// rescale_to_next, :902-947 transform_to/from_ntt, :984-1021 apply_galois, :1201-1239 rotate_vector), doing
+// (evaluator.h:246-298 multiply/square, :344-371 relinearize, :396-430 mod_switch_to_next, :479-502 mod_switch_to, :565-583
+// rescale_to_next, :606-629 rescale_to, :183 add_many, :902-947 transform_to/from_ntt, :984-1021 apply_galois, :1057-1103
+// rotate_rows, :1131-1173 rotate_columns, :1201-1239 rotate_vector, :1269-1308 complex_conjugate, and every
+// destination-taking variant), doing
 // the same metadata checks on the host and forwarding raw pointers to the ABI. It is a template over the
 // ciphertext type so that it compiles both against seal::Ciphertext (where the reference headers exist) and
 // against the plain sealhip::HostCiphertext below (everywhere else, e.g. the GPU box).
@@ -225,8 +227,15 @@ namespace sealhip_host
             c.down(encrypted.data(), 2 * k * n);
         }
 
-        // Evaluator::rotate_vector_inplace / rotate_rows_inplace -> rotate_internal (evaluator.cpp:1945-2000)
+        // Evaluator::rotate_vector_inplace (evaluator.h:1201-1211): CKKS only, then rotate_internal
         void rotate_vector_inplace(CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (ctx_.scheme() != SEALHIP_SCHEME_CKKS)
+                throw std::logic_error("unsupported scheme"); // :1205-1208
+            rotate_vector_like(encrypted, steps, galois_keys);
+        }
+        // rotate_internal (evaluator.cpp:1945-2000): one automorphism when its key is present, else the NAF of the step count
+        void rotate_vector_like(CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
         {
             if (steps == 0)
                 return;
@@ -249,7 +258,168 @@ namespace sealhip_host
                 throw std::invalid_argument("Galois key not present"); // :1985-1988
             for (int s : naf)
                 if (std::size_t(s < 0 ? -s : s) != (ctx_.n() >> 1))
-                    rotate_vector_inplace(encrypted, s, galois_keys);
+                    rotate_vector_like(encrypted, s, galois_keys);
+        }
+
+        // Evaluator::rotate_rows_inplace (evaluator.h:1057-1067): BFV only, then rotate_internal like rotate_vector
+        void rotate_rows_inplace(CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (ctx_.scheme() != SEALHIP_SCHEME_BFV)
+                throw std::logic_error("unsupported scheme"); // :1061-1064
+            rotate_vector_like(encrypted, steps, galois_keys);
+        }
+        // Evaluator::rotate_columns_inplace (evaluator.h:1131-1139): BFV only; conjugate_internal = apply_galois with
+        // get_elt_from_step(0) = 2N - 1 (:1343-1363)
+        void rotate_columns_inplace(CT &encrypted, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (ctx_.scheme() != SEALHIP_SCHEME_BFV)
+                throw std::logic_error("unsupported scheme"); // :1134-1137
+            conjugate_internal(encrypted, galois_keys);
+        }
+        // Evaluator::complex_conjugate_inplace (evaluator.h:1269-1277): CKKS only, the same automorphism
+        void complex_conjugate_inplace(CT &encrypted, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            if (ctx_.scheme() != SEALHIP_SCHEME_CKKS)
+                throw std::logic_error("unsupported scheme"); // :1272-1275
+            conjugate_internal(encrypted, galois_keys);
+        }
+
+        // Evaluator::mod_switch_to_inplace (evaluator.cpp:1038-1060) / rescale_to_inplace (:1128-1165). The ABI names a level by
+        // its number of primes k (the chain drops one prime per level, context.cpp:423-431); for seal::Ciphertext the
+        // binding maps the parms_id argument to it.
+        void mod_switch_to_inplace(CT &encrypted, std::size_t target_coeff_modulus_size)
+        {
+            if (target_coeff_modulus_size < 1)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters"); // :1047-1050
+            if (encrypted.coeff_modulus_size() < target_coeff_modulus_size)
+                throw std::invalid_argument("cannot switch to higher level modulus"); // :1051-1054
+            while (encrypted.coeff_modulus_size() != target_coeff_modulus_size)
+                mod_switch_to_next_inplace(encrypted); // :1056-1059
+        }
+        void rescale_to_inplace(CT &encrypted, std::size_t target_coeff_modulus_size)
+        {
+            if (target_coeff_modulus_size < 1)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters"); // :1137-1140
+            if (encrypted.coeff_modulus_size() < target_coeff_modulus_size)
+                throw std::invalid_argument("cannot switch to higher level modulus"); // :1141-1144
+            if (ctx_.scheme() != SEALHIP_SCHEME_CKKS)
+                throw std::invalid_argument("unsupported operation for scheme type"); // :1146-1162
+            while (encrypted.coeff_modulus_size() != target_coeff_modulus_size)
+                rescale_to_next_inplace(encrypted);
+        }
+        // Evaluator::add_many (evaluator.cpp:153-172)
+        void add_many(const std::vector<CT> &encrypteds, CT &destination)
+        {
+            if (encrypteds.empty())
+                throw std::invalid_argument("encrypteds cannot be empty"); // :155-158
+            for (const CT &c : encrypteds)
+                if (&c == &destination)
+                    throw std::invalid_argument("encrypteds must be different from destination"); // :159-165
+            destination = encrypteds[0];
+            for (std::size_t i = 1; i < encrypteds.size(); i++)
+                add_inplace(destination, encrypteds[i]);
+        }
+
+        // ---- destination-taking variants (evaluator.h:121-126, :156-168, :214-226, :268-284, :317-322, :371-376, :396-430,
+        // :565-583, :916-947, :1021-1027, :1097-1103, :1167-1173, :1239-1245, :1302-1308): copy, then the in-place form
+        void negate(const CT &encrypted, CT &destination) { destination = encrypted; negate_inplace(destination); }
+        void add(const CT &encrypted1, const CT &encrypted2, CT &destination)
+        {
+            if (&encrypted2 == &destination) // (:160-163: addition commutes, the alias is kept valid)
+                add_inplace(destination, encrypted1);
+            else
+            {
+                destination = encrypted1;
+                add_inplace(destination, encrypted2);
+            }
+        }
+        void sub(const CT &encrypted1, const CT &encrypted2, CT &destination)
+        {
+            if (&encrypted2 == &destination) // :216-222: destination = -(encrypted2 - encrypted1)
+            {
+                sub_inplace(destination, encrypted1);
+                negate_inplace(destination);
+            }
+            else
+            {
+                destination = encrypted1;
+                sub_inplace(destination, encrypted2);
+            }
+        }
+        void multiply(const CT &encrypted1, const CT &encrypted2, CT &destination)
+        {
+            if (&encrypted2 == &destination) // :272-275
+                multiply_inplace(destination, encrypted1);
+            else
+            {
+                destination = encrypted1;
+                multiply_inplace(destination, encrypted2);
+            }
+        }
+        void square(const CT &encrypted, CT &destination) { destination = encrypted; square_inplace(destination); }
+        void relinearize(const CT &encrypted, const std::vector<const KSwitchKeys *> &relin_keys, CT &destination)
+        {
+            destination = encrypted;
+            relinearize_inplace(destination, relin_keys);
+        }
+        void mod_switch_to_next(const CT &encrypted, CT &destination) { destination = encrypted; mod_switch_to_next_inplace(destination); }
+        void rescale_to_next(const CT &encrypted, CT &destination) { destination = encrypted; rescale_to_next_inplace(destination); }
+        void mod_switch_to(const CT &encrypted, std::size_t target_coeff_modulus_size, CT &destination)
+        {
+            destination = encrypted;
+            mod_switch_to_inplace(destination, target_coeff_modulus_size);
+        }
+        void rescale_to(const CT &encrypted, std::size_t target_coeff_modulus_size, CT &destination)
+        {
+            destination = encrypted;
+            rescale_to_inplace(destination, target_coeff_modulus_size);
+        }
+        void transform_to_ntt(const CT &encrypted, CT &destination_ntt) { destination_ntt = encrypted; transform_to_ntt_inplace(destination_ntt); }
+        void transform_from_ntt(const CT &encrypted_ntt, CT &destination) { destination = encrypted_ntt; transform_from_ntt_inplace(destination); }
+        void apply_galois(const CT &encrypted, std::uint32_t galois_elt, const KSwitchKeys &galois_key, CT &destination)
+        {
+            destination = encrypted;
+            apply_galois_inplace(destination, galois_elt, galois_key);
+        }
+        void rotate_vector(const CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys, CT &destination)
+        {
+            destination = encrypted;
+            rotate_vector_inplace(destination, steps, galois_keys);
+        }
+        void rotate_rows(const CT &encrypted, int steps, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys, CT &destination)
+        {
+            destination = encrypted;
+            rotate_rows_inplace(destination, steps, galois_keys);
+        }
+        void rotate_columns(const CT &encrypted, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys, CT &destination)
+        {
+            destination = encrypted;
+            rotate_columns_inplace(destination, galois_keys);
+        }
+        void complex_conjugate(const CT &encrypted, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys, CT &destination)
+        {
+            destination = encrypted;
+            complex_conjugate_inplace(destination, galois_keys);
+        }
+        void multiply_plain(const CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form, CT &destination)
+        {
+            destination = encrypted;
+            multiply_plain_inplace(destination, plain, plain_is_ntt_form);
+        }
+        void add_plain(const CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form, CT &destination)
+        {
+            destination = encrypted;
+            add_plain_inplace(destination, plain, plain_is_ntt_form);
+        }
+        void sub_plain(const CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form, CT &destination)
+        {
+            destination = encrypted;
+            sub_plain_inplace(destination, plain, plain_is_ntt_form);
+        }
+        void exponentiate(const CT &encrypted, std::uint64_t exponent, const std::vector<const KSwitchKeys *> &relin_keys, CT &destination)
+        {
+            destination = encrypted; // :719-726
+            exponentiate_inplace(destination, exponent, relin_keys);
         }
 
         // Evaluator::multiply_many (evaluator.cpp:1180-1255): destination = product of all, relinearized after every step
@@ -412,6 +582,16 @@ namespace sealhip_host
         }
 
     private:
+        // conjugate_internal (evaluator.h:1343-1363): the automorphism x -> x^(2N-1), i.e. get_elt_from_step(0)
+        void conjugate_internal(CT &encrypted, const std::map<std::uint32_t, const KSwitchKeys *> &galois_keys)
+        {
+            std::uint32_t elt = 0;
+            throw_on(sealhip_galois_elt_from_step(ctx_.get(), 0, &elt));
+            auto it = galois_keys.find(elt);
+            if (it == galois_keys.end() || !it->second)
+                throw std::invalid_argument("Galois key not present"); // evaluator.cpp:1871-1874
+            apply_galois_inplace(encrypted, elt, *it->second);
+        }
         void plain_linear(CT &encrypted, const std::uint64_t *plain, bool plain_is_ntt_form, bool sub)
         {
             if (ctx_.scheme() == SEALHIP_SCHEME_BFV && encrypted.is_ntt_form())

@@ -144,6 +144,117 @@ int main(int argc, char **argv)
             if (!many_ok)
                 return 1;
         }
+        // Round 4: the rest of f1's names. BFV rotate_rows / rotate_columns on `b` (coefficient form) with
+        // the key buffer above standing in for the Galois keys of both elements; digests compared by the Python test with
+        // the oracle's apply_galois on the same words. Destination-taking variants, add_many, mod_switch_to.
+        {
+            const auto digest = [](const HostCiphertext &ct) {
+                std::uint64_t hh = 0xcbf29ce484222325ULL;
+                for (std::uint64_t w : ct.words)
+                    for (int i = 0; i < 8; i++)
+                    {
+                        hh ^= (w >> (8 * i)) & 0xff;
+                        hh *= 0x100000001b3ULL;
+                    }
+                return (unsigned long long)hh;
+            };
+            std::uint32_t e1 = 0, ec = 0;
+            throw_on(sealhip_galois_elt_from_step(ctx.get(), 1, &e1));
+            throw_on(sealhip_galois_elt_from_step(ctx.get(), 0, &ec));
+            const std::map<std::uint32_t, const KSwitchKeys *> gks{ { e1, &rk }, { ec, &rk } };
+            HostCiphertext rr, rc, rr2 = b;
+            ev.rotate_rows(b, 1, gks, rr);
+            ev.rotate_columns(b, gks, rc);
+            ev.rotate_rows_inplace(rr2, 1, gks);
+            std::printf("rotate_rows digest %016llx\n", digest(rr));
+            std::printf("rotate_columns digest %016llx\n", digest(rc));
+            bool names_ok = rr2.words == rr.words && rr.words != b.words && rc.words != b.words;
+            // wrong scheme -> std::logic_error (evaluator.h:1205-1208, :1272-1275)
+            int logic = 0;
+            try { HostCiphertext t = b; ev.rotate_vector_inplace(t, 1, gks); } catch (const std::logic_error &) { logic++; }
+            try { HostCiphertext t = b; ev.complex_conjugate_inplace(t, gks); } catch (const std::logic_error &) { logic++; }
+            // a missing key -> std::invalid_argument (evaluator.cpp:1871-1874)
+            try { HostCiphertext t = b; ev.rotate_columns_inplace(t, { { e1, &rk } }); } catch (const std::invalid_argument &) { logic++; }
+            names_ok = names_ok && logic == 3;
+            // destination variants == in-place forms; aliasing of the second operand as the reference handles it
+            HostCiphertext s1, s2 = b, d1, n1, m1, m2 = a;   // a is the level-1 result of the chain above: use fresh copies
+            HostCiphertext x = b, y = b;
+            y.words[1] = (y.words[1] + 5) % mods[0];
+            ev.add(x, y, s1);
+            HostCiphertext s3 = y;
+            ev.add(x, s3, s3); // destination aliases encrypted2
+            HostCiphertext want = x;
+            ev.add_inplace(want, y);
+            names_ok = names_ok && s1.words == want.words && s3.words == want.words;
+            ev.sub(x, y, d1);
+            HostCiphertext d3 = y;
+            ev.sub(x, d3, d3);
+            want = x;
+            ev.sub_inplace(want, y);
+            names_ok = names_ok && d1.words == want.words && d3.words == want.words;
+            ev.negate(x, n1);
+            want = x;
+            ev.negate_inplace(want);
+            names_ok = names_ok && n1.words == want.words;
+            ev.multiply(x, y, m1);
+            want = x;
+            ev.multiply_inplace(want, y);
+            names_ok = names_ok && m1.words == want.words && m1.size() == 3;
+            HostCiphertext rl, ms, ms2, sqd;
+            ev.relinearize(m1, { &rk }, rl);
+            ev.mod_switch_to_next(rl, ms);
+            ev.mod_switch_to(rl, 1, ms2); // level k = 2 -> 1: one step
+            ev.square(x, sqd);
+            HostCiphertext sq_want = x;
+            ev.square_inplace(sq_want);
+            names_ok = names_ok && rl.size() == 2 && ms.words == ms2.words && ms.coeff_modulus_size() == 1 && sqd.words == sq_want.words;
+            bool higher = false;
+            try { ev.mod_switch_to_inplace(ms, 2); } catch (const std::invalid_argument &) { higher = true; } // :1051-1054
+            HostCiphertext am, am_want = x;
+            ev.add_many({ x, y, x }, am);
+            ev.add_inplace(am_want, y);
+            ev.add_inplace(am_want, x);
+            names_ok = names_ok && higher && am.words == am_want.words;
+            std::printf("f1 names %s\n", names_ok ? "ok" : "FAILED");
+            if (!names_ok)
+                return 1;
+        }
+        // CKKS: complex_conjugate / rotate_vector / rescale_to through the adapter, same moduli, NTT-form words
+        {
+            sealhip_params pc{ SEALHIP_SCHEME_CKKS, 12, 3, 1, mods, 0, SEALHIP_MODE_PARITY, p.device };
+            Context cctx(pc);
+            Evaluator<HostCiphertext> cev(cctx);
+            KSwitchKeys gk(cctx, key.data(), 2);
+            std::uint32_t e1 = 0, ec = 0;
+            throw_on(sealhip_galois_elt_from_step(cctx.get(), 1, &e1));
+            throw_on(sealhip_galois_elt_from_step(cctx.get(), 0, &ec));
+            const std::map<std::uint32_t, const KSwitchKeys *> gks{ { e1, &gk }, { ec, &gk } };
+            HostCiphertext x = b, cj, rv, rs, rs2;
+            x.is_ntt_form() = true;
+            cev.complex_conjugate(x, gks, cj);
+            cev.rotate_vector(x, 1, gks, rv);
+            cev.rescale_to_next(x, rs);
+            cev.rescale_to(x, 1, rs2);
+            const auto digest = [](const HostCiphertext &ct) {
+                std::uint64_t hh = 0xcbf29ce484222325ULL;
+                for (std::uint64_t w : ct.words)
+                    for (int i = 0; i < 8; i++)
+                    {
+                        hh ^= (w >> (8 * i)) & 0xff;
+                        hh *= 0x100000001b3ULL;
+                    }
+                return (unsigned long long)hh;
+            };
+            std::printf("complex_conjugate digest %016llx\n", digest(cj));
+            std::printf("rotate_vector digest %016llx\n", digest(rv));
+            int logic = 0;
+            try { HostCiphertext t = x; cev.rotate_rows_inplace(t, 1, gks); } catch (const std::logic_error &) { logic++; }
+            try { HostCiphertext t = x; cev.rotate_columns_inplace(t, gks); } catch (const std::logic_error &) { logic++; }
+            const bool ckks_ok = logic == 2 && rs.words == rs2.words && rs.coeff_modulus_size() == 1;
+            std::printf("ckks names %s\n", ckks_ok ? "ok" : "FAILED");
+            if (!ckks_ok)
+                return 1;
+        }
     }
     catch (const std::exception &e)
     {

@@ -612,6 +612,20 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
     # the batch overloads: 11 separately allocated ciphertexts through the pointer-array entry in chunks of 4
     assert "host batch ok" in out.stdout, out.stdout
     assert "multiply_many ok" in out.stdout, out.stdout
+    # round 4: rotate_rows / rotate_columns (BFV), complex_conjugate / rotate_vector (CKKS), the destination-taking
+    # variants, add_many, mod_switch_to / rescale_to -- the automorphisms against the oracle's apply_galois on the same words
+    # (evaluator.h:1057-1308; evaluator.cpp:1841-1943), the rest against the in-place forms inside the check
+    assert "f1 names ok" in out.stdout and "ckks names ok" in out.stdout, out.stdout
+    row = [r for r in DIG["end_to_end"] if r["cfg"] == 1][0]
+    inp = synth.end_to_end_inputs(row)
+    n, k = inp["n"], inp["k"]
+    for scheme, names in ((1, ("rotate_rows", "rotate_columns")), (2, ("rotate_vector", "complex_conjugate"))):
+        ref = O.RefContext(scheme, inp["logn"], inp["kmods"], nsp=1, t=row["t"] if scheme == 1 else 0)
+        for name, step in zip(names, (1, 0)):
+            c = inp["b"].copy()
+            elt = L.ref_galois_elt_from_step(n, step, None)
+            assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(c), elt, O.ptr(inp["rk"])) == 0
+            assert "%s digest %s" % (name, h(c)) in out.stdout, (name, out.stdout)
 
 
 @pytest.mark.parametrize("logn", [14, 15, 16])
@@ -2487,7 +2501,8 @@ def test_bench_rccl_path_with_one_rank(launcher):
     timed output against the oracle, and reports `rccl_ranks_seen` from the collective. SURVEY 8(e); the workload is
     evaluator.cpp:235-272,772-827 (multiply + relinearize)."""
     line = _bench_child(["--gpus", "1", "--force-dist", "--batch", "64", "--steps", "1", "--warmup", "1",
-                         "--no-cpu-baseline", "--ntt-polys", "0", "--gather-cts", "16"], launcher=launcher)
+                         "--no-cpu-baseline", "--ntt-polys", "0", "--gather-cts", "16", "--verify-items", "3",
+                         "--pcie-pairs", "0"], launcher=launcher)
     assert line["dist_initialized"] is True and line["n_gpus"] == 1
     assert line["gather"]["backend"] == "nccl" and line["gather"]["ranks_seen"] == 1 and line["rccl_ranks_seen"] == 1
     assert line["gather"]["bytes_per_rank"] == 16 * 2 * 7 * 32768 * 8
@@ -2521,12 +2536,35 @@ def test_bench_other_baseline_configs_verify_themselves(config, batch):
     equals the oracle's repeated apply_galois) and --config 5 (BFV N = 2^16 multiply + relinearize + mod_switch_to_next,
     evaluator.cpp:996-1036): the same JSON schema, the first / middle / last item checked word for word against the oracle."""
     line = _bench_child(["--config", str(config), "--batch", str(batch), "--steps", "2", "--warmup", "1",
-                         "--no-cpu-baseline", "--ntt-polys", "0"])
+                         "--no-cpu-baseline", "--ntt-polys", "0", "--pcie-pairs", "2"])
     assert line["config"]["baseline_config"] == config and line["config"]["ciphertexts_per_gpu"] == batch
-    assert line["verified_vs_oracle"] is True and len(line["verified_items"]) == 3
+    assert line["verified_vs_oracle"] is True and line["verified_items"] == list(range(batch))  # small batch: every item
+    assert line["pcie_inclusive"]["matches_device_path"] is True and line["pcie_inclusive"]["units"] == 2
     assert line["unit"] == {4: "rotate_vector/s", 5: "pipeline/s"}[config]
     assert line["roofline"]["kernel"].startswith("ntt_") and 0 < line["roofline"]["frac"] < 1
     assert line["pipeline_roofline"]["compulsory_bytes_per_unit"] > 0 and len(line["kernels"]) >= 3
+
+
+@pytest.mark.parametrize("config,batch,mode", [(4, 1024, "parity"), (5, 256, "parity"), (3, 1024, "strict")])
+def test_bench_full_size_batches_verify_256_items(config, batch, mode):
+    """the BASELINE batch sizes of the side configs (config 4: 1024 ciphertexts per GPU, config 5:
+    256) and the STRICT mode of config 3 go through the bench child with the wide self-check: at least 256 items -- 0, B/2,
+    B-1, the edges of every arena chunk, seeded random picks -- word for word against the oracle (evaluator.h:1201-1211,
+    evaluator.cpp:235-272,772-827,996-1036; STRICT: SURVEY B.6), the PCIe-inclusive block against the device path, and the
+    roofline carrying the measured arithmetic ceiling next to the HBM fraction."""
+    line = _bench_child(["--config", str(config), "--batch", str(batch), "--mode", mode, "--steps", "2", "--warmup", "1",
+                         "--no-cpu-baseline", "--ntt-polys", "0", "--pcie-pairs", "8"])
+    assert line["config"]["baseline_config"] == config and line["config"]["ciphertexts_per_gpu"] == batch
+    assert line["config"]["mode"] == mode.upper()
+    assert line["verified_vs_oracle"] is True and line["verified_count"] == len(line["verified_items"]) >= 256
+    items = line["verified_items"]
+    assert {0, batch // 2, batch - 1} <= set(items) and items == sorted(set(items)) and items[-1] == batch - 1
+    for c in line["verified_chunk_sizes"]:  # every chunk edge is among the checked items
+        assert all({e - 1, e} <= set(items) for e in range(c, batch, c))
+    assert line["pcie_inclusive"]["matches_device_path"] is True and line["pcie_inclusive"]["value"] > 0
+    roof = line["roofline"]
+    assert roof["bound"] == ("hbm" if config == 4 else "valu") and 0 < roof["frac"] < 1
+    assert roof["valu_ceiling"]["butterflies_per_s"] > 1e11 and roof["alu_ceiling_frac"] > 0
 
 
 @pytest.mark.skipif("SEALHIP_TEST_SMALL_ARENA_COUNT" not in os.environ, reason="child of test_bench_shapes_with_a_small_arena")
@@ -2553,8 +2591,6 @@ def test_ntt_handoff_failure_surfaces_at_every_host_visible_point(sealhip):
     sticky flag is raised. sealhip_debug_ntt_handoff withholds the hand-off signal and cuts the wait to one poll, which
     drives exactly that path: every entry point that makes results host-visible must then fail (E_UNEXPECTED ->
     RuntimeError) instead of returning the rows with S_OK, once per failure, and the engine must work again afterwards."""
-    if os.environ.get("SEALHIP_NTT_TWO_PASS"):
-        pytest.skip("the two-pass tiled kernels have no cross-workgroup hand-off")
     logn, n = 15, 1 << 15
     kmods = O.coeff_modulus_create(n, [55] * 3)
     ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433)
@@ -2614,27 +2650,21 @@ def test_exact_ntt_variants_still_match_the_golden_digests():
     assert r.returncode == 0 and " passed" in tail, tail
 
 
-def test_round2_fast_paths_off_still_match_the_golden_digests():
-    """Round 2's fast paths each have a switch that restores the form they replaced: the FP64 NTT instances
-    (SEALHIP_NTT_NO_FP64), the top layer applied by bfv_lift2 (SEALHIP_LIFT_TOP_OFF), the CKKS mod-down folded into the
-    gathered transform (SEALHIP_KS_MODDOWN_UNFUSED) and the tensor product formed by the inverse transform
-    (SEALHIP_TENSOR_UNFUSED), the whole-row inverse (SEALHIP_NTT_WHOLE_ROW=0: half-row kernel + top-layer pass). With all of them off (child process: the switches are read once) the golden digests of the
-    compiled reference must come out as they do in this process with all of them on."""
+def test_integer_instances_instead_of_fp64_still_match_the_golden_digests():
+    """SEALHIP_NTT_NO_FP64 is the last switch of this kind the SHIPPING library reads: integer instances for primes below
+    2^50 (configs 2, 4, 5), next to the SEALHIP_NTT_EXACT_* / _CANON_EXACT switches of the test above, which run the
+    reference's own sequences. Child process (read once): the golden digests of the compiled reference must come out as
+    they do here. (Round 4: the A/B knobs that restored REPLACED forms -- SEALHIP_LIFT_TOP_OFF, SEALHIP_KS_MODDOWN_UNFUSED,
+    SEALHIP_KS_MODDOWN_STORE_UNFUSED, SEALHIP_TENSOR_UNFUSED, SEALHIP_NTT_WHOLE_ROW, SEALHIP_NTT_TWO_PASS, SEALHIP_RNS_UNFUSED
+    -- are gone from it: the first five exist in the measurement-only build alone, the last two were deleted with the
+    two-launch transform. The forms they restored are still reached by PARAMETERS -- primes of 59+ bits, operand sizes
+    other than 2, nsp > 1, N = 2^16 and N = 2^14, STRICT mode, k > 16 -- and the tests with such parameters cover them.)"""
     import subprocess
     import sys
 
-    env = dict(os.environ, SEALHIP_NTT_NO_FP64="1", SEALHIP_LIFT_TOP_OFF="1", SEALHIP_KS_MODDOWN_UNFUSED="1",
-               SEALHIP_TENSOR_UNFUSED="1", SEALHIP_NTT_WHOLE_ROW="0")
+    env = dict(os.environ, SEALHIP_NTT_NO_FP64="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "end_to_end_golden_digests or ntt_golden_digests or bench_launch_shapes or cfg4_rotate_large_batch"],
-                       env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    tail = r.stdout.decode("utf-8", "replace")[-400:]
-    assert r.returncode == 0 and " passed" in tail, tail
-    # one level up: the gathered mod-down transform (floating-point reduce mode 5) with its last kernel separate, which
-    # the default path at config 4's size no longer takes (it stores the finished mod-down itself, mode 7)
-    env = dict(os.environ, SEALHIP_KS_MODDOWN_STORE_UNFUSED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "cfg4_rotate_large_batch or cfg4_variant or (end_to_end_golden_digests and cfg4)"],
                        env=env, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode("utf-8", "replace")[-400:]
     assert r.returncode == 0 and " passed" in tail, tail

@@ -202,6 +202,55 @@ def test_bench_other_baseline_configs_multi_rank_gloo(config):
     assert len(set(line["rank_digests"])) == 2
 
 
+@pytest.mark.parametrize("config", [3, 4, 5])
+def test_bench_eight_rank_shape_rehearsal_gloo(config):
+    """The shape the driver's SCALE run has, rehearsed on CPU before the first hardware run: EIGHT
+    ranks started by bench.py itself as one `torch.distributed.run` child, shard_range(8 B, r, 8), rank-dependent seeds, the
+    replicated key checked by digest, eight result slices of the default 512 ciphertexts each gathered into rank 0
+    (scaled-down rows: the stub's ring), one JSON line with n_gpus 8 and rccl_ranks_seen 8. Backend gloo, stub step."""
+    import json
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    B = 520  # more than the 512 gathered ciphertexts, not a multiple of anything convenient
+    for r in range(8):
+        lo, hi = bench.shard_range(8 * B, r, 8)
+        assert (lo, hi) == (r * B, (r + 1) * B)
+    assert [bench.shard_range(8195, r, 8) for r in range(8)][-1][1] == 8195  # ragged totals are covered without gaps
+    assert sum(hi - lo for lo, hi in (bench.shard_range(8195, r, 8) for r in range(8))) == 8195
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--config", str(config),
+                          "--steps", "2", "--warmup", "1", "--batch", str(B)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["baseline_config"] == config
+    assert line["config"]["global_batch"] == 8 * B and line["config"]["ciphertexts_per_gpu"] == B
+    assert line["rccl_ranks_seen"] == 8 and line["gather"]["ranks_seen"] == 8  # eight slices arrived intact at rank 0
+    assert line["gather"]["bytes_per_rank"] == 512 * 2 * 2 * 64 * 8  # the default --gather-cts, the stub's row length
+    assert line["key_replicated"] is True and len(set(line["rank_digests"])) == 8
+    assert line["dist_initialized"] is True
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus N` on a node with fewer devices fails fast with a clear message, before any rank is started."""
+    import subprocess
+    import sys
+
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "HIP device" in out.stderr and "nothing was launched" in out.stderr, out.stderr
+
+
 def test_bench_force_dist_runs_the_collectives_with_one_rank_gloo():
     """--force-dist: a single rank still initialises the process group and runs barrier / all_reduce / all_gather and the
     final gather (to itself), so `rccl_ranks_seen` comes from the collective and not from the world == 1 shortcut. This is
