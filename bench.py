@@ -766,6 +766,19 @@ def main(argv=None):
             "butterflies_per_row": per_row, "rows_per_s": rows_s, "as_frac_of_hbm": rows_s * 16 * n / 1e9 / HBM_PEAK_GBS,
             "note": "measured in this run on this device: a kernel of nothing but the instance's butterflies, operands in registers"}
         r["alu_ceiling_frac"] = r["frac"] / r["valu_ceiling"]["as_frac_of_hbm"]
+        # With the counters of --measure-traffic (SQ_INSTS_VALU in its own --pmc pass): the kernel executes more vector
+        # instructions than its butterflies (addressing, exchanges, canonicalisation, the duplicated top layer), so its own
+        # issue ceiling is lower: the rate kernel's instruction throughput divided by the kernel's instructions per row.
+        tk = (traffic_rec or {}).get(r["kernel"], {})
+        ipb = (traffic_rec or {}).get("rate_kernel_valu_insts_per_butterfly", {}).get(str(kind))
+        if tk.get("valu_wave_insts_per_row") and ipb:
+            wave_insts_s = rate * ipb / 64.0
+            rows_issue = wave_insts_s / tk["valu_wave_insts_per_row"]
+            r["valu_ceiling"].update({"valu_insts_per_butterfly": ipb, "kernel_valu_wave_insts_per_row": tk["valu_wave_insts_per_row"],
+                                      "issue_ceiling_rows_per_s": rows_issue,
+                                      "issue_ceiling_as_frac_of_hbm": rows_issue * 16 * n / 1e9 / HBM_PEAK_GBS})
+            r["alu_ceiling_frac_butterflies_only"] = r["alu_ceiling_frac"]
+            r["alu_ceiling_frac"] = r["frac"] / r["valu_ceiling"]["issue_ceiling_as_frac_of_hbm"]
 
     roof, traffic_rec = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -851,7 +864,8 @@ def main(argv=None):
                          "more prime; the rate is per row)" % (P, k),
         }
         if roof and roof.get("valu_ceiling"):
-            ntt["alu_ceiling_frac"] = ntt["hbm_roofline_frac"] / roof["valu_ceiling"]["as_frac_of_hbm"]
+            vc = roof["valu_ceiling"]  # (the in-step launches' instruction count per row stands in for this launch's)
+            ntt["alu_ceiling_frac"] = ntt["hbm_roofline_frac"] / vc.get("issue_ceiling_as_frac_of_hbm", vc["as_frac_of_hbm"])
         del x
 
     # ---- PCIe-inclusive rate of the same step (N = 1): host-pointer entries on separately allocated pageable ciphertexts
@@ -951,14 +965,15 @@ def measure_traffic(args):
     if not exe:
         return None
     batch, steps = min(256, args.batch), 2
-    totals = {}  # tag -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "rows": rows, "launches": n}
-    everything = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    totals = {}  # tag -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "SQ_INSTS_VALU": wave instructions, "rows": rows, "launches": n}
+    everything = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
+    rate_kernel_insts = {}  # kind -> SQ_INSTS_VALU of the butterfly-rate kernel (bench.py's valu_ceiling runs it in the child too)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="sealhip_pmc_", dir="/tmp")
         # the step only (no NTT-only section): the same mix of launches that roofline.achieved is measured over
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                os.path.abspath(__file__), "--config", str(args.config), "--batch", str(batch), "--steps", str(steps),
-               "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--ntt-polys", "0"]
+               "--warmup", "0", "--no-cpu-baseline", "--no-verify", "--ntt-polys", "0", "--pcie-pairs", "0", "--mode", args.mode]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -969,11 +984,16 @@ def measure_traffic(args):
             val = float(row["Counter_Value"])
             if "fill_mod" in name or "at::native" in name or "distribution" in name:
                 continue  # torch's input fills are not part of the step
+            if "butterfly_rate_kernel" in name:
+                if counter == "SQ_INSTS_VALU":
+                    kind = name.split("butterfly_rate_kernel<")[1].split(">")[0]
+                    rate_kernel_insts[kind] = rate_kernel_insts.get(kind, 0.0) + val
+                continue  # the ceiling microbenchmark is not part of the step either
             everything[counter] += val
             tag = next((t for key, t in KERNEL_TAGS if key in name), None)
             if tag is None:
                 continue
-            t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "rows": 0.0, "launches": 0})
+            t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "rows": 0.0, "launches": 0})
             t[counter] += val
             if counter == "FETCH_SIZE":
                 t["rows"] += int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # half kernels: two workgroups per row
@@ -997,7 +1017,16 @@ def measure_traffic(args):
                     "read_bytes_per_row": 2 * t["FETCH_SIZE"] * 1024 / t["rows"],
                     "write_bytes_per_row": t["WRITE_SIZE"] * 1024 / t["rows"],
                     "rows_total": t["rows"], "launches": t["launches"], "fetch_size_kb_raw_total": t["FETCH_SIZE"],
-                    "write_size_kb_total": t["WRITE_SIZE"]}
+                    "write_size_kb_total": t["WRITE_SIZE"],
+                    # wave-level vector-ALU instructions per transformed row (SQ_INSTS_VALU, its own --pmc pass)
+                    "valu_wave_insts_per_row": t["SQ_INSTS_VALU"] / t["rows"]}
+    # the butterfly-rate kernel under the same counter: wave-level VALU instructions per butterfly of the measured sequence
+    # (csrc/ntt.hip ntt_butterfly_rate: a warm-up launch of iters / 8 and two of iters = 800, 2048 workgroups x 512 lanes x 32
+    # butterflies per iteration; two calls -- the instance's sequence and the reference's -- when they differ)
+    if rate_kernel_insts:
+        per_call = (100 + 800 + 800) * 2048 * 512 * 32  # butterflies of one sealhip_debug_butterfly_rate call
+        calls = {kd: max(1, round(v * 64 / per_call / 15)) for kd, v in rate_kernel_insts.items()}  # (~15 instructions each)
+        rec["rate_kernel_valu_insts_per_butterfly"] = {kd: v * 64 / (per_call * calls[kd]) for kd, v in rate_kernel_insts.items()}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     return rec
 

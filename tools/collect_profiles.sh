@@ -3,7 +3,7 @@
 # merged back; copy what is to be judged into profiles/<round>/ afterwards.
 #   tools/collect_profiles.sh r03
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/${tag}_profiles
 mkdir -p $out
@@ -45,4 +45,7 @@ find $out/stats4 -name "*kernel_stats.csv" -exec cp {} $out/cfg4_rotate_kernel_s
 rm -rf $out/stats4
 cd $root
 rm -rf $out/stats
+# 7. (round 4) STRICT mode through bench.py, and the quarter-row projection at N = 2^16 (needs lib/libsealhip_exp.so)
+python3 bench.py --mode strict > $out/bench_strict.jsonl 2> $out/bench_strict.err
+[ -f gemini-seal_amd/lib/libsealhip_exp.so ] && tools/n65536_projection.sh > $out/n65536_quarter_row_projection.txt 2>&1
 ls -la $out
