@@ -1140,12 +1140,13 @@ def test_f1_transparent_mod63_and_native_rotate(sealhip):
 
 
 @pytest.mark.parametrize("scheme,logn,bits", [
-    (1, 15, 55), (1, 15, 56), (1, 15, 58), (1, 15, 59), (1, 14, 56), (1, 14, 57), (1, 16, 55), (1, 16, 56),
-    (2, 15, 55), (2, 15, 56), (2, 15, 58), (2, 14, 56), (2, 16, 55)])
+    (1, 15, 55), (1, 15, 56), (1, 15, 57), (1, 15, 58), (1, 15, 59), (1, 14, 56), (1, 14, 57), (1, 14, 58), (1, 16, 55), (1, 16, 56),
+    (1, 16, 57), (1, 16, 58), (2, 15, 55), (2, 15, 56), (2, 15, 58), (2, 14, 56), (2, 16, 55), (2, 16, 57), (2, 16, 58)])
 def test_shortcut_boundaries_largest_admitted_primes(sealhip, scheme, logn, bits):
     """csrc/ntt_bounds.hpp admits each shortcut up to a prime size (lazy-sum inverse: 2^55 whole-row / 2^56 half-row at
-    N = 2^15, 2^56 / 2^56 at 2^14, 2^55 at 2^16; kNttAnyRep, kNttApprox and the unreduced mod-up: 2^58; fused tensor
-    product: 2^59). The recurrences are proved on the CPU (tests/bounds_check.cpp); this drives the real pipelines with the
+    N = 2^15, 2^56 / 2^56 at 2^14, 2^55 at 2^16; kNttAnyRep, kNttApprox (round 4: the level-2 quotient, 4p per layer) and the
+    unreduced mod-up: 2^58 at N = 2^14 / 2^15, 2^57 at 2^16; fused tensor product: 2^59 on exact-quotient rows, 2^57 on
+    approximate-quotient rows; the canonical entry's schedule on inputs below 4p: the same sizes). The recurrences are proved on the CPU (tests/bounds_check.cpp); this drives the real pipelines with the
     LARGEST primes below each bound and one size above it, and the inputs that maximise growth (all p-1, alternating,
     half, plus random), bit-exact against the oracle: multiply + relinearize (BFV) / rotate + multiply + relinearize +
     rescale (CKKS), and the standalone inverse on lazy-range inputs up to 2p-1.
@@ -1219,13 +1220,18 @@ def test_shortcut_boundaries_largest_admitted_primes(sealhip, scheme, logn, bits
             for i in range(k):
                 L.ref_ntt_inverse(O.ptr(e[c, i]), C.byref(tabs[i].t))
         assert np.array_equal(buf.download(x.shape), e), "inverse lazy_in=%s" % lazy_in
-    buf = ctx.upload(x)
-    ctx.ntt_negacyclic_harvey(buf, x.shape[0], k)
-    e = x.copy()
-    for c in range(x.shape[0]):
-        for i in range(k):
-            L.ref_ntt_forward(O.ptr(e[c, i]), C.byref(tabs[i].t), 0)
-    assert np.array_equal(buf.download(x.shape), e), "forward"
+    for top in (False, True):  # residues, and the top of the documented operand range: every word in [3p, 4p)
+        y = x.copy()
+        if top:
+            for i, p in enumerate(kmods[:k]):
+                y[:, i, :] += np.uint64(3 * p)
+        buf = ctx.upload(y)
+        ctx.ntt_negacyclic_harvey(buf, x.shape[0], k)
+        e = y.copy()
+        for c in range(x.shape[0]):
+            for i in range(k):
+                L.ref_ntt_forward(O.ptr(e[c, i]), C.byref(tabs[i].t), 0)
+        assert np.array_equal(buf.download(x.shape), e), "forward top=%s" % top
 
 
 @pytest.mark.parametrize("scheme,logn,bits", [(1, 15, [55] * 4), (1, 14, [50] * 3 + [58]), (1, 16, [50] * 3), (1, 12, [36, 36, 37]),

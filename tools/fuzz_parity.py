@@ -88,6 +88,29 @@ def one(rng, it):
         assert np.array_equal(got_l[i], lo), ("mod_switch", it, i)
         assert L.ref_apply_galois_inplace(C.byref(ref.c), k, O.ptr(e2), elt, O.ptr(key)) == 0
         assert np.array_equal(got_g[i], e2), ("galois", it, i)
+    # round 4: the NTT entries themselves on the operand ranges include/sealhip.h documents (forward below 4p, inverse below 2p):
+    # canonical and lazy forms, every row against the oracle (the canonical forward entry runs the approximate-quotient schedule
+    # with the single-precision estimate in its store where the primes admit it; the inverse the level-2 quotient in its lazy layers)
+    if logn >= 4:
+        tabs = [O.Tables(logn, p) for p in kmods[:k]]
+        cn = min(count, 5)
+        lim_f = [min(4 * p, (1 << 64) - 1) for p in kmods[:k]]
+        xf = np.stack([rng.integers(0, lim, size=(cn, 2, n), dtype=np.uint64) for lim in lim_f], axis=2).copy()
+        xi = np.stack([rng.integers(0, 2 * p, size=(cn, 2, n), dtype=np.uint64) for p in kmods[:k]], axis=2).copy()
+        xf[0, 0, :, :7] = np.array([[lim - 1] * 7 for lim in lim_f], dtype=np.uint64)  # the top of the range
+        for name, fn, src, reffn in (("ntt", ctx.ntt_negacyclic_harvey, xf, lambda r, tb: L.ref_ntt_forward(O.ptr(r), C.byref(tb.t), 0)),
+                                     ("ntt_lazy", ctx.ntt_negacyclic_harvey_lazy, xf, lambda r, tb: L.ref_ntt_forward_lazy(O.ptr(r), C.byref(tb.t), 0)),
+                                     ("intt", ctx.inverse_ntt_negacyclic_harvey, xi, lambda r, tb: L.ref_ntt_inverse(O.ptr(r), C.byref(tb.t))),
+                                     ("intt_lazy", ctx.inverse_ntt_negacyclic_harvey_lazy, xi, lambda r, tb: L.ref_ntt_inverse_lazy(O.ptr(r), C.byref(tb.t)))):
+            dx = ctx.upload(src)
+            fn(dx, cn * 2, k)
+            gotx = dx.download(src.shape)
+            for c in range(cn):
+                for s2 in range(2):
+                    for r in range(k):
+                        e = src[c, s2, r].copy()
+                        reffn(e, tabs[r])
+                        assert np.array_equal(gotx[c, s2, r], e), (name, it, c, s2, r, kmods[r])
     # encrypt-side arithmetic with the same samples on both sides, both output forms
     rows = int(rng.choice([k, k + nsp]))
     sk = rand_ct(rng, kmods, 1, n, 1)[0, 0]
