@@ -651,9 +651,10 @@ namespace sealhip
     };
     // IL inverse (Gentleman-Sande) lazy butterflies in lock step (BackwardLazy, ntt.cpp:265-272):
     // x' = u + v - (2p if >= 2p), y' = (u - v + 2p) * w lazily. Same instruction discipline as butterflies_fwd_hs.
-    // MODE 0: the reference's sequence (addend = 2p). MODE 1 / 2 (the caller allows any representative and has checked
-    // that nothing can wrap): the sum is left unreduced / reduced with barrett_lazy to [0, 2p), and `addend` is a
-    // multiple of p not below the largest second operand, so that u - v + addend stays non-negative.
+    // MODE 0: the reference's sequence (addend = 2p). MODE 1 / 2 / 3 (the caller allows any representative and has checked
+    // that nothing can wrap): the sum is left unreduced / reduced with barrett_lazy / reduced with the single-precision
+    // quotient estimate to [0, 2p), and `addend` is a multiple of p not below the largest second operand, so that
+    // u - v + addend stays non-negative.
     template <bool WU, int IL, int MODE = 0>
     __device__ __forceinline__ void butterflies_inv_hs(u64 (&u)[IL], u64 (&y)[IL], const u64 (&w)[IL], const u64 (&ws)[IL],
                                                        u64 neg_p, u64 two_p, u64 rdp = 0)
@@ -672,6 +673,8 @@ namespace sealhip
                 u[j] = tt >= two_p ? tt - two_p : tt;
             else if (MODE == 1)
                 u[j] = tt;
+            else if (MODE == 3) // dense lazy schedule: sums below 16p, the quotient estimated in single precision (rdp = its constant's bits)
+                u[j] = reduce_small_quot(tt, __uint_as_float(static_cast<unsigned>(rdp)), neg_p);
             else
                 u[j] = barrett_lazy_hs(tt, rdp, neg_p);
         }

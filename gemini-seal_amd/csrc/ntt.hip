@@ -1445,18 +1445,26 @@ namespace sealhip
 #define SEALHIP_NTT_INV_APX2 1
 #endif
         constexpr bool kInvApx2 = SEALHIP_NTT_INV_APX2 != 0;
-        template <int T>
+        // LZ 1: the sparse schedule (two reducing layers; primes with head-room), LZ 3 (round 4): the DENSE schedule for primes
+        // up to 2^60 -- every third layer and the last reduce their sums with the single-precision quotient estimate, values
+        // never pass 16p (ntt_bounds.hpp section 1): the 60-bit Bsk rows of a BFV multiply and ciphertext primes of 56-60 bits
+        // no longer pay a conditional subtraction in every butterfly.
+        template <int LZ>
+        constexpr bool kLazy = LZ == 1 || LZ == 3;
+        template <int T, int LZ = 1>
         struct InvLazy
         {
-            static constexpr int r1 = bounds::inv_lazy_r1(T);
+            static constexpr int sched = LZ == 3 ? 1 : 0;
             static constexpr int mode(int l)
             {
-                return bounds::inv_lazy_mode(T, l);
+                return bounds::inv_lazy_mode(T, l, sched);
             }
             static constexpr int shift(int l)
             {
-                return bounds::inv_lazy_shift(T, l);
+                return bounds::inv_lazy_shift(T, l, sched);
             }
+            // what butterflies_inv_hs gets for a reducing layer: Barrett (sparse) or the quotient estimate (dense)
+            static constexpr int reduce_mode = LZ == 3 ? 3 : 2;
         };
         // on-chip layers of the inverse kernel instance ntt_inv_half_kernel<KLOGN, ...> (half-row form of a ring of 2^KLOGN,
         // or whole-row form of a ring of 2^(KLOGN-1)): what the launchers hand to bounds::inv_lazy_admits
@@ -1540,11 +1548,11 @@ namespace sealhip
                     u[j] = x[slot(j)];
                     y[j] = x[slot(j) | bit];
                 }
-                if constexpr (LZ == 1 && InvLazy<T>::mode(layer) == 1 && kInvApx2)
-                    butterflies_inv_apx2<UNIFORM, kIL>(u, y, w, ws, neg_p, lazy_addend(neg_p, InvLazy<T>::shift(layer)), zp.z);
-                else if constexpr (LZ == 1)
-                    butterflies_inv_hs<UNIFORM, kIL, InvLazy<T>::mode(layer)>(u, y, w, ws, neg_p,
-                                                                             lazy_addend(neg_p, InvLazy<T>::shift(layer)), rdp);
+                if constexpr (kLazy<LZ> && InvLazy<T, LZ>::mode(layer) == 1 && kInvApx2)
+                    butterflies_inv_apx2<UNIFORM, kIL>(u, y, w, ws, neg_p, lazy_addend(neg_p, InvLazy<T, LZ>::shift(layer)), zp.z);
+                else if constexpr (kLazy<LZ>)
+                    butterflies_inv_hs<UNIFORM, kIL, InvLazy<T, LZ>::mode(layer) == 1 ? 1 : InvLazy<T, LZ>::reduce_mode>(
+                        u, y, w, ws, neg_p, lazy_addend(neg_p, InvLazy<T, LZ>::shift(layer)), rdp);
                 else
                     butterflies_inv_hs<UNIFORM, kIL>(u, y, w, ws, neg_p, two_p); // BackwardLazy, ntt.cpp:265-272
 #pragma unroll
@@ -1599,16 +1607,16 @@ namespace sealhip
             }
         }
         template <int T, int G, int LZ>
-        __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
+        __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp)
         {
             constexpr int f = T - 12;
-            static_assert(f - 1 < InvLazy<T>::r1, "the first layers are never the reducing ones");
+            static_assert(LZ != 1 || f - 1 < bounds::inv_lazy_r1(T), "sparse schedule: the first layers are never the reducing ones");
             int base = 0;
 #pragma unroll
             for (int W = 0; W < f; W++)
             {
                 const int bit = 1 << W;
-                const u64 addend = LZ == 1 ? lazy_addend(neg_p, InvLazy<T>::shift(W)) : two_p; // layer index = W
+                const u64 addend = kLazy<LZ> ? lazy_addend(neg_p, InvLazy<T, LZ>::shift(W)) : two_p; // layer index = W
 #pragma unroll
                 for (int e = 0; e < (1 << f); e++)
                 {
@@ -1629,8 +1637,10 @@ namespace sealhip
                     }
                     const u64 u = x[s], v = x[s | bit];
                     u64 tt = u + v;
-                    if (!LZ)
+                    if (!kLazy<LZ>)
                         tt = tt >= two_p ? tt - two_p : tt;
+                    else if (InvLazy<T, LZ>::mode(W) != 1) // (dense schedule at N = 2^16: its layer 2 is one of the first three)
+                        tt = reduce_small_quot(tt, __uint_as_float(static_cast<unsigned>(rdp)), neg_p);
                     x[s] = tt;
                     x[s | bit] = mulmod_lazy_hs<false>(u - v + addend, Wv.x, Wv.y, neg_p);
                 }
@@ -1646,11 +1656,11 @@ namespace sealhip
                 if constexpr (I + 1 < FinalStage<T>::SG)
                     FirstStage<T, ST, LZ, I + 1>::load(tg, tw, jb, N);
             }
-            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p)
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp)
             {
-                h_first_group_regs<T, ST * FinalStage<T>::SG + I, LZ>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p);
+                h_first_group_regs<T, ST * FinalStage<T>::SG + I, LZ>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p, rdp);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p);
+                    FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p, rdp);
             }
         };
         // AHEAD: the next stage's twiddles are requested before this stage is computed (two stages of twiddles live: 48
@@ -1661,18 +1671,18 @@ namespace sealhip
         struct FirstPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
-                                                       int N, u64 neg_p, u64 two_p)
+                                                       int N, u64 neg_p, u64 two_p, u64 rdp)
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS && AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p);
+                FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p, rdp);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS && !AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FirstPipe<T, ST + 1, LZ, AHEAD>::run(x, next, tw, jb, N, neg_p, two_p);
+                    FirstPipe<T, ST + 1, LZ, AHEAD>::run(x, next, tw, jb, N, neg_p, two_p, rdp);
             }
         };
 
@@ -1907,6 +1917,9 @@ namespace sealhip
             const u64 *inp = src ? src + (row / map.rows) * src_poly_stride + ((row % map.rows) << LOGR) + gbase : halfp;
             u64 x[32];
             const u64 neg_p = FP ? fp_bits(P.pinv_d) : 0 - p;
+            // what the reducing layers of the lazy schedules read: floor(2^64 / p) (sparse: Barrett) or the bits of the
+            // single-precision quotient constant (dense)
+            const u64 rdp = LZ == 1 ? P.rdp : (LZ == 3 ? static_cast<u64>(__float_as_uint(small_quot_const(p))) : 0);
             {
                 // every coefficient of the half row first (16 x 16 bytes per lane in flight at once), the twiddles of
                 // the first stage with them
@@ -1955,29 +1968,28 @@ namespace sealhip
                     h_exchange<T, LA, 4>(x, lds, fresh_tid(wave_base));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                FirstPipe<T, 0, LZ, FinalStage<T>::PIPE && !(DY && LZ == 1) && !(WHOLE && LZ == 0)>::run(x, tg0, tw, gbase + jloc, N, neg_p,
-                                                                                                      two_p);
+                FirstPipe<T, 0, LZ, FinalStage<T>::PIPE && !(DY && kLazy<LZ>) && !(WHOLE && LZ == 0)>::run(x, tg0, tw, gbase + jloc, N, neg_p,
+                                                                                                         two_p, rdp);
             }
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh_tid(wave_base));
             u64 w0[kIL], ws0[kIL];
-            const u64 rdp = LZ == 1 ? P.rdp : 0; // only the reducing layers of the lazy schedule read it
             RoundStageInv<T, 3, false, 0, LZ>::load(w0, ws0, tw, jb3, N); // lands while the exchange runs
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 4, 3>(x, lds, fresh_tid(wave_base));
             ZeroPairs zp; // (devmath.hpp mulhi_apx2; written again where each phase starts)
-            if constexpr (LZ == 1 && kInvApx2)
+            if constexpr (kLazy<LZ> && kInvApx2)
                 zp.init();
             RoundPipeInv<T, 3, false, LZ>::run(x, w0, ws0, tw, jb3, N, two_p, neg_p, rdp, zp);
             const int jb2 = gbase + Arr<T, 2>::tid_index(fresh_tid(wave_base));
             RoundStageInv<T, 2, false, 0, LZ>::load(w0, ws0, tw, jb2, N);
             __builtin_amdgcn_sched_barrier(0);
             h_exchange<T, 3, 2>(x, lds, fresh_tid(wave_base));
-            if constexpr (LZ == 1 && kInvApx2)
+            if constexpr (kLazy<LZ> && kInvApx2)
                 zp.init();
             RoundPipeInv<T, 2, false, LZ>::run(x, w0, ws0, tw, jb2, N, two_p, neg_p, rdp, zp);
             RoundStageInv<T, 1, true, 0, LZ>::load(w0, ws0, tw, gbase, N); // block-uniform twiddles -> scalar loads
             h_exchange<T, 2, 1>(x, lds, fresh_tid(wave_base));
-            if constexpr (LZ == 1 && kInvApx2)
+            if constexpr (kLazy<LZ> && kInvApx2)
                 zp.init();
             if constexpr (WHOLE)
             {
@@ -2000,7 +2012,7 @@ namespace sealhip
                 {
                     // BackwardLazyLast as ntt_inv_top_kernel applies it; with lazy sums the operands are below
                     // 2^shift(T - 1) p, so that multiple of p keeps the difference non-negative
-                    const u64 addend = LZ == 1 ? (0 - neg_p) << InvLazy<T>::shift(T - 1) : two_p;
+                    const u64 addend = kLazy<LZ> ? (0 - neg_p) << InvLazy<T, LZ>::shift(T - 1) : two_p;
 #pragma unroll
                     for (int s2 = 0; s2 < 16; s2++)
                     {
@@ -2150,8 +2162,12 @@ namespace sealhip
                 //  itself requires of an inverse transform, values below 2p)
                 static const bool exact_only = std::getenv("SEALHIP_NTT_EXACT_INV") != nullptr;
                 bool lazy = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !exact_only;
+                bool dense = lazy; // (round 4) the dense schedule where the sparse one has no head-room: primes of 2^45 .. 2^60
+                for (int i = 0; dense && i < live.n; i++)
+                    dense = bounds::inv_dense_admits(kInvLayers<LOGN>, e.tables[map.prime[live.slot[i]]].p);
                 for (int i = 0; lazy && i < live.n; i++)
                     lazy = bounds::inv_lazy_admits(kInvLayers<LOGN>, e.tables[map.prime[live.slot[i]]].p);
+                dense = dense && !lazy;
                 // floating-point instance: same contract (inputs below 2p, any representative out), every live prime below 2^50
                 bool fp = (flags & (kNttAnyRep | kNttCanonical)) != 0 && fp64_enabled() && !dyadic;
                 for (int i = 0; fp && i < live.n; i++)
@@ -2178,13 +2194,17 @@ namespace sealhip
             data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy, canon)
                         // (the lazy-sum schedule of the larger shape has one more layer: its own bound on the primes -- the
                         //  predicate takes the layer count of the instance that is launched, ntt_inv_half_kernel<LOGN + 1, ..>)
-                        bool lazy_w = lazy;
+                        bool lazy_w = lazy, dense_w = (lazy || dense);
                         for (int i = 0; lazy_w && i < live.n; i++)
                             lazy_w = bounds::inv_lazy_admits(kInvLayers<LOGN + 1>, e.tables[map.prime[live.slot[i]]].p);
+                        for (int i = 0; dense_w && i < live.n; i++)
+                            dense_w = bounds::inv_dense_admits(kInvLayers<LOGN + 1>, e.tables[map.prime[live.slot[i]]].p);
                         if (fp)
                             SEALHIP_INV_WHOLE(2);
                         else if (lazy_w)
                             SEALHIP_INV_WHOLE(1);
+                        else if (dense_w)
+                            SEALHIP_INV_WHOLE(3);
                         else
                             SEALHIP_INV_WHOLE(0);
 #undef SEALHIP_INV_WHOLE
@@ -2198,6 +2218,8 @@ namespace sealhip
                 {
                     if (lazy)
                         SEALHIP_INV_HALF(1, true);
+                    else if (dense)
+                        SEALHIP_INV_HALF(3, true);
                     else
                         SEALHIP_INV_HALF(0, true);
                 }
@@ -2205,6 +2227,8 @@ namespace sealhip
                     SEALHIP_INV_HALF(2, false);
                 else if (lazy)
                     SEALHIP_INV_HALF(1, false);
+                else if (dense)
+                    SEALHIP_INV_HALF(3, false);
                 else
                     SEALHIP_INV_HALF(0, false);
 #undef SEALHIP_INV_HALF
@@ -2256,6 +2280,19 @@ namespace sealhip
             const std::size_t blocks = chunk * 16;
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
+            // STRICT mode means "no wrap-around": Harvey's corrected butterflies (one conditional subtraction each)
+            // guarantee it for any prime. Where the consumer takes any representative (kNttAnyRep, kNttApprox) or the
+            // canonical residue is what is returned (kNttCanonical), and every live prime leaves the head-room that the cheaper
+            // schedules are proved on (ntt_bounds.hpp section 2: nothing can wrap there either), the residues are the same and
+            // the flag is dropped for the launch (round 4). The `_lazy` entries and the 60-bit rows keep the corrected sequence.
+            if ((flags & kNttStrict) != 0 && (flags & (kNttAnyRep | kNttCanonical | kNttApprox)) != 0 && (flags & kNttReduceOut) == 0)
+            {
+                bool ok = std::getenv("SEALHIP_NTT_EXACT_FWD") == nullptr;
+                for (int i = 0; ok && i < live.n; i++)
+                    ok = bounds::fwd_canon_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
+                if (ok)
+                    flags &= ~kNttStrict;
+            }
             // SEALHIP_NTT_NO_TICKET=1 (A/B of the hand-off cost) re-opens the race: read by the measurement-only build alone
             // (engine.hpp exp_env); in the shipping library this is the constant false
             static const bool no_ticket = exp_env("SEALHIP_NTT_NO_TICKET") != nullptr;
@@ -2515,10 +2552,12 @@ namespace sealhip
                 if (err != hipSuccess)
                     return err;
             }
-            const void *inv[5] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false>),
+            const void *inv[7] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 3, false>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, true>),
+                                   reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 3, true>),
                                    reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, true>) };
             for (const void *f : inv)
             {
@@ -2528,8 +2567,9 @@ namespace sealhip
             }
             if constexpr (LOGN <= 15)
             {
-                const void *whole[3] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 2, false, true>),
+                const void *whole[4] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 2, false, true>),
                                          reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 1, false, true>),
+                                         reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 3, false, true>),
                                          reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN + 1, 0, false, true>) };
                 for (const void *f : whole)
                 {

@@ -53,28 +53,40 @@ namespace sealhip
         // uses since round 4. A MODE 1 layer's outputs are bounded by its unreduced sum, 2^(shift + 1) p >= 4p, so the
         // recurrence below takes the maximum of the two and finds the schedule unchanged.
         constexpr int kInvLazyProductMult = 4;
+        // Two schedules (`sched`):
+        //   0  SPARSE (rounds 1-3): two reducing layers, r1 and T - 1; for primes with head-room (2^55 / 2^56 per shape);
+        //   1  DENSE (round 4): every third layer (l % 3 == 2) and the last reduce, so values never pass 16p: for primes up to
+        //      2^60 -- the 60-bit Bsk rows of a BFV multiply, and ciphertext primes of 56 to 60 bits -- which ran the
+        //      reference's own sequence (a conditional subtraction in every butterfly) for want of head-room. The reducing
+        //      layers bring their SUM below 2p with the single-precision quotient estimate (section 6: quotient below 16) and
+        //      form their product with the exact quotient (below 2p); the two layers in between leave sums of up to 4p / 8p
+        //      entering and products below 4p (level-2 quotient).
         constexpr int inv_lazy_r1(int T)
         {
             return (T - 1) / 2;
         }
-        constexpr int inv_lazy_mode(int T, int l)
+        constexpr int inv_lazy_mode(int T, int l, int sched = 0)
         {
+            if (sched == 1)
+                return (l % 3 == 2 || l == T - 1) ? 2 : 1;
             return (l == inv_lazy_r1(T) || l == T - 1) ? 2 : 1;
         }
-        constexpr int inv_lazy_shift(int T, int l)
+        constexpr int inv_lazy_shift(int T, int l, int sched = 0)
         {
+            if (sched == 1)
+                return 1 + l % 3; // entering: 2p after a reducing layer (and at the start), then 4p, then 8p
             return 1 + (l <= inv_lazy_r1(T) ? l : l - inv_lazy_r1(T) - 1);
         }
         // worst-case recurrence: the largest true value any instruction of the schedule forms (sum u + y, difference
         // u - y + addend), for inputs below 2p. Also checks the schedule's own claim "values entering layer l are below
         // 2^shift(l) p" -- returns 2^64 (overflow) if the claim were violated, so a wrong shift table cannot pass.
-        constexpr u128 inv_lazy_peak(int T, u64 p)
+        constexpr u128 inv_lazy_peak(int T, u64 p, int sched = 0)
         {
             u128 bound = static_cast<u128>(2) * p; // inputs: what the reference requires of an inverse transform's input
             u128 peak = bound;
             for (int l = 0; l < T; l++)
             {
-                const u128 claimed = static_cast<u128>(p) << inv_lazy_shift(T, l);
+                const u128 claimed = static_cast<u128>(p) << inv_lazy_shift(T, l, sched);
                 if (bound > claimed)
                     return kWord; // schedule inconsistent
                 const u128 sum = 2 * claimed;       // u + y < 2 * claimed
@@ -84,23 +96,23 @@ namespace sealhip
                 // outputs: a reducing layer (MODE 2) leaves sum and product (exact quotient) below 2p; a MODE 1 layer keeps
                 // the sum and may leave its product anywhere below 4p (level-2 quotient)
                 const u128 prod = static_cast<u128>(kInvLazyProductMult) * p;
-                bound = inv_lazy_mode(T, l) == 2 ? static_cast<u128>(2) * p : (sum > prod ? sum : prod);
+                bound = inv_lazy_mode(T, l, sched) == 2 ? static_cast<u128>(2) * p : (sum > prod ? sum : prod);
             }
             return peak;
         }
-        constexpr int inv_lazy_max_shift(int T)
+        constexpr int inv_lazy_max_shift(int T, int sched = 0)
         {
             int m = 0;
             for (int l = 0; l < T; l++)
-                m = inv_lazy_shift(T, l) > m ? inv_lazy_shift(T, l) : m;
+                m = inv_lazy_shift(T, l, sched) > m ? inv_lazy_shift(T, l, sched) : m;
             return m;
         }
         // admission: largest prime size (bits) for which the recurrence stays below 2^64
-        constexpr int inv_lazy_prime_bits(int T)
+        constexpr int inv_lazy_prime_bits(int T, int sched = 0)
         {
             int bits = 0;
             for (int b = 1; b <= kMaxPrimeBits; b++)
-                if (inv_lazy_peak(T, max_prime_of_bits(b)) < kWord)
+                if (inv_lazy_peak(T, max_prime_of_bits(b), sched) < kWord)
                     bits = b;
             return bits;
         }
@@ -108,6 +120,19 @@ namespace sealhip
         {
             return p <= max_prime_of_bits(inv_lazy_prime_bits(T));
         }
+        constexpr u64 kSmallQuotMinPrime = u64(1) << 45; // section 6
+        // the dense schedule: sums up to 16p must fit the word (primes below 2^60) and its reducing layers estimate a quotient
+        // below 16 in single precision (section 6: p at least 2^45; the predicate calls small_quot_admits itself)
+        constexpr bool small_quot_admits(u64 p, int mult);
+        constexpr int kInvDenseSumMult = 16;
+        constexpr bool inv_dense_admits(int T, u64 p)
+        {
+            return T >= 3 && p <= max_prime_of_bits(inv_lazy_prime_bits(T, 1)) && small_quot_admits(p, kInvDenseSumMult);
+        }
+        static_assert(inv_lazy_prime_bits(13, 1) == 60 && inv_lazy_prime_bits(14, 1) == 60 && inv_lazy_prime_bits(15, 1) == 60 &&
+                          inv_lazy_prime_bits(16, 1) == 60,
+                      "dense lazy inverse: primes below 2^60 in every shape");
+        static_assert(inv_lazy_max_shift(16, 1) == 3, "dense lazy inverse: values entering a layer are below 8p");
 
         // =====================================================================================================
         // 2. Forward transform, integer (ntt_fwd_half_kernel<.., STRICT = 0 / 2>). The fork's forward butterfly
@@ -371,7 +396,7 @@ namespace sealhip
         // M <= 128 and p >= 2^45 (the hi word must also fit single precision's exponent range trivially, and M p < 2^64).
         constexpr bool small_quot_admits(u64 p, int mult)
         {
-            if (p < (u64(1) << 45) || mult < 1 || mult > 128 || static_cast<u128>(mult) * p > kWord)
+            if (p < kSmallQuotMinPrime || mult < 1 || mult > 128 || static_cast<u128>(mult) * p > kWord)
                 return false;
             const long double loss = 0x1p32L / static_cast<long double>(p) +
                                      static_cast<long double>(mult) * (0x1p-20L + 3 * 0x1p-24L + 0x1p-51L);

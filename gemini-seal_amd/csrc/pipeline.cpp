@@ -487,7 +487,7 @@ namespace sealhip
             {
                 // steps (4) + (5) (:376-424): D[I] = inverse NTT of sum_{i1+i2=I} X[i1] (.) X[2+i2], top layer deferred, every
                 // word with the Montgomery factor 2^-64 that bfv_floor_sk's constants undo. q rows: lazy sums (any
-                // representative); Bsk rows: operands reduced on load, the reference's butterfly sequence
+                // representative, sparse schedule); Bsk rows: operands reduced on load, the dense lazy schedule
                 RowMap mq{}, mb{};
                 mq.rows = mb.rows = dest * kb;
                 for (int I = 0; I < dest; I++)
@@ -498,7 +498,10 @@ namespace sealhip
                     }
                 check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mq, kNttDeferTop | kNttAnyRep, sq),
                       "intt(tensor, q rows)");
-                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop, sq), "intt(tensor, Bsk rows)");
+                // (round 4: the Bsk rows may store any representative below 2p as well -- bfv_floor_sk2 takes u, v below 2p and
+                //  canonicalises; the launcher then runs the DENSE lazy schedule on the 60-bit primes, ntt_bounds.hpp section 1)
+                check(launch_intt_tensor(e, D, X, w_x, poly_x, kb, m * dest * kb, mb, kNttDeferTop | kNttAnyRep, sq),
+                      "intt(tensor, Bsk rows)");
                 for (int I = 0; I < dest; I++)
                 {
                     SinkArm arm(e, I >= 1 ? sink_at(e, off) : nullptr); // polynomials 1.. of the product
@@ -517,13 +520,13 @@ namespace sealhip
             if (defer)
             {
                 // two launches over disjoint rows: the q rows may store any representative (bfv_floor_sk canonicalises
-                // while it applies the deferred top layer), which lets the kernel drop most conditional subtractions;
-                // the 60-bit Bsk rows have no head-room for that and keep the reference's sequence
+                // while it applies the deferred top layer), which lets the kernel drop most conditional subtractions
+                // (sparse lazy schedule); so may the 60-bit Bsk rows, which take the dense schedule (round 4)
                 RowMap mq = lt.map_qbsk, mb = lt.map_qbsk;
                 for (int r = 0; r < kb; r++)
                     (r < k ? mb : mq).prime[r] = kSkipRow;
                 check(launch_ntt(e, D, m * dest * kb, mq, true, kNttDeferTop | kNttAnyRep), "intt(D, q rows)");
-                check(launch_ntt(e, D, m * dest * kb, mb, true, kNttDeferTop), "intt(D, Bsk rows)");
+                check(launch_ntt(e, D, m * dest * kb, mb, true, kNttDeferTop | kNttAnyRep), "intt(D, Bsk rows)");
             }
             else
                 check(launch_ntt(e, D, m * dest * kb, lt.map_qbsk, true, kNttCanonical), "intt(D)");

@@ -67,6 +67,20 @@ static void enumerate_predicates()
             CHECK(inv_lazy_prime_bits(T) == 63 - inv_lazy_max_shift(T), "inverse lazy T=%d: closed form 63 - max_shift", T);
             checked++;
         }
+    // 1a'. the dense schedule (round 4): admitted up to 60 bits in every shape, tight, and never below 2^45
+    for (int T = kMinHalfLogn - 1; T <= kMaxHalfLogn; T++)
+        for (int bits = 20; bits <= kMaxPrimeBits; bits++)
+        {
+            const u64 p = max_prime_of_bits(bits);
+            const bool adm = inv_dense_admits(T, p);
+            const u128 peak = inv_lazy_peak(T, p, 1);
+            if (adm)
+                CHECK(peak < kWord && small_quot_admits(p, kInvDenseSumMult) && peak <= static_cast<u128>(kInvDenseSumMult) * p,
+                      "dense inverse T=%d bits=%d admitted but the recurrence overflows or passes 16p", T, bits);
+            else
+                CHECK(peak >= kWord || bits <= 45, "dense inverse T=%d bits=%d rejected although it fits (not tight)", T, bits);
+            checked++;
+        }
     // 1b. forward integer shortcuts (kNttAnyRep, kNttApprox, unreduced inputs), every combination that is launched
     for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
         for (int bits = 20; bits <= kMaxPrimeBits; bits++)
@@ -300,7 +314,7 @@ static void fp_forward_execution(int logn, u64 pu, int pattern)
 
 // ---- inverse integer lazy-sum schedule executed on 64-bit words with a 128-bit shadow of every true value
 static u64 quotient_model(u64 y, u64 s, int level);
-static void inv_lazy_execution(int T, u64 p)
+static void inv_lazy_execution(int T, u64 p, int sched = 0)
 {
     const int n = 1 << T;
     std::mt19937_64 rng(T);
@@ -312,7 +326,7 @@ static void inv_lazy_execution(int T, u64 p)
     for (int l = 0; l < T; l++)
     {
         const int gap = 1 << l;
-        const u64 addend = p << inv_lazy_shift(T, l);
+        const u64 addend = p << inv_lazy_shift(T, l, sched);
         for (int blk = 0; blk < n; blk += 2 * gap)
         {
             const u64 w = rng() % p;
@@ -326,20 +340,27 @@ static void inv_lazy_execution(int T, u64 p)
                 peak = sum > peak ? sum : peak;
                 peak = static_cast<u128>(diff) > peak ? static_cast<u128>(diff) : peak;
                 u64 s = static_cast<u64>(sum);
-                if (inv_lazy_mode(T, l) == 2) // barrett_lazy: x - floor(x * floor(2^64 / p) / 2^64) * p
+                if (inv_lazy_mode(T, l, sched) == 2 && sched == 0) // barrett_lazy: x - floor(x * floor(2^64 / p) / 2^64) * p
                     s = s - static_cast<u64>((static_cast<u128>(s) * static_cast<u64>(kWord / p)) >> 64) * p;
+                else if (inv_lazy_mode(T, l, sched) == 2) // dense schedule: the single-precision quotient estimate (section 6)
+                {
+                    const float c = static_cast<float>(4294967296.0 / static_cast<double>(p) * (1.0 - 0x1p-20));
+                    const unsigned q = static_cast<unsigned>(static_cast<float>(static_cast<unsigned>(s >> 32)) * c);
+                    s = s - static_cast<u64>(q) * p;
+                    wrapped = wrapped || sum >= static_cast<u128>(kInvDenseSumMult) * p;
+                }
                 const u64 d = static_cast<u64>(diff);
                 // MODE 1 layers: the level-2 quotient (product below 4p); reducing layers: the exact one (below 2p)
-                const u64 q = quotient_model(d, ws, inv_lazy_mode(T, l) == 1 ? 2 : 0);
+                const u64 q = quotient_model(d, ws, inv_lazy_mode(T, l, sched) == 1 ? 2 : 0);
                 x[j] = s;
                 x[j + gap] = d * w - q * p;
                 wrapped = wrapped || static_cast<u128>(d) * w - static_cast<u128>(q) * p >=
-                                         static_cast<u128>(inv_lazy_mode(T, l) == 1 ? kInvLazyProductMult : 2) * p;
+                                         static_cast<u128>(inv_lazy_mode(T, l, sched) == 1 ? kInvLazyProductMult : 2) * p;
             }
         }
     }
-    CHECK(!wrapped, "inverse lazy execution T=%d p=%llu wrapped", T, p);
-    CHECK(peak <= inv_lazy_peak(T, p), "inverse lazy execution T=%d above the recurrence", T);
+    CHECK(!wrapped, "inverse lazy execution T=%d p=%llu sched=%d wrapped", T, p, sched);
+    CHECK(peak <= inv_lazy_peak(T, p, sched), "inverse lazy execution T=%d sched=%d above the recurrence", T, sched);
     bool below_2p = true;
     for (int i = 0; i < n; i++)
         below_2p = below_2p && x[i] < 2 * p;
@@ -527,7 +548,11 @@ int main()
         for (int pattern = 0; pattern < 4; pattern++)
             fp_forward_execution(logn, max_ntt_prime_of_bits(kFpPrimeBits, logn), pattern);
     for (int T = kMinHalfLogn - 1; T <= kMaxHalfLogn; T++)
+    {
         inv_lazy_execution(T, max_prime_of_bits(inv_lazy_prime_bits(T)));
+        inv_lazy_execution(T, max_prime_of_bits(inv_lazy_prime_bits(T, 1)), 1); // dense schedule at the largest 60-bit value
+        inv_lazy_execution(T, (u64(1) << 59) + 12345, 1);
+    }
     std::printf(failures ? "bounds_check: %d FAILURES\n" : "bounds_check: OK\n", failures);
     return failures ? 1 : 0;
 }
