@@ -116,7 +116,7 @@ out += ["```", "", "Round-4 experiment records in this directory:",
         "projected standalone 2^16 inverse 0.27 / 0.24 against 0.237 / 0.205. **Then built** (quarter-row kernels + one streaming radix-4 pass, "
         "the default for standalone inverses at 2^16): the file shows both forms on one box -- measured **0.27 / 0.24**, the projection to the digit. "
         "The forward transform has no such option (a quarter-row forward pays three products per kept output on load).",
-        "- `kernel_regs_ntt.txt`: 105 kernels of `ntt.hip`, 0 with spills (the zero-high pairs cost two registers per phase).",
-        "- `gpu_tests_final.txt`: the `-m gpu` suite on the final build (172 passed)."]
+        "- `kernel_regs_ntt.txt`: 110 kernels of `ntt.hip`, 0 with spills (the zero-high pairs cost two registers per phase).",
+        "- `gpu_tests_final.txt`: the `-m gpu` suite on the final build (176 passed)."]
 open(os.path.join(root, "summary.md"), "w").write("\n".join(out) + "\n")
 print("wrote", os.path.join(root, "summary.md"))
