@@ -2411,7 +2411,8 @@ namespace sealhip
             // the flag is dropped for the launch (round 4). The `_lazy` entries and the 60-bit rows keep the corrected sequence.
             if ((flags & kNttStrict) != 0 && (flags & (kNttAnyRep | kNttCanonical | kNttApprox)) != 0 && (flags & kNttReduceOut) == 0)
             {
-                bool ok = std::getenv("SEALHIP_NTT_EXACT_FWD") == nullptr;
+                static const bool exact_fwd = std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr;
+                bool ok = !exact_fwd;
                 for (int i = 0; ok && i < live.n; i++)
                     ok = bounds::fwd_canon_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
                 if (ok)

@@ -1080,6 +1080,17 @@ def test_transparency_is_a_flag_output_of_the_operations(sealhip, scheme, logn, 
         ctx.transparency_sink(flags, 2)
         with pytest.raises(ValueError):
             ev.negate(ctx.upload(a), 2, k, count, neg)
+        # a call rejected for the sink's capacity leaves BOTH the in-place operand and the flags as they were
+        # (the capacity is validated before the first launch; the flags are cleared only where they start to be written)
+        before = got()
+        dct = ctx.upload(a)
+        plain_ntt = ctx.upload(np.stack([rand_rows(rng, kmods[:k], n) for _ in range(count)]))
+        with pytest.raises(ValueError):
+            ev.multiply_plain_inplace(dct, 2, k, count, plain_ntt, plain_stride=k * n, ntt_form=True)
+        assert np.array_equal(dct.download(a.shape), a) and got() == before
+        with pytest.raises(ValueError):  # rejected for its level before anything else: the flags stay
+            ev.mod_switch_to_next(ctx.upload(a), 2, k + 5, count, ctx.alloc(count * 2 * k * n))
+        assert got() == before
     finally:
         ctx.transparency_sink(None, 0)
     # the same operations without a sink give the same words
