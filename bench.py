@@ -457,7 +457,10 @@ class EngineWorkload:
         so the inputs of the chosen items are kept."""
         B = self.B
         picks = {0, B // 2, B - 1}
-        self.chunks = sorted({c for cnt, c in self.ctx.chunk_log() if cnt == B and 0 < c < B})
+        try:
+            self.chunks = sorted({c for cnt, c in self.ctx.chunk_log() if cnt == B and 0 < c < B})
+        except Exception:  # (a library without the debug entry: the edges are simply not among the picks)
+            self.chunks = []
         for c in self.chunks:
             for edge in range(c, B, c):
                 picks.update((edge - 1, edge))
@@ -875,8 +878,12 @@ def main(argv=None):
     if not args.stub and world == 1 and args.pcie_pairs > 0:
         try:
             pcie = w.pcie_inclusive(args.pcie_pairs)
-        except MemoryError:
-            pcie = None
+        except Exception as exc:  # an auxiliary section must never cost the run its line: report what failed instead
+            pcie = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                w.ctx.synchronize()
+            except Exception:
+                pass
 
     # ---- the final gather (N > 1, or --force-dist): every rank's result slice to rank 0 over RCCL, timed on its own
     gather = gather_payload(w.result_slice(min(B, args.gather_cts)), cheap_digest, force=args.force_dist)
