@@ -39,9 +39,11 @@ def one(rng, it):
     count = int(rng.choice([1, 2, 5, 17, 33])) if logn <= 12 else (int(rng.choice([1, 3, 17])) if logn <= 14 else int(rng.choice([1, 2, 2, 17])))
     print("case", it, "%s logn=%d k=%d nsp=%d count=%d bits=%s" % ("BFV" if scheme == 1 else "CKKS", logn, k, nsp, count, bits),
           flush=True) if os.environ.get("FUZZ_VERBOSE") else None
-    ctx = S.Context(scheme, logn, kmods, nsp, t)
+    # round 4: a quarter of the cases in STRICT mode (corrected forward butterflies, NTT'd in-bundle BFV rows) on both sides
+    strict = int(rng.random() < 0.25)
+    ctx = S.Context(scheme, logn, kmods, nsp, t, mode=S.MODE_STRICT if strict else S.MODE_PARITY)
     ev = S.Evaluator(ctx)
-    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t)
+    ref = O.RefContext(scheme, logn, kmods, nsp=nsp, t=t, mode=strict)
     d = (k + nsp - 1) // nsp
     key = np.stack([rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(d)])
     dkey = S.KSwitchKeys(ctx, key)
@@ -98,8 +100,8 @@ def one(rng, it):
         xf = np.stack([rng.integers(0, lim, size=(cn, 2, n), dtype=np.uint64) for lim in lim_f], axis=2).copy()
         xi = np.stack([rng.integers(0, 2 * p, size=(cn, 2, n), dtype=np.uint64) for p in kmods[:k]], axis=2).copy()
         xf[0, 0, :, :7] = np.array([[lim - 1] * 7 for lim in lim_f], dtype=np.uint64)  # the top of the range
-        for name, fn, src, reffn in (("ntt", ctx.ntt_negacyclic_harvey, xf, lambda r, tb: L.ref_ntt_forward(O.ptr(r), C.byref(tb.t), 0)),
-                                     ("ntt_lazy", ctx.ntt_negacyclic_harvey_lazy, xf, lambda r, tb: L.ref_ntt_forward_lazy(O.ptr(r), C.byref(tb.t), 0)),
+        for name, fn, src, reffn in (("ntt", ctx.ntt_negacyclic_harvey, xf, lambda r, tb: L.ref_ntt_forward(O.ptr(r), C.byref(tb.t), strict)),
+                                     ("ntt_lazy", ctx.ntt_negacyclic_harvey_lazy, xf, lambda r, tb: L.ref_ntt_forward_lazy(O.ptr(r), C.byref(tb.t), strict)),
                                      ("intt", ctx.inverse_ntt_negacyclic_harvey, xi, lambda r, tb: L.ref_ntt_inverse(O.ptr(r), C.byref(tb.t))),
                                      ("intt_lazy", ctx.inverse_ntt_negacyclic_harvey_lazy, xi, lambda r, tb: L.ref_ntt_inverse_lazy(O.ptr(r), C.byref(tb.t)))):
             dx = ctx.upload(src)
@@ -164,7 +166,7 @@ def one(rng, it):
             rc, exp = ck.encode(v[i], k, sc)
             assert rc == 0 and np.array_equal(got_e[i], exp), ("ckks_encode", it, i)
             assert np.array_equal(dec[i].view(np.uint64), ck.decode(exp, sc).view(np.uint64)), ("ckks_decode", it, i)
-    return "%s logn=%d k=%d nsp=%d count=%d bits=%s" % ("BFV" if scheme == 1 else "CKKS", logn, k, nsp, count, bits)
+    return "%s%s logn=%d k=%d nsp=%d count=%d bits=%s" % ("BFV" if scheme == 1 else "CKKS", " STRICT" if strict else "", logn, k, nsp, count, bits)
 
 
 def main():
