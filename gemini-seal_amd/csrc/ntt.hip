@@ -279,6 +279,22 @@ namespace sealhip
         // Arrangement R (R = 1..3: compute rounds on index bits [T-4R, T-4R+4); R = 4: final round on the
         // remaining T-12 low bits): slot bit 0 <-> index bit 0 always; the other slot bits and the lane id
         // cover the rest as two runs of consecutive index bits.
+        //
+        // Round 4, wave-local arrangements (SEALHIP_NTT_WAVE_LOCAL, default on). A workgroup has 2^(T-11) waves, and in
+        // arrangements 2 and 3 the wave number of a lane (tid >> 6) is exactly index bits [11, T): the lane bits below
+        // cover everything else. With arrangement 4's fillers on index bits [f+6, 11) instead of the top bits -- lane bits
+        // 0..5 <-> index bits [f, f+6), wave number <-> bits [11, T) there as well -- a wave owns the SAME 2048 indices
+        // (1024 LDS words, one contiguous range of the exchange buffer) from arrangement 2 to the store: the exchanges
+        // 2 <-> 3 and 3 <-> 4 move data between lanes of one wave only. LDS instructions of a wave execute in order, so those
+        // exchanges need no s_barrier at all (h_exchange): 4 workgroup barriers per transform instead of 12, and the eight
+        // waves of a workgroup drift apart after round 1 -- one wave's exchange overlaps another's arithmetic inside the same
+        // workgroup, where before every wave of it waited at the same barrier. Memory side unchanged per instruction (a wave
+        // still covers 2^(f+6) consecutive coefficients per final-round group); its groups are now neighbours (a contiguous
+        // 16 KB per wave) instead of 16 KB apart.
+#ifndef SEALHIP_NTT_WAVE_LOCAL
+#define SEALHIP_NTT_WAVE_LOCAL 1
+#endif
+        constexpr bool kWaveLocal = SEALHIP_NTT_WAVE_LOCAL != 0;
         template <int T, int R>
         struct Arr
         {
@@ -292,6 +308,8 @@ namespace sealhip
                     return beta + (w - 1);
                 if (w < f)
                     return w;
+                if (kWaveLocal)
+                    return f + 6 + (w - f);   // fillers: index bits [f+6, 11), just above the lane's
                 return T - (5 - f) + (w - f); // fillers: the top index bits
             }
             static constexpr int low_start = R <= 3 ? 1 : f;
@@ -299,11 +317,15 @@ namespace sealhip
             static constexpr int high_start = beta + 4;
             __device__ static __forceinline__ int tid_index(int tid)
             {
+                if constexpr (R == 4 && kWaveLocal)
+                    return ((tid & 63) << f) | ((tid >> 6) << 11);
                 int v = (tid & ((1 << low_len) - 1)) << low_start;
                 if (R <= 3 && low_len < T - 5)
                     v |= (tid >> low_len) << high_start;
                 return v;
             }
+            // the wave number is index bits [11, T) in this arrangement (2, 3 always; 4 in the wave-local form)
+            static constexpr bool wave_owned = R == 2 || R == 3 || (R == 4 && kWaveLocal);
             static constexpr int slot_index(int s)
             {
                 int r = 0;
@@ -347,6 +369,20 @@ namespace sealhip
         {
             const int pa = hpad(Arr<T, RA>::tid_index(tid) >> 1);
             const int pb = hpad(Arr<T, RB>::tid_index(tid) >> 1);
+            // both arrangements wave-owned: every word a wave writes is read by the same wave and by no other. The LDS
+            // executes a wave's instructions in order, so the hardware needs nothing; the fences keep the compiler from
+            // moving a read above the writes it depends on (they emit no instruction at wavefront scope).
+            constexpr bool LOCAL = kWaveLocal && Arr<T, RA>::wave_owned && Arr<T, RB>::wave_owned;
+            const auto sync = [] {
+                if constexpr (LOCAL)
+                {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                else
+                    __syncthreads();
+            };
 #pragma unroll
             for (int phase = 0; phase < 2; phase++)
             {
@@ -354,12 +390,12 @@ namespace sealhip
                 for (int s = 0; s < 32; s++)
                     if ((s & 1) == phase)
                         lds[pa + hpad(Arr<T, RA>::slot_index(s) >> 1)] = x[s];
-                __syncthreads();
+                sync();
 #pragma unroll
                 for (int s = 0; s < 32; s++)
                     if ((s & 1) == phase)
                         x[s] = lds[pb + hpad(Arr<T, RB>::slot_index(s) >> 1)];
-                __syncthreads();
+                sync();
             }
         }
 
@@ -501,9 +537,10 @@ namespace sealhip
             static_assert(f == 2 || f == 3, "register transposition: runs of 4 or 8 coefficients");
             constexpr int s = G << f;
             const int j = jb & ((1 << T) | ((1 << T) - 1)); // (the experiment build keeps its hooks above)
-            const int tid = (j & ((1 << T) - 1)) >> f;
             // lane part of the address: the wave's base, then r * 2^f + (the swapped lane bits) * 2
-            int base = (j & (1 << T)) + ((tid >> 6) << (6 + f));
+            // (wave-local form: the lane is index bits [f, f+6), everything above -- no filler bit is set in j -- is the base)
+            const int tid = kWaveLocal ? ((j >> f) & 63) : ((j & ((1 << T) - 1)) >> f);
+            int base = kWaveLocal ? (j & ~((1 << (6 + f)) - 1)) : ((j & (1 << T)) + ((tid >> 6) << (6 + f)));
             if constexpr (f == 2)
             {
                 base += ((tid & 31) << 2) + (((tid >> 5) & 1) << 1);
