@@ -1333,6 +1333,20 @@ long sealhip_evaluator_rescale_to_next_host(sealhip_context *ctx, uint32_t k, co
     return level_down_host(ctx, k, ct, size, count, out, true);
 }
 
+long sealhip_host_register(sealhip_context *ctx, void *ptr, size_t bytes)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ptr);
+    return guarded([&] { host_register(device_engine(ctx), ptr, bytes); });
+}
+
+long sealhip_host_unregister(sealhip_context *ctx, void *ptr)
+{
+    REQUIRE_PTR(ctx);
+    REQUIRE_PTR(ptr);
+    return guarded([&] { host_unregister(device_engine(ctx), ptr); });
+}
+
 long sealhip_evaluator_mod_switch_to_next(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size,
                                           size_t count, uint64_t *out)
 {

@@ -524,6 +524,10 @@ namespace sealhip
     using HostChunkFn = std::function<void(Engine &, const std::vector<u64 *> &d_in, const std::vector<u64 *> &d_out, u64 *d_tmp,
                                            std::size_t m)>;
     void run_host_batch(Engine &e, const HostBatchIO &io, std::size_t count, const HostChunkFn &fn);
+    // pins [ptr, ptr + bytes) in place (hipHostRegister) and remembers the range: run_host_batch copies arrays whose items lie
+    // in registered ranges straight between the caller's buffers and the device (no staging copy)
+    void host_register(const Engine &e, void *ptr, std::size_t bytes);
+    void host_unregister(const Engine &e, void *ptr);
 
     // ---- composed operations (pipeline.cpp) ----
     // c0_src: see launch_ks_moddown_bfv -- the ciphertext is then write-only: (c0_src + result_0, result_1)

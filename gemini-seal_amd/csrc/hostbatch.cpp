@@ -14,15 +14,77 @@
 // with two staging slots, HIP events between the stages and no host synchronisation other than "the results of chunk
 // c-1 have landed". PCIe, not the engine, is what bounds this path (7.3 MB in + 3.7 MB out per
 // config-3 multiply+relinearize); the pipeline keeps the link busy in both directions while the kernels run.
+//
+// Round 4: what bounds it in fact is the gather / scatter -- 12 host threads move ~58 GB/s, and the calling thread does
+// both for every chunk (config 3: 8.1 + 4.0 ms of copies per 64 pairs against 8.5 ms on the link). A caller whose buffers
+// live in memory it keeps (the blocks of a MemoryPool, native/src/seal/util/mempool.cpp:45,145) can pin them in place
+// once -- sealhip_host_register -- and an array whose items all lie in registered ranges skips the staging copy: the DMA
+// engine reads / writes the caller's buffers directly, the host threads have nothing to do for it.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <thread>
 
 #include "engine.hpp"
 
 namespace sealhip
 {
+    // ---- host ranges pinned in place (process-wide: a registration is visible to every device, hipHostRegisterPortable)
+    namespace
+    {
+        std::shared_mutex g_reg_mutex;
+        std::map<std::uintptr_t, std::size_t> g_registered; // start -> bytes, disjoint
+
+        bool range_registered(const void *p, std::size_t bytes)
+        {
+            const std::uintptr_t a = reinterpret_cast<std::uintptr_t>(p);
+            auto it = g_registered.upper_bound(a);
+            if (it == g_registered.begin())
+                return false;
+            --it;
+            return a >= it->first && bytes <= it->second && a - it->first <= it->second - bytes;
+        }
+    } // namespace
+
+    void host_register(const Engine &e, void *ptr, std::size_t bytes)
+    {
+        if (!ptr || !bytes)
+            throw std::invalid_argument("host_register: empty range");
+        if (e.device < 0)
+            throw std::logic_error("host_register needs a device context");
+        const std::uintptr_t a = reinterpret_cast<std::uintptr_t>(ptr);
+        std::unique_lock<std::shared_mutex> lock(g_reg_mutex);
+        // overlap with a range already pinned: the runtime would refuse it; say which argument is wrong
+        auto it = g_registered.upper_bound(a);
+        if (it != g_registered.end() && it->first - a < bytes)
+            throw std::invalid_argument("host_register: the range overlaps a registered one");
+        if (it != g_registered.begin())
+        {
+            --it;
+            if (a - it->first < it->second)
+                throw std::invalid_argument("host_register: the range overlaps a registered one");
+        }
+        SEALHIP_CHECK(hipSetDevice(e.device));
+        SEALHIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+        g_registered.emplace(a, bytes);
+    }
+
+    void host_unregister(const Engine &e, void *ptr)
+    {
+        std::unique_lock<std::shared_mutex> lock(g_reg_mutex);
+        const auto it = g_registered.find(reinterpret_cast<std::uintptr_t>(ptr));
+        if (it == g_registered.end())
+            throw std::invalid_argument("host_unregister: not the start of a registered range");
+        if (e.device >= 0)
+            SEALHIP_CHECK(hipSetDevice(e.device));
+        // (a transfer still in flight on the range is the caller's to wait for: the *_host entries return synchronised)
+        SEALHIP_CHECK(hipHostUnregister(ptr));
+        g_registered.erase(it);
+    }
+
     struct HostStage
     {
         int device = -1;
@@ -207,19 +269,34 @@ namespace sealhip
                   std::max<std::size_t>(chunk * io.tmp_words * sizeof(u64), 256));
 
         const std::size_t nchunks = (count + chunk - 1) / chunk;
+        // an array whose items of this chunk all lie inside registered ranges is copied by the DMA engine from / to the
+        // caller's buffers themselves (the registry is read under its lock: a concurrent unregister of a range in use is
+        // the caller's error, as freeing the buffer would be)
+        const auto all_registered = [&](auto const &a, std::size_t off, std::size_t m) {
+            std::shared_lock<std::shared_mutex> lock(g_reg_mutex);
+            if (g_registered.empty())
+                return false;
+            for (std::size_t i = 0; i < m; i++)
+                if (!range_registered(a.ptrs[off + i], a.words * sizeof(u64)))
+                    return false;
+            return true;
+        };
+        std::vector<char> out_direct(nchunks * io.out.size(), 0);
         auto scatter = [&](std::size_t c) {
             HostStage::Slot &s = st.slot[c & 1];
             SEALHIP_CHECK(hipEventSynchronize(s.out_ready));
             e.check_fault(); // results are about to become host-visible
             const std::size_t off = c * chunk, m = std::min(chunk, count - off);
-            std::size_t base = 0;
+            std::size_t base = 0, ai = 0;
             for (const auto &a : io.out)
             {
                 const char *src = s.h_out + base;
-                parallel_items(m, [&](std::size_t i) {
-                    std::memcpy(a.ptrs[off + i], src + i * a.words * sizeof(u64), a.words * sizeof(u64));
-                });
+                if (!out_direct[c * io.out.size() + ai]) // (else: already in the caller's buffers)
+                    parallel_items(m, [&](std::size_t i) {
+                        std::memcpy(a.ptrs[off + i], src + i * a.words * sizeof(u64), a.words * sizeof(u64));
+                    });
                 base += chunk * a.words * sizeof(u64);
+                ai++;
             }
         };
         try
@@ -234,10 +311,18 @@ namespace sealhip
                 for (const auto &a : io.in)
                 {
                     char *dst = s.h_in + base;
-                    parallel_items(m, [&](std::size_t i) {
-                        std::memcpy(dst + i * a.words * sizeof(u64), a.ptrs[off + i], a.words * sizeof(u64));
-                    });
-                    SEALHIP_CHECK(hipMemcpyAsync(s.d_in + base, dst, m * a.words * sizeof(u64), hipMemcpyHostToDevice, st.s_h2d));
+                    const std::size_t item_bytes = a.words * sizeof(u64);
+                    if (all_registered(a, off, m))
+                    {
+                        for (std::size_t i = 0; i < m; i++)
+                            SEALHIP_CHECK(hipMemcpyAsync(s.d_in + base + i * item_bytes, a.ptrs[off + i], item_bytes,
+                                                         hipMemcpyHostToDevice, st.s_h2d));
+                    }
+                    else
+                    {
+                        parallel_items(m, [&](std::size_t i) { std::memcpy(dst + i * item_bytes, a.ptrs[off + i], item_bytes); });
+                        SEALHIP_CHECK(hipMemcpyAsync(s.d_in + base, dst, m * item_bytes, hipMemcpyHostToDevice, st.s_h2d));
+                    }
                     d_in.push_back(reinterpret_cast<u64 *>(s.d_in + base));
                     base += chunk * a.words * sizeof(u64);
                 }
@@ -253,11 +338,21 @@ namespace sealhip
                 SEALHIP_CHECK(hipEventRecord(s.done, lane.stream));
                 SEALHIP_CHECK(hipStreamWaitEvent(st.s_d2h, s.done, 0));
                 base = 0;
+                std::size_t ai = 0;
                 for (const auto &a : io.out)
                 {
-                    SEALHIP_CHECK(hipMemcpyAsync(s.h_out + base, s.d_out + base, m * a.words * sizeof(u64), hipMemcpyDeviceToHost,
-                                                 st.s_d2h));
-                    base += chunk * a.words * sizeof(u64);
+                    const std::size_t item_bytes = a.words * sizeof(u64);
+                    if (all_registered(a, off, m))
+                    {
+                        out_direct[c * io.out.size() + ai] = 1;
+                        for (std::size_t i = 0; i < m; i++)
+                            SEALHIP_CHECK(hipMemcpyAsync(a.ptrs[off + i], s.d_out + base + i * item_bytes, item_bytes,
+                                                         hipMemcpyDeviceToHost, st.s_d2h));
+                    }
+                    else
+                        SEALHIP_CHECK(hipMemcpyAsync(s.h_out + base, s.d_out + base, m * item_bytes, hipMemcpyDeviceToHost, st.s_d2h));
+                    base += chunk * item_bytes;
+                    ai++;
                 }
                 SEALHIP_CHECK(hipEventRecord(s.out_ready, st.s_d2h));
                 if (c > 0)

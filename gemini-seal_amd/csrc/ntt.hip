@@ -273,7 +273,8 @@ namespace sealhip
         // finishes all T remaining layers on chip: 32 coefficients per lane (5 index bits), radix-16 register
         // rounds, LDS exchanges between rounds. The LDS holds only half of the tile, so every exchange runs
         // in two phases keyed on index bit 0, which stays in the registers through all rounds ("sticky"):
-        // coefficients with bit0 = p only ever move between slots with slot-bit0 = p.
+        // coefficients with bit0 = p only ever move between slots with slot-bit0 = p. Only the exchange between
+        // arrangements 1 and 2 crosses waves (workgroup barriers); the others stay inside a wave (see kWaveLocal below).
         // HBM traffic: one read of the row (+ the sibling re-read, mostly from L2) and one write.
         //
         // Arrangement R (R = 1..3: compute rounds on index bits [T-4R, T-4R+4); R = 4: final round on the
@@ -298,6 +299,7 @@ namespace sealhip
         template <int T, int R>
         struct Arr
         {
+            static_assert(T >= 13 && T <= 15, "half-row shapes of N = 2^14 .. 2^16: 2^(T-5) lanes, i.e. 2^(T-11) waves <-> index bits [11, T)");
             static constexpr int beta = R <= 3 ? T - 4 * R : 0;
             static constexpr int f = T - 12; // low bits left for the final round (incl. bit 0)
             static constexpr int slot_bit(int w)

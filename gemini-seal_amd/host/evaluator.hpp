@@ -532,6 +532,17 @@ namespace sealhip_host
                                                           keys.data(), std::uint32_t(elts.size())));
         }
 
+        // The vector entries above read / write the ciphertexts' own buffers; a pool block (mempool.cpp:45,145) pinned here
+        // once lets the DMA engine do that in place (sealhip_host_register). Unregister before freeing.
+        void register_pool_block(void *ptr, std::size_t bytes)
+        {
+            throw_on(sealhip_host_register(ctx_.get(), ptr, bytes));
+        }
+        void unregister_pool_block(void *ptr)
+        {
+            throw_on(sealhip_host_unregister(ctx_.get(), ptr));
+        }
+
         // ---- the rest of the Evaluator surface
         // Evaluator::negate_inplace (evaluator.cpp:65-88)
         void negate_inplace(CT &encrypted)

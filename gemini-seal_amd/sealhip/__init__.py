@@ -146,6 +146,8 @@ SYMBOLS = {
     "sealhip_ciphertext_resize": [_vp, _u32, _vp, _u32, _vp, _u32, _sz],
     "sealhip_kswitch_key_load_stream": [_vp, _vp, _sz, _u32, C.POINTER(_vp), C.POINTER(_u64)],
     "sealhip_expand_seed_host": [_vp, _u32, _vp, _vp],
+    "sealhip_host_register": [_vp, _vp, _sz],
+    "sealhip_host_unregister": [_vp, _vp],
     "sealhip_debug_blake2xb": [_vp, _sz, _vp, _sz, _vp, _sz],
     "sealhip_kswitch_keys_save": [_vp, C.POINTER(_vp), _u32, _vp, _sz, C.POINTER(_sz)],
     "sealhip_graph_capture_begin": [_vp],
@@ -733,6 +735,13 @@ class Evaluator:
         for a in arrays:
             assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
         return (C.c_void_p * max(1, len(arrays)))(*[a.ctypes.data for a in arrays])
+
+    def host_register(self, array):
+        """sealhip_host_register: pins the array's memory in place; *_host entries then copy it without staging"""
+        _check(lib().sealhip_host_register(self.ctx.handle, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        _check(lib().sealhip_host_unregister(self.ctx.handle, array.ctypes.data))
 
     def multiply_host(self, a, size_a, b, size_b, k, out, relin_keys=None):
         """Evaluator::multiply (+ relinearize when relin_keys is given) over lists of host ciphertexts; out[i] is written"""

@@ -300,6 +300,18 @@ long sealhip_evaluator_mod_switch_to_next_host(sealhip_context *ctx, uint32_t k,
 long sealhip_evaluator_rescale_to_next_host(sealhip_context *ctx, uint32_t k, const uint64_t *const *ct, uint32_t size,
                                             size_t count, uint64_t *const *out);
 
+/* Pins the caller's range [ptr, ptr + bytes) in place (hipHostRegister, visible to every device) and remembers it. A *_host
+   entry whose item buffers of an array all lie inside registered ranges skips that array's staging copy: the DMA engine reads /
+   writes the caller's buffers themselves, which takes the host threads (the bound of the pageable path) out of the transfer.
+   Meant for memory the caller keeps -- the reference's ciphertexts come from a MemoryPool whose blocks are allocated at
+   native/src/seal/util/mempool.cpp:45 and :145 and reused for the life of the pool: register a block once where it is
+   allocated, unregister it where the pool frees it. Pinning costs far more than one copy, so registering a buffer for a single
+   call does not pay. E_INVALIDARG: empty range, a range that overlaps a registered one, (unregister) a pointer that is not the
+   start of a registered range; HIP's refusal (e.g. a locked-memory limit) -> E_UNEXPECTED with its message. The caller must not
+   unregister or free a range while a *_host call that uses it is running. */
+long sealhip_host_register(sealhip_context *ctx, void *ptr, size_t bytes);
+long sealhip_host_unregister(sealhip_context *ctx, void *ptr);
+
 /* ---------------------------------------------------------------- Evaluator surface beyond the hot path */
 /* Ciphertext batches [count][size][k][N]. Evaluator::negate_inplace (evaluator.cpp:65-88); out may alias ct. */
 long sealhip_evaluator_negate(sealhip_context *ctx, uint32_t k, const uint64_t *ct, uint32_t size, size_t count,

@@ -120,6 +120,33 @@ int main(int argc, char **argv)
             std::printf("host batch %s\n", batch_ok ? "ok" : "FAILED");
             if (!batch_ok)
                 return 1;
+            // the batch rotated in place, once on pageable buffers and once with every buffer pinned in place
+            // (register_pool_block): same words
+            {
+                std::vector<HostCiphertext> plain(xs), pinned(xs);
+                std::vector<HostCiphertext *> pp, pq;
+                for (std::size_t i = 0; i < count; i++)
+                {
+                    pp.push_back(&plain[i]);
+                    pq.push_back(&pinned[i]);
+                }
+                std::uint32_t g1 = 0;
+                throw_on(sealhip_galois_elt_from_step(ctx.get(), 1, &g1));
+                const std::map<std::uint32_t, const KSwitchKeys *> gk1{ { g1, &rk } };
+                ev.rotate_vector_inplace(pp, 1, gk1); // (in place, no reallocation: the pinned pointers stay the objects' buffers)
+                for (auto &c : pinned)
+                    ev.register_pool_block(c.data(), c.words.size() * sizeof(std::uint64_t));
+                ev.rotate_vector_inplace(pq, 1, gk1);
+                bool reg_ok = true, refused = false;
+                try { ev.register_pool_block(pinned[0].data(), 64); } catch (const std::invalid_argument &) { refused = true; }
+                for (auto &c : pinned)
+                    ev.unregister_pool_block(c.data());
+                for (std::size_t i = 0; i < count; i++)
+                    reg_ok = reg_ok && plain[i].words == pinned[i].words && plain[i].words != xs[i].words;
+                std::printf("registered batch %s\n", reg_ok && refused ? "ok" : "FAILED");
+                if (!reg_ok || !refused)
+                    return 1;
+            }
             // multiply_many / exponentiate_inplace through the adapter: x^2 == relinearize(x * x), and a three-operand product
             // follows the reference's queue order [a0*b0, a0] -> (a0*b0)*a0
             HostCiphertext sq = a0, want_sq = a0;

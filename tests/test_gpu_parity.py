@@ -2282,6 +2282,89 @@ def test_host_pointer_array_entries_match_the_device_batch_path(sealhip, scheme)
     ev.multiply_host([], 2, [], 2, k, [])  # empty batch
 
 
+def test_host_entries_on_registered_pool_blocks(sealhip):
+    """sealhip_host_register: the reference's ciphertexts are pieces of MemoryPool blocks (mempool.cpp:45,145) that live as long
+    as the pool. With the blocks pinned in place the *_host entries copy straight between the caller's buffers and the device;
+    results must be the same words as through the staging path -- all items registered, only the inputs registered (outputs
+    staged), items of one array half in and half out of registered memory (falls back to staging for that array), in place
+    (relinearize, rotate) -- and the registry must refuse overlaps and unknown pointers."""
+    logn, n, nsp, t = 12, 4096, 1, 65537
+    kmods = O.coeff_modulus_create(n, [40] * 4)
+    k, count = 3, 150  # three chunks of 64, the last one ragged
+    ctx = sealhip.Context(1, logn, kmods, nsp, t)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(77)
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    d3 = ctx.alloc(count * 3 * k * n)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, d3)
+    ev.relinearize_inplace(d3, 3, k, count, [dkey])
+    relin = d3.download((count, 3, k, n))[:, :2].copy()
+    elt = ctx.galois_elt_from_step(3)
+    drel = ctx.upload(relin)
+    ev.rotate_vector_inplace(drel, k, count, 3, {elt: dkey})
+    want_rot = drel.download((count, 2, k, n))
+    # "pool blocks": a few big allocations, ciphertexts are pieces of them at odd offsets
+    words = 2 * k * n
+    blocks = [np.zeros(50 * (words + 3) + 5, dtype=np.uint64) for _ in range(9)]
+
+    def piece(blk, j):
+        o = 1 + j * (words + 3)
+        return blk[o:o + words].reshape(2, k, n)
+
+    ha = [piece(blocks[i // 50], i % 50) for i in range(count)]
+    hb = [piece(blocks[3 + i // 50], i % 50) for i in range(count)]
+    ho = [piece(blocks[6 + i // 50], i % 50) for i in range(count)]
+    for i in range(count):
+        ha[i][...] = a[i]
+        hb[i][...] = b[i]
+    for blk in blocks[:6]:
+        ev.host_register(blk)
+    # inputs pinned, outputs staged
+    ev.multiply_host(ha, 2, hb, 2, k, ho, relin_keys=[dkey])
+    for i in range(count):
+        assert np.array_equal(ho[i], relin[i]), i
+        ho[i][...] = 0
+    for blk in blocks[6:]:
+        ev.host_register(blk)
+    # everything pinned
+    ev.multiply_host(ha, 2, hb, 2, k, ho, relin_keys=[dkey])
+    for i in range(count):
+        assert np.array_equal(ho[i], relin[i]), i
+    # in place on pinned buffers
+    ev.rotate_vector_host(ho, k, 3, {elt: dkey})
+    for i in range(count):
+        assert np.array_equal(ho[i], want_rot[i]), i
+    # one array partly outside registered memory: that array takes the staging path, the words do not change
+    mixed = [ha[i] if i % 2 else ha[i].copy() for i in range(count)]
+    out = [np.zeros((2, k, n), dtype=np.uint64) for _ in range(count)]
+    ev.multiply_host(mixed, 2, hb, 2, k, out, relin_keys=[dkey])
+    for i in range(count):
+        assert np.array_equal(out[i], relin[i]), i
+    # a buffer that only starts inside a registered block is not "registered"
+    tail = blocks[0][-words // 2:]
+    assert tail.nbytes < words * 8
+    # registry errors
+    with pytest.raises(ValueError):
+        ev.host_register(blocks[0])  # again
+    with pytest.raises(ValueError):
+        ev.host_register(blocks[1][10:20])  # inside a registered range
+    with pytest.raises(ValueError):
+        ev.host_unregister(blocks[1][10:20])  # not the start of one
+    for blk in blocks:
+        ev.host_unregister(blk)
+    with pytest.raises(ValueError):
+        ev.host_unregister(blocks[0])
+    # and the staging path still serves the same buffers afterwards
+    for i in range(count):
+        ho[i][...] = 0
+    ev.multiply_host(ha, 2, hb, 2, k, ho, relin_keys=[dkey])
+    for i in range(count):
+        assert np.array_equal(ho[i], relin[i]), i
+
+
 def test_context_is_reentrant_one_lane_per_thread(sealhip):
     """seal::Evaluator is re-entrant (evaluator.h:1375-1377). Four host threads drive ONE context with different operations at
     the same time; each gets its own lane (stream + arena), nothing serialises on a context lock, and every result equals

@@ -28,9 +28,10 @@ fw = tr["ntt_fwd_half"]
 out += ["", "Bench line of the same build (`bench_with_traffic.jsonl`, traffic measured by this run's own `--measure-traffic` PMC passes):",
         "- value **%.0f ct-mul+relin/s**, %.1f ms per step of %d pairs; %d items verified word for word against the CPU oracle (0, B/2, B-1, the "
         "edges of the arena chunks %s, seeded random picks): %s; PCIe-inclusive (host-pointer entries, %d separately allocated pageable pairs): "
-        "%.0f ct/s at %.1f GB/s host -> device" % (
+        "%.0f ct/s at %.1f GB/s host -> device; on pool blocks pinned in place (`sealhip_host_register`, no staging copies): %.0f ct/s at %.1f GB/s" % (
             b["value"], b["ms_per_step"], b["config"]["global_batch"], b["verified_count"], b["verified_chunk_sizes"], b["verified_vs_oracle"],
-            b["pcie_inclusive"]["units"], b["pcie_inclusive"]["value"], b["pcie_inclusive"]["h2d_GBps"]),
+            b["pcie_inclusive"]["units"], b["pcie_inclusive"]["value"], b["pcie_inclusive"]["h2d_GBps"],
+            b["pcie_inclusive"]["registered"]["value"], b["pcie_inclusive"]["registered"]["h2d_GBps"]),
         "- roofline (dominant kernel `ntt_fwd_half`): achieved %.0f GB/s of %.0f = **%.3f**; %d launches, avg %.3f ms, %.0f rows per launch; "
         "PMC traffic / algorithmic bytes = %.3f. **bound: %s** -- measured arithmetic ceiling of the butterfly sequence on this box %.2f T "
         "butterflies/s (reference's exact sequence: %.2f T) = %.3f of HBM for butterflies alone; the kernel executes %.0f wave-level VALU "
