@@ -656,6 +656,13 @@ namespace sealhip
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
+                else if constexpr (ROUT && STRICT == 4)
+                {
+                    // dense lazy schedule: words below 16p -> [0, 2p) (rdp carries the bits of the quotient constant)
+                    const float cq = __uint_as_float(static_cast<unsigned>(rdp));
+                    v.x = reduce_small_quot(v.x, cq, neg_p);
+                    v.y = reduce_small_quot(v.y, cq, neg_p);
+                }
                 else if constexpr (ROUT)
                 {
                     // kNttReduceOut: [0, 4p) -> [0, 2p), same residue. (The last layer reduces its first operand and its
@@ -808,6 +815,13 @@ namespace sealhip
                     v.x = v.x >= p ? v.x - p : v.x;
                     v.y = v.y >= p ? v.y - p : v.y;
                 }
+                else if constexpr (ROUT && STRICT == 4)
+                {
+                    // dense lazy schedule: words below 16p -> [0, 2p) (rdp carries the bits of the quotient constant)
+                    const float cq = __uint_as_float(static_cast<unsigned>(rdp));
+                    v.x = reduce_small_quot(v.x, cq, neg_p);
+                    v.y = reduce_small_quot(v.y, cq, neg_p);
+                }
                 else if constexpr (ROUT)
                 {
                     // kNttReduceOut: [0, 4p) -> [0, 2p), same residue. (The last layer reduces its first operand and its
@@ -957,6 +971,14 @@ namespace sealhip
                 // (before on-chip layers 5 and 10 -- after round 2's first and round 3's second layer: see fp_reduce_all)
                 if constexpr (STRICT == 3 && K % (16 / kIL) == 0 && bounds::fp_fwd_reduce_before_layer(4 * (R - 1) + K / (16 / kIL)))
                     fp_reduce_all(x, two_p, neg_p);
+                // dense lazy schedule (STRICT == 4, ntt_bounds.hpp section 2b): every word back below 2p before rounds 2 and 3
+                if constexpr (STRICT == 4 && K == 0 && bounds::fwd_dense_reduce_before_round(R))
+                {
+                    const float cq = small_quot_const(0 - neg_p);
+#pragma unroll
+                    for (int i = 0; i < 32; i++)
+                        x[i] = reduce_small_quot(x[i], cq, neg_p);
+                }
                 RoundStage<T, R, STRICT, UNIFORM, K>::run(x, w, ws, two_p, neg_p, zp);
                 if constexpr (K + 1 < NST)
                     RoundPipe<T, R, STRICT, UNIFORM, K + 1>::run(x, wn, wsn, tw, jb, N, two_p, neg_p, zp);
@@ -1420,8 +1442,10 @@ namespace sealhip
             // bit 0: canonicalising wrapper; bit 1: leave the last layer's first operand unreduced (kNttAnyRep)
             // bit 2 (approximate-quotient canonical launches on primes of at least 45 bits, launch_half): the canonicalising
             // step estimates its small quotient in single precision (devmath.hpp reduce_small_quot)
-            const int fin = ((flags & kNttCanonical) ? 1 : 0) | ((flags & kNttAnyRep) ? 2 : 0) | ((flags & kNttSmallQuot) ? 4 : 0);
-            const u64 rdp_fin = (STRICT == 2 && (flags & kNttSmallQuot)) ? static_cast<u64>(__float_as_uint(small_quot_const(p))) : rdp;
+            // (STRICT == 4, the dense lazy schedule: the last layer leaves its first operand as it is, the store reduces)
+            const int fin = ((flags & kNttCanonical) ? 1 : 0) | (((flags & kNttAnyRep) || STRICT == 4) ? 2 : 0) | ((flags & kNttSmallQuot) ? 4 : 0);
+            const u64 rdp_fin =
+                ((STRICT == 2 && (flags & kNttSmallQuot)) || STRICT == 4) ? static_cast<u64>(__float_as_uint(small_quot_const(p))) : rdp;
             constexpr bool ROUT = REDUCE == 3 || REDUCE == 6; // kNttReduceOut launches (never gathered: no load treatment to combine with)
             if constexpr (kFinalApx<T, STRICT> == 2)
                 zp.init();
@@ -2548,6 +2572,17 @@ namespace sealhip
                     flags |= kNttPolyMajor | (g << 16);
                 }
             }
+            // STRICT launches on primes without the head-room of the rule above (the 60-bit Bsk rows of a BFV multiply) whose
+            // consumer takes any representative below 2p (kNttReduceOut | kNttAnyRep): the dense lazy schedule of
+            // ntt_bounds.hpp section 2b instead of a conditional subtraction per butterfly -- the reference's own butterfly,
+            // every word brought back below 2p before rounds 2 and 3 and in the store. Same residues, nothing wraps.
+#ifndef SEALHIP_NTT_FWD_DENSE
+#define SEALHIP_NTT_FWD_DENSE 1 // (0: A/B build without it -- Harvey's corrected butterflies on those rows, as before)
+#endif
+            bool dense = SEALHIP_NTT_FWD_DENSE && (flags & kNttStrict) != 0 && (flags & kNttReduceOut) != 0 && (flags & kNttAnyRep) != 0 &&
+                         (flags & (kNttCanonical | kNttTopDone)) == 0 && !src.base[0] && std::getenv("SEALHIP_NTT_EXACT_FWD") == nullptr;
+            for (int i = 0; dense && i < live.n; i++)
+                dense = bounds::fwd_dense_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
             if (flags & kNttAnyRep)
             {
                 // the last layer may keep its first operand unreduced only if the grown values cannot wrap
@@ -2641,6 +2676,8 @@ namespace sealhip
                 else
                     SEALHIP_FWD_HALF(2, 0);
             }
+            else if (dense)
+                SEALHIP_FWD_HALF(4, 3);
             else if (flags & kNttStrict)
             {
                 if (red == 5)
@@ -2682,7 +2719,8 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[21] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 6>),
+            const void *fwd[22] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 4, 3>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 6>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 1, 5>),

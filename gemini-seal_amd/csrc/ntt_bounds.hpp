@@ -217,6 +217,44 @@ namespace sealhip
             return anyrep ? 2 + kFwdApxGrowth * logn : 2 + kFwdApxGrowth;
         }
 
+        // ---- 2b. Dense lazy FORWARD schedule (round 4; STRICT mode's 56-60-bit rows, ntt_fwd_half_kernel<.., STRICT = 4>).
+        // STRICT means "nothing wraps" (SURVEY B.6); Harvey's corrected butterflies guarantee it for any prime with a
+        // conditional subtraction per butterfly. Where the consumer takes any representative below 2p (the Bsk rows of the BFV
+        // multiply: the tensor product reduces whatever it reads) the same residues come out of the reference's own
+        // butterfly -- exact quotient, product below 2p, first operand left as it is: values grow by 2p per layer -- if all 32
+        // words of a lane are brought back below 2p often enough that nothing reaches 2^64: with the single-precision quotient
+        // estimate (section 6) before rounds 2 and 3 and in the store. Inputs below kFwdDenseInMult p (the range the entry
+        // documents), top layer +2p, round 1 +8p = 14p; rounds 2 and 3 from 2p to 10p; the final round's f = log n - 13 layers
+        // from 10p to at most 16p: every value is BELOW fwd_dense_peak_mult(log n) p <= 16p < 2^64 for p < 2^60.
+        constexpr int kFwdDenseInMult = 4;
+        constexpr bool fwd_dense_reduce_before_round(int r) // r = 1..3 register rounds, 4 = the final round
+        {
+            return r == 2 || r == 3;
+        }
+        constexpr int fwd_dense_peak_mult(int logn)
+        {
+            int b = kFwdDenseInMult + 2, peak = b; // after the top layer
+            for (int r = 1; r <= 4; r++)
+            {
+                if (fwd_dense_reduce_before_round(r))
+                    b = 2;
+                const int layers = r <= 3 ? 4 : logn - 13;
+                for (int l = 0; l < layers; l++)
+                    b += 2;
+                peak = b > peak ? b : peak;
+            }
+            return peak; // (also the bound of the stored words before the store's reduction)
+        }
+        constexpr bool fwd_dense_admits(u64 p, int logn)
+        {
+            // (p below 2^60 in every shape although 14p would allow a little more: the stored words, below 2p, are operands of
+            //  the carry-free dot products of section 3, which take words below 2^61)
+            return logn >= kMinHalfLogn && logn <= kMaxHalfLogn && p < (u64(1) << 60) &&
+                   small_quot_admits(p, fwd_dense_peak_mult(logn)) && static_cast<u128>(fwd_dense_peak_mult(logn)) * p <= kWord;
+        }
+        static_assert(fwd_dense_peak_mult(14) == 14 && fwd_dense_peak_mult(15) == 14 && fwd_dense_peak_mult(16) == 16,
+                      "dense forward schedule: 14p after round 1, at most 16p after the final round at N = 2^16");
+
         // =====================================================================================================
         // 3. Tensor product formed by the inverse transform's load (dyadic_redc in ntt.hip): t = (sum of NP products) *
         // 2^-64 mod p as ONE Montgomery reduction, t < sum / 2^64 + p. Carry-free accumulation needs operands below 2^61

@@ -250,8 +250,22 @@ namespace sealhip
             std::size_t inb_stride = target_stride;
             if (strict_bfv && !finish)
             {
-                check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
-                check(launch_ntt(e, coeff, m * k, map_q, false, 0), "ntt(target)");
+                if (ntt_can_gather(e))
+                {
+                    // the transform reads the target rows where they are (no copy pass); the inner product reduces canonically,
+                    // so any representative of the transformed rows will do, as for the digit rows above
+                    NttSource ns{};
+                    ns.base[0] = tg;
+                    ns.poly_stride[0] = target_stride;
+                    for (int r = 0; r < k; r++)
+                        ns.code[r] = static_cast<unsigned short>(r);
+                    check(launch_ntt_gather(e, coeff, m * k, map_q, ns, kNttAnyRep | kNttApprox), "ntt(target, gathered)");
+                }
+                else
+                {
+                    check(launch_copy_rows(e, tg, target_stride, coeff, static_cast<std::size_t>(k) * N, m, k), "copy");
+                    check(launch_ntt(e, coeff, m * k, map_q, false, 0), "ntt(target)");
+                }
                 inb = coeff;
                 inb_stride = static_cast<std::size_t>(k) * N;
             }
@@ -476,7 +490,10 @@ namespace sealhip
                       "ntt(X, gathered q rows)");
                 // (fused tensor product: the wrapped Bsk words are brought below 2p as they are stored -- the residue class
                 //  is all the dyadic product depends on)
-                check(launch_ntt(e, X, m * sin * kb, mb, false, fused_tensor ? (kNttReduceOut | (lift_top ? kNttTopDone : 0)) : 0),
+                // (kNttAnyRep next to kNttReduceOut: "any representative below 2p will do". PARITY launches drop it on these
+                //  60-bit primes and keep the reference's words; STRICT launches take the dense lazy schedule with it, launch_half)
+                check(launch_ntt(e, X, m * sin * kb, mb, false,
+                                 fused_tensor ? (kNttReduceOut | kNttAnyRep | (lift_top ? kNttTopDone : 0)) : 0),
                       "ntt(X, Bsk rows)");
             }
             else

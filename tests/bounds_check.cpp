@@ -464,6 +464,70 @@ static void fwd_apx_execution(int logn, u64 p)
     CHECK(bad == 0, "forward approximate execution logn=%d: %d words leave their residue class or the documented range", logn, bad);
 }
 
+// ---- dense lazy forward schedule (ntt_bounds.hpp section 2b; STRICT mode's 56-60-bit rows) executed on 64-bit words with
+// the true values shadowed in 128 bits: inputs below 4p, the reference's butterfly with the EXACT Shoup quotient and no
+// reduction of its first operand, every word brought below 2p by the single-precision quotient estimate before rounds 2 and
+// 3 and in the store -- the layers in the order and grouping of ntt_fwd_half_kernel (top layer, three rounds of four, final)
+static void fwd_dense_execution(int logn, u64 p)
+{
+    const int n = 1 << logn;
+    std::mt19937_64 rng(logn * 11 + 3);
+    std::vector<u64> x(n), shadow(n);
+    for (int i = 0; i < n; i++)
+    {
+        x[i] = (i % 3 == 0) ? kFwdDenseInMult * p - 1 : rng() % (kFwdDenseInMult * p);
+        shadow[i] = x[i] % p;
+    }
+    const float c = static_cast<float>(4294967296.0 / static_cast<double>(p) * (1.0 - 0x1p-20));
+    u128 peak = 0;
+    bool wrapped = false, bad_reduce = false;
+    const auto reduce_all = [&] {
+        for (int i = 0; i < n; i++)
+        {
+            const unsigned q = static_cast<unsigned>(static_cast<float>(static_cast<unsigned>(x[i] >> 32)) * c);
+            const u64 r = x[i] - static_cast<u64>(q) * p;
+            bad_reduce = bad_reduce || r >= 2 * p || r % p != x[i] % p;
+            x[i] = r;
+        }
+    };
+    int layer = 0; // 0 = the top layer (gap n/2); the half-row kernel's rounds are layers 1-4, 5-8, 9-12, the rest is the final round
+    for (int l = logn - 1; l >= 0; l--, layer++)
+    {
+        const int round = layer == 0 ? 0 : (layer <= 12 ? (layer - 1) / 4 + 1 : 4);
+        if (layer >= 1 && layer <= 12 && (layer - 1) % 4 == 0 && fwd_dense_reduce_before_round(round))
+            reduce_all();
+        const int gap = 1 << l;
+        for (int blk = 0; blk < n; blk += 2 * gap)
+        {
+            const u64 w = (blk / (2 * gap)) % 5 == 0 ? p - 1 : rng() % p;
+            const u64 ws = static_cast<u64>((static_cast<u128>(w) << 64) / p);
+            for (int j = blk; j < blk + gap; j++)
+            {
+                const u64 u = x[j], y = x[j + gap];
+                const u64 q = quotient_model(y, ws, 0);
+                const u128 v = static_cast<u128>(y) * w - static_cast<u128>(q) * p;
+                const u128 X = static_cast<u128>(u) + v;
+                const i128 Y = static_cast<i128>(u) - static_cast<i128>(v) + 2 * static_cast<i128>(p);
+                wrapped = wrapped || v >= 2 * static_cast<u128>(p) || X >= kWord || Y < 0 || static_cast<u128>(Y) >= kWord;
+                peak = X > peak ? X : peak;
+                peak = static_cast<u128>(Y) > peak ? static_cast<u128>(Y) : peak;
+                x[j] = u + (y * w - q * p);
+                x[j + gap] = (u << 1) + 2 * p - x[j];
+                const u64 sv = static_cast<u64>(static_cast<u128>(shadow[j + gap]) * w % p), su = shadow[j];
+                shadow[j] = (su + sv) % p;
+                shadow[j + gap] = (su + p - sv) % p;
+            }
+        }
+    }
+    reduce_all(); // the store
+    CHECK(!wrapped && !bad_reduce, "dense forward execution logn=%d p=%llu wrapped or a reduction left [0, 2p)", logn, p);
+    CHECK(peak < static_cast<u128>(fwd_dense_peak_mult(logn)) * p, "dense forward execution logn=%d above its bound", logn);
+    int bad = 0;
+    for (int i = 0; i < n; i++)
+        bad += x[i] % p != shadow[i] || x[i] >= 2 * p;
+    CHECK(bad == 0, "dense forward execution logn=%d: %d words leave their residue class or [0, 2p)", logn, bad);
+}
+
 // ---- devmath.hpp reduce_small_quot: the same IEEE single-precision operations (u32 -> float round to nearest, one
 // multiplication, truncation) on words that sit on and next to multiples of p
 static void small_quot_model()
@@ -542,6 +606,15 @@ int main()
     small_quot_model();
     for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
         fwd_apx_execution(logn, max_prime_of_bits(fwd_lazy_prime_bits(logn)));
+    for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)
+    {
+        fwd_dense_execution(logn, max_prime_of_bits(60));
+        fwd_dense_execution(logn, (u64(1) << 59) + 12345);
+        fwd_dense_execution(logn, (u64(1) << 45) + 7);
+        CHECK(fwd_dense_admits(max_prime_of_bits(60), logn) && fwd_dense_admits(u64(1) << 45, logn) &&
+                  !fwd_dense_admits((u64(1) << 45) - 1, logn) && !fwd_dense_admits((u64(1) << 60) + 1, logn),
+              "dense forward admission edges logn=%d", logn);
+    }
     regression_whole_row();
     fp_product_model();
     for (int logn = kMinHalfLogn; logn <= kMaxHalfLogn; logn++)

@@ -1,4 +1,4 @@
-"""Absolute kernel times (HIP events) of one step: tools/step_profile.py [batch] [cfg1|cfg3|cfg3sq|cfg4|cfg4mul|cfg5]
+"""Absolute kernel times (HIP events) of one step: tools/step_profile.py [batch] [cfg1|cfg3|cfg3sq|cfg3strict|cfg4|cfg4mul|cfg5]
 cfg1 / cfg3 / cfg5: BFV multiply+relinearize at that config (cfg5: + mod_switch_to_next); cfg4: CKKS rotate_vector at
 config 4; cfg4mul: CKKS multiply+relinearize. Run it under rocprofv3 --kernel-trace to see what the tags do not cover."""
 import os, sys
@@ -10,9 +10,9 @@ dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 which = sys.argv[2] if len(sys.argv) > 2 else "cfg3"
 n = 1 << 15
-if which in ("cfg3", "cfg3sq"):
+if which in ("cfg3", "cfg3sq", "cfg3strict"):
     k, pr = 7, bench.CFG3_PRIMES
-    ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433)
+    ctx = S.Context(S.SCHEME_BFV, 15, pr, 1, 786433, mode=S.MODE_STRICT if which == "cfg3strict" else S.MODE_PARITY)
 elif which == "cfg1":
     n, k, pr = 1 << 12, 2, P12
     ctx = S.Context(S.SCHEME_BFV, 12, pr, 1, 786433)
