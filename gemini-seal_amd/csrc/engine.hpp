@@ -394,6 +394,7 @@ namespace sealhip
     hipError_t launch_ntt(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, bool inverse, int flags);
     // forward transform whose input rows are gathered from elsewhere (only when ntt_can_gather(e))
     bool ntt_can_gather(const Engine &e);
+    bool ntt_strict_top_done_ok(const Engine &e, const RowMap &map); // STRICT: kNttTopDone needs the dense forward schedule
     hipError_t launch_ntt_gather(const Engine &e, u64 *data, std::size_t nrows, const RowMap &map, const NttSource &src,
                                  int flags);
 

@@ -292,6 +292,10 @@ namespace sealhip
         // workgroup, where before every wave of it waited at the same barrier. Memory side unchanged per instruction (a wave
         // still covers 2^(f+6) consecutive coefficients per final-round group); its groups are now neighbours (a contiguous
         // 16 KB per wave) instead of 16 KB apart.
+#ifndef SEALHIP_NTT_FWD_DENSE
+#define SEALHIP_NTT_FWD_DENSE 1 // (0: A/B build without the dense lazy forward schedule of STRICT mode's 60-bit rows)
+#endif
+#define SEALHIP_NTT_FWD_DENSE_DEFAULT (SEALHIP_NTT_FWD_DENSE != 0)
 #ifndef SEALHIP_NTT_WAVE_LOCAL
 #define SEALHIP_NTT_WAVE_LOCAL 1
 #endif
@@ -2481,12 +2485,21 @@ namespace sealhip
                 if (ok)
                     flags &= ~kNttStrict;
             }
+            // STRICT launches on primes without the head-room of the rule above (the 60-bit Bsk rows of a BFV multiply) whose
+            // consumer takes any representative below 2p (kNttReduceOut | kNttAnyRep): the dense lazy schedule of
+            // ntt_bounds.hpp section 2b instead of a conditional subtraction per butterfly -- the reference's own butterfly,
+            // every word brought back below 2p before rounds 2 and 3 and in the store. Same residues, nothing wraps.
+            bool dense = SEALHIP_NTT_FWD_DENSE_DEFAULT && (flags & kNttStrict) != 0 && (flags & kNttReduceOut) != 0 && (flags & kNttAnyRep) != 0 &&
+                         (flags & kNttCanonical) == 0 && !src.base[0] && std::getenv("SEALHIP_NTT_EXACT_FWD") == nullptr;
+            for (int i = 0; dense && i < live.n; i++)
+                dense = bounds::fwd_dense_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
             // SEALHIP_NTT_NO_TICKET=1 (A/B of the hand-off cost) re-opens the race: read by the measurement-only build alone
             // (engine.hpp exp_env); in the shipping library this is the constant false
             static const bool no_ticket = exp_env("SEALHIP_NTT_NO_TICKET") != nullptr;
             // (kNttTopDone: no workgroup reads the other's half, nothing to hand off)
             const bool top_done = (flags & kNttTopDone) != 0;
-            if (top_done && ((flags & (kNttReduceOut | kNttStrict | kNttCanonical)) != kNttReduceOut || src.base[0]))
+            // (a STRICT launch may start below the top layer only on the dense schedule: Harvey's sequence has no such instance)
+            if (top_done && (((flags & (kNttReduceOut | kNttStrict | kNttCanonical)) != kNttReduceOut && !dense) || src.base[0]))
                 return hipErrorInvalidValue;
             // a launch whose live rows are all gathered from another buffer writes no row that anybody reads: nothing to
             // hand off either (SEALHIP_NTT_GATHER_TICKET=1 keeps the hand-off, for A/B)
@@ -2572,17 +2585,6 @@ namespace sealhip
                     flags |= kNttPolyMajor | (g << 16);
                 }
             }
-            // STRICT launches on primes without the head-room of the rule above (the 60-bit Bsk rows of a BFV multiply) whose
-            // consumer takes any representative below 2p (kNttReduceOut | kNttAnyRep): the dense lazy schedule of
-            // ntt_bounds.hpp section 2b instead of a conditional subtraction per butterfly -- the reference's own butterfly,
-            // every word brought back below 2p before rounds 2 and 3 and in the store. Same residues, nothing wraps.
-#ifndef SEALHIP_NTT_FWD_DENSE
-#define SEALHIP_NTT_FWD_DENSE 1 // (0: A/B build without it -- Harvey's corrected butterflies on those rows, as before)
-#endif
-            bool dense = SEALHIP_NTT_FWD_DENSE && (flags & kNttStrict) != 0 && (flags & kNttReduceOut) != 0 && (flags & kNttAnyRep) != 0 &&
-                         (flags & (kNttCanonical | kNttTopDone)) == 0 && !src.base[0] && std::getenv("SEALHIP_NTT_EXACT_FWD") == nullptr;
-            for (int i = 0; dense && i < live.n; i++)
-                dense = bounds::fwd_dense_admits(e.tables[map.prime[live.slot[i]]].p, LOGN);
             if (flags & kNttAnyRep)
             {
                 // the last layer may keep its first operand unreduced only if the grown values cannot wrap
@@ -2676,6 +2678,8 @@ namespace sealhip
                 else
                     SEALHIP_FWD_HALF(2, 0);
             }
+            else if (dense && top_done)
+                SEALHIP_FWD_HALF(4, 6);
             else if (dense)
                 SEALHIP_FWD_HALF(4, 3);
             else if (flags & kNttStrict)
@@ -2719,7 +2723,8 @@ namespace sealhip
         {
             const int lds_bytes = hpad(1 << (LOGN - 2)) * 8;
             hipError_t err = hipSuccess;
-            const void *fwd[22] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 4, 3>),
+            const void *fwd[23] = { reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 4, 3>),
+                                    reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 4, 6>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 6>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 3, 5>),
                                     reinterpret_cast<const void *>(&ntt_fwd_half_kernel<LOGN, 0, 5>),
@@ -3071,6 +3076,18 @@ namespace sealhip
             return false;
         for (int r = 0; r < k; r++)
             if (e.key_moduli[r] >= kFpPrimeBound)
+                return false;
+        return true;
+    }
+
+    // STRICT mode: may a producer apply the forward transform's top layer to rows on these primes (kNttTopDone)? Only the
+    // dense lazy schedule has an instance that starts below it (launch_half)
+    bool ntt_strict_top_done_ok(const Engine &e, const RowMap &map)
+    {
+        if (!SEALHIP_NTT_FWD_DENSE_DEFAULT || !e.use_half_kernel || e.logn < 14 || e.logn > 16 || std::getenv("SEALHIP_NTT_EXACT_FWD") != nullptr)
+            return false;
+        for (int r = 0; r < map.rows; r++)
+            if (map.prime[r] != kSkipRow && !bounds::fwd_dense_admits(e.tables[map.prime[r]].p, e.logn))
                 return false;
         return true;
     }

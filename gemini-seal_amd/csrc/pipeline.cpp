@@ -446,7 +446,15 @@ namespace sealhip
             for (int j = 0; j < nB; j++)
                 fused_tensor = fused_tensor && bounds::tensor_admits_2p(e.tables[lt.map_qbsk.prime[k + j]].p);
             // the lift applies the forward transform's top layer to the Bsk rows it writes (kNttTopDone below)
-            const bool lift_top = fused_tensor && bfv_lift_can_apply_top(e, h);
+            bool lift_top = fused_tensor && bfv_lift_can_apply_top(e, h);
+            if (lift_top && e.mode_strict)
+            {
+                RowMap bsk{};
+                bsk.rows = nB;
+                for (int j = 0; j < nB; j++)
+                    bsk.prime[j] = lt.map_qbsk.prime[k + j];
+                lift_top = ntt_strict_top_done_ok(e, bsk);
+            }
             for (int s = 0; s < sin; s++)
             {
                 const bool first = s < sa;

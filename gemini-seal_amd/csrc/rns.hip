@@ -855,7 +855,9 @@ namespace sealhip
     bool bfv_lift_can_apply_top(const Engine &e, const RnsDev &h)
     {
         static const bool off = exp_env("SEALHIP_LIFT_TOP_OFF") != nullptr; // (measurement-only build)
-        return !off && !e.mode_strict && h.redc_small && h.k >= 1 && h.k <= 16 && e.logn >= 14;
+        // (STRICT: the caller also asks ntt_strict_top_done_ok -- only the dense forward schedule starts below the top layer;
+        //  the layer itself is the same butterfly on canonical words either way: nothing can wrap in it)
+        return !off && h.redc_small && h.k >= 1 && h.k <= 16 && e.logn >= 14;
     }
 
     hipError_t launch_bfv_lift(const Engine &e, const RnsDev *d, const RnsDev &h, const u64 *in, std::size_t in_stride,
