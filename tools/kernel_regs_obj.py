@@ -16,7 +16,8 @@ KEYS = ("name", "vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment
 def kernels(path):
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = os.path.join(tmp, "fat"), os.path.join(tmp, "co")
-        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path])
+        # (with an output file: without one objcopy rewrites its input in place, and make then relinks the library)
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(tmp, "copy.o")])
         subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
