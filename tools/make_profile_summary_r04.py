@@ -64,7 +64,7 @@ out += ["", "Bench line of the same build (`bench_with_traffic.jsonl`, traffic m
         "- kernel time shares in the timed steps: %s" % json.dumps(d["kernel_time_shares"]), ""]
 st = last("bench_strict.jsonl")
 out += ["`--mode strict` (SURVEY F4 \"report both modes\"; `bench_strict.jsonl`): **%.0f ct-mul+relin/s**, %.1f ms per step, forward NTT %.3f in-step (launches whose consumer takes "
-        "any representative drop Harvey's conditional subtraction where nothing can wrap; the 60-bit Bsk rows and the in-bundle rows keep the corrected sequence), NTT section %.3f, %d items verified against the oracle's STRICT restatement: %s, "
+        "any representative drop Harvey's conditional subtraction where nothing can wrap; the 60-bit Bsk rows run the dense lazy forward schedule, the in-bundle rows are gathered and run the approximate quotient), NTT section %.3f, %d items verified against the oracle's STRICT restatement: %s, "
         "PCIe-inclusive %.0f ct/s" % (st["value"], st["ms_per_step"], st["roofline"]["frac"], st["ntt"]["hbm_roofline_frac"], st["verified_count"],
                                       st["verified_vs_oracle"], st["pcie_inclusive"]["value"]), ""]
 out += ["Other BASELINE lines through the same `bench.py` (`--config 4`, `--config 5`; 256 items each verified against the oracle):"]
