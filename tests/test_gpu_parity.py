@@ -535,6 +535,46 @@ def test_strict_mode_chain_vs_oracle(sealhip):
     assert np.array_equal(out.download(exp.shape)[:, :2], exp[:, :2])
 
 
+@pytest.mark.parametrize("logn,bits,count", [(14, [45, 45, 46], 5), (15, [55] * 4, 3), (16, [50] * 3, 2), (15, [58, 58, 59], 2)])
+def test_strict_mode_at_the_single_pass_ring_sizes(sealhip, logn, bits, count):
+    """STRICT at N = 2^14 .. 2^16 (round 4): the 60-bit Bsk rows run the dense lazy forward schedule (ntt_bounds.hpp section 2b) --
+    below the top layer, which the lift applies -- and the in-bundle rows of the key switch are gathered and transformed with the
+    approximate quotient. Word for word against the oracle's STRICT restatement, operands at their extremes planted (p - 1, 0, 1
+    in whole rows and scattered), multiply and relinearize separately and fused through square."""
+    n = 1 << logn
+    kmods = O.coeff_modulus_create(n, bits)
+    k = len(kmods) - 1
+    ctx = sealhip.Context(sealhip.SCHEME_BFV, logn, kmods, 1, 786433, mode=sealhip.MODE_STRICT)
+    ref = O.RefContext(1, logn, kmods, nsp=1, t=786433, mode=1)
+    ev = sealhip.Evaluator(ctx)
+    rng = np.random.default_rng(logn * 100 + bits[0])
+    key = np.stack([_rand_ct(rng, kmods, 2, n, 1)[0] for _ in range(k)])
+    dkey = sealhip.KSwitchKeys(ctx, key)
+    a = _rand_ct(rng, kmods[:k], 2, n, count)
+    b = _rand_ct(rng, kmods[:k], 2, n, count)
+    for r in range(k):
+        a[0, 0, r, :] = kmods[r] - 1          # a whole row at the top of the range
+        b[0, 1, r, ::3] = kmods[r] - 1
+        b[0, 0, r, 1::3] = 0
+        a[-1, 1, r, : n // 2] = 1
+    exp = np.zeros((count, 3, k, n), dtype=np.uint64)
+    keys = (C.c_void_p * 1)(key.ctypes.data)
+    for c in range(count):
+        assert L.ref_bfv_multiply(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(b[c]), 2, O.ptr(exp[c])) == 0
+    out = ctx.alloc(exp.size)
+    ev.multiply(ctx.upload(a), 2, ctx.upload(b), 2, k, count, out)
+    assert np.array_equal(out.download(exp.shape), exp), "multiply"
+    for c in range(count):
+        assert L.ref_relinearize(C.byref(ref.c), k, O.ptr(exp[c]), 3, keys) == 0
+    ev.relinearize_inplace(out, 3, k, count, [dkey])
+    assert np.array_equal(out.download(exp.shape)[:, :2], exp[:, :2]), "relinearize"
+    sq = np.zeros((count, 3, k, n), dtype=np.uint64)
+    for c in range(count):
+        assert L.ref_bfv_square(C.byref(ref.c), k, O.ptr(a[c]), 2, O.ptr(sq[c])) == 0
+    ev.square(ctx.upload(a), 2, k, count, out)
+    assert np.array_equal(out.download(sq.shape), sq), "square"
+
+
 # ------------------------------------------------------------------ full BASELINE sizes: properties
 @pytest.mark.parametrize("logn,bits,count", [(14, [50] * 6, 64), (15, [55] * 8, 32), (16, [50] * 4, 8)])
 def test_full_size_ntt_properties(sealhip, logn, bits, count):
