@@ -15,11 +15,12 @@
 // c-1 have landed". PCIe, not the engine, is what bounds this path (7.3 MB in + 3.7 MB out per
 // config-3 multiply+relinearize); the pipeline keeps the link busy in both directions while the kernels run.
 //
-// Round 4: what bounds it in fact is the gather / scatter -- 12 host threads move ~58 GB/s, and the calling thread does
-// both for every chunk (config 3: 8.1 + 4.0 ms of copies per 64 pairs against 8.5 ms on the link). A caller whose buffers
-// live in memory it keeps (the blocks of a MemoryPool, native/src/seal/util/mempool.cpp:45,145) can pin them in place
-// once -- sealhip_host_register -- and an array whose items all lie in registered ranges skips the staging copy: the DMA
-// engine reads / writes the caller's buffers directly, the host threads have nothing to do for it.
+// Round 4, measured (profiles/r04/pcie_probe.txt, host_batch_probe.txt): the link gives 48.6 GB/s each way when both directions
+// run; through the staging copies (12 host threads, the calling thread gathers and scatters every chunk) a config-3 batch
+// sees 37-41 GB/s in. A caller whose buffers live in memory it keeps (the blocks of a MemoryPool,
+// native/src/seal/util/mempool.cpp:45,145) can pin them in place once -- sealhip_host_register -- and an array whose items all
+// lie in registered ranges skips the staging copy: the DMA engine reads / writes the caller's buffers directly (42-45 GB/s
+// in, +10-20 % ciphertexts per second), the host threads have nothing to do for it.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
