@@ -835,6 +835,11 @@ def main(argv=None):
                                       "issue_ceiling_as_frac_of_hbm": rows_issue * 16 * n / 1e9 / HBM_PEAK_GBS})
             r["alu_ceiling_frac_butterflies_only"] = r["alu_ceiling_frac"]
             r["alu_ceiling_frac"] = r["frac"] / r["valu_ceiling"]["issue_ceiling_as_frac_of_hbm"]
+        # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the same passes: how full the vector ALUs are in CYCLES (the single-pass
+        # kernels hold four waves per SIMD, so a wave can have a vector instruction executing in at most a quarter of its cycles).
+        # Larger than alu_ceiling_frac by the clock: the rate kernel alone runs faster under the power limit than the transform.
+        if tk.get("valu_active_share_of_wave_cycles"):
+            r["valu_busy_frac"] = min(1.0, 4.0 * tk["valu_active_share_of_wave_cycles"])
 
     roof, traffic_rec = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -1026,9 +1031,13 @@ def measure_traffic(args):
         return None
     batch, steps = min(256, args.batch), 2
     totals = {}  # tag -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "SQ_INSTS_VALU": wave instructions, "rows": rows, "launches": n}
-    everything = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
+    everything = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "SQ_ACTIVE_INST_VALU": 0.0, "SQ_WAVE_CYCLES": 0.0}
     rate_kernel_insts = {}  # kind -> SQ_INSTS_VALU of the butterfly-rate kernel (bench.py's valu_ceiling runs it in the child too)
-    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+    # (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: the share of a resident wave's cycles with a vector instruction executing -- with
+    #  the kernels' four waves per SIMD, four times that is how full the vector ALUs are, in cycles; optional: a pass that
+    #  fails leaves the traffic figures alone)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"):
+        optional = counter in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES")
         d = tempfile.mkdtemp(prefix="sealhip_pmc_", dir="/tmp")
         # the step only (no NTT-only section): the same mix of launches that roofline.achieved is measured over
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
@@ -1038,6 +1047,9 @@ def measure_traffic(args):
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
+            if optional:
+                shutil.rmtree(d, ignore_errors=True)
+                continue
             return None
         for row in csv.DictReader(open(files[0])):
             name = row["Kernel_Name"]
@@ -1053,7 +1065,8 @@ def measure_traffic(args):
             tag = next((t for key, t in KERNEL_TAGS if key in name), None)
             if tag is None:
                 continue
-            t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "rows": 0.0, "launches": 0})
+            t = totals.setdefault(tag, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "SQ_ACTIVE_INST_VALU": 0.0,
+                                        "SQ_WAVE_CYCLES": 0.0, "rows": 0.0, "launches": 0})
             t[counter] += val
             if counter == "FETCH_SIZE":
                 t["rows"] += int(row["Grid_Size"]) / int(row["Workgroup_Size"]) / 2  # half kernels: two workgroups per row
@@ -1080,6 +1093,8 @@ def measure_traffic(args):
                     "write_size_kb_total": t["WRITE_SIZE"],
                     # wave-level vector-ALU instructions per transformed row (SQ_INSTS_VALU, its own --pmc pass)
                     "valu_wave_insts_per_row": t["SQ_INSTS_VALU"] / t["rows"]}
+        if t["SQ_WAVE_CYCLES"] > 0 and t["SQ_ACTIVE_INST_VALU"] > 0:
+            rec[tag]["valu_active_share_of_wave_cycles"] = t["SQ_ACTIVE_INST_VALU"] / t["SQ_WAVE_CYCLES"]
     # the butterfly-rate kernel under the same counter: wave-level VALU instructions per butterfly of the measured sequence
     # (csrc/ntt.hip ntt_butterfly_rate: a warm-up launch of iters / 8 and two of iters = 800, 2048 workgroups x 512 lanes x 32
     # butterflies per iteration; two calls -- the instance's sequence and the reference's -- when they differ)

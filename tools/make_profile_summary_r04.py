@@ -36,12 +36,14 @@ out += ["", "Bench line of the same build (`bench_with_traffic.jsonl`, traffic m
         "PMC traffic / algorithmic bytes = %.3f. **bound: %s** -- measured arithmetic ceiling of the butterfly sequence on this box %.2f T "
         "butterflies/s (reference's exact sequence: %.2f T) = %.3f of HBM for butterflies alone; the kernel executes %.0f wave-level VALU "
         "instructions per row (SQ_INSTS_VALU, own --pmc pass) against %.2f per butterfly in the rate kernel -> issue ceiling %.3f of HBM; "
-        "the kernel runs at **%.2f of that ceiling** (`roofline.alu_ceiling_frac`)" % (
+        "the kernel runs at **%.2f of that ceiling** (`roofline.alu_ceiling_frac`); in cycles its vector ALUs are occupied %.0f %% of the time "
+        "(`roofline.valu_busy_frac`: 4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, own --pmc passes) -- the difference is the clock, which the power "
+        "limit holds lower in the transform than in the rate kernel (`fwd_clock_trace.txt`)" % (
             rf["achieved"], rf["peak"], rf["frac"], rf["launches"], rf["avg_launch_ms"], rf["rows_per_launch"],
             (rf["traffic"] or 0) / rf["algorithmic_bytes_per_launch"], rf["bound"], rf["valu_ceiling"]["butterflies_per_s"] / 1e12,
             rf["valu_ceiling"]["butterflies_per_s_reference_sequence"] / 1e12, rf["valu_ceiling"]["as_frac_of_hbm"],
             rf["valu_ceiling"].get("kernel_valu_wave_insts_per_row", 0), rf["valu_ceiling"].get("valu_insts_per_butterfly", 0),
-            rf["valu_ceiling"].get("issue_ceiling_as_frac_of_hbm", 0), rf["alu_ceiling_frac"]),
+            rf["valu_ceiling"].get("issue_ceiling_as_frac_of_hbm", 0), rf["alu_ceiling_frac"], 100 * rf.get("valu_busy_frac", 0)),
         "- forward NTT per row from the counters: read %.1f KB (x%.3f of 262.1), written %.1f KB (x%.4f of 262.1): no wasted traffic (reads below "
         "the algorithmic 262 KB on average: the key-switch digit launches run four readers of a source row on one XCD)" % (
             fw["read_bytes_per_row"] / 1e3, fw["read_bytes_per_row"] / 262144, fw["write_bytes_per_row"] / 1e3, fw["write_bytes_per_row"] / 262144),
