@@ -242,7 +242,7 @@ namespace sealhip
                 for (int q = 0; q < k; q++)
                 {
                     const PrimeDev &Q = primes[d->row_prime[q]];
-                    pt[q * N] = barrett_reduce_128(v, 0, Q.p, Q.cr0, Q.cr1);
+                    pt[q * N] = barrett_reduce_63(v, Q.p, Q.cr1); // (v < P < 2^61: the one-word Barrett step gives the same canonical residue)
                 }
                 return;
             }
@@ -372,7 +372,9 @@ namespace sealhip
                 {
 #pragma unroll
                     for (int h = 0; h < 2; h++)
-                        temp[h] = barrett_reduce_128(sred[h], 0, Q.p, Q.cr0, Q.cr1);
+                        // (sred < P < 2^61 is one word: the one-word Barrett step -- a 64-bit high product, a multiply, a
+                        //  conditional subtraction -- gives the canonical residue the two-word form gave with four times the work)
+                        temp[h] = barrett_reduce_63(sred[h], Q.p, Q.cr1);
                 }
                 else
                 {
