@@ -96,6 +96,7 @@ namespace sealhip
     constexpr int kNttPolyMajor = 0x4000;        // forward half kernel: live positions grouped item by item (ntt.hip half_block_map; group size in bits 16-23)
     constexpr int kNttPolyMajorRequest = 0x8000; // (launcher-internal: resolved per arithmetic instance)
     constexpr int kNttSmallQuot = 0x1000000;     // (launcher-internal) canonical approximate-quotient launch: single-precision quotient estimate in the store
+    constexpr int kNttXchgTop = 0x2000000;       // (launcher-internal, SEALHIP_NTT_XCHG_TOP builds) the two workgroups of a row share the top layer
     constexpr int kNttDebugNoSignal = 0x40; // forward half kernel: never send the hand-off signal (tests of the time-out path)
     // forward, single-pass kernel, with kNttReduceOut, in place: the producer of the rows has already applied the top layer
     // (gap N/2) -- bfv_lift2 does for the Bsk rows it writes. Each workgroup then loads its own half only: no second read of

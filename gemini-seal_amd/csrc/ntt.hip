@@ -1143,6 +1143,140 @@ namespace sealhip
             }
         }
 
+        // ---- round 4 experiment (SEALHIP_NTT_XCHG_TOP, default 0): the top layer SHARED by the two workgroups of a row instead
+        // of computed by both. Workgroup h owns the butterflies j whose index bit T-1 equals h (slot bit 4 of arrangement 1:
+        // 16 of a lane's 32 slots): it loads both inputs of those, computes both outputs, keeps the one of its half and PUBLISHES
+        // the other into the row at the position of the input it has just consumed (in place: position (1-h) 2^T + j is an
+        // input of this very butterfly and of no other); then it signals, waits for the sibling's wave with the same lanes, and
+        // reads what that wave published for it (positions h 2^T + j', bit T-1 of j' = 1-h). 16 full butterflies per lane instead
+        // of 32 products with one output each. Published words and the signal cross CUs: relaxed atomics at agent scope (sc1:
+        // write-through / L1-bypassing accesses), the signal ordered after the stores by a wait for their completion. The final
+        // stores of a workgroup only touch positions whose last reader it is itself, so the "both have finished reading" hand-off
+        // before the store phase is not needed in this form.
+        // MEASURED (profiles/r04/sibling_top_exchange_ab.txt; bit-exact in both forms): standalone forward transform at N = 2^15
+        // 40.3 % of the HBM roofline without it, 34.2 % with it as written here, 39.0 % with plain 16-byte stores and
+        // nontemporal loads (which is only correct while the two workgroups share an L2); FP64 instances 50.9 / 40.2 / 47.8 %.
+        // The 160 instructions per lane it saves cost more in the load phase (write-through stores, L1-bypassing loads, the
+        // wait for the sibling's wave) than they are worth: left in the tree as the record of that, compiled out.
+#ifndef SEALHIP_NTT_XCHG_TOP
+#define SEALHIP_NTT_XCHG_TOP 0
+#endif
+        template <int T, int STRICT, int HALF, int REDUCE>
+        __device__ __forceinline__ void h_load_top_xchg(u64 (&x)[32], const u64 *srcp, u64 *rowp,
+                                                        const u64 *__restrict__ tw, int tid, u64 two_p, u64 neg_p, u64 cr1,
+                                                        unsigned *flagw, unsigned *timeout_flag, unsigned spin_limit, bool signal)
+        {
+            static_assert(REDUCE <= 3, "plain or single-prime mod-up loads");
+            const int jb = Arr<T, 1>::tid_index(tid);
+            ZeroPairs zp;
+            if constexpr (kApx<STRICT> == 2)
+                zp.init();
+            u64x2 W1;
+            if constexpr (STRICT == 3)
+                W1.x = ((twd_const_t)tw)[1];
+            else
+                W1 = ((tw_const_t)tw)[1];
+            u64 *pub = rowp + ((1 - HALF) << T) + jb; // where the outputs of the other half go
+#pragma unroll
+            for (int batch = 0; batch < 2; batch++)
+            {
+                ulonglong2 lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    const int s = (HALF << 4) | ((batch * 4 + i) * 2);
+                    const int idx = jb + Arr<T, 1>::slot_index(s);
+                    lo[i] = *reinterpret_cast<const ulonglong2 *>(srcp + idx);
+                    hi[i] = *reinterpret_cast<const ulonglong2 *>(srcp + (1 << T) + idx);
+                }
+                if constexpr (REDUCE == 1 || REDUCE == 2) // gathered single-prime mod-up (multi_special_primes.cpp:103-107)
+                {
+                    const u64 p = STRICT == 3 ? static_cast<u64>(fp_of(two_p)) : 0 - neg_p;
+                    const auto red = [&](u64 v) {
+                        if constexpr (REDUCE == 2)
+                            return v >= p ? v - p : v;
+                        else
+                            return barrett_reduce_63(v, p, cr1);
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        lo[i].x = red(lo[i].x);
+                        lo[i].y = red(lo[i].y);
+                        hi[i].x = red(hi[i].x);
+                        hi[i].y = red(hi[i].y);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2)
+                {
+                    const int s = (HALF << 4) | ((batch * 4 + i) * 2);
+                    u64 u[4] = {lo[i].x, lo[i].y, lo[i + 1].x, lo[i + 1].y};
+                    u64 y[4] = {hi[i].x, hi[i].y, hi[i + 1].x, hi[i + 1].y};
+                    if constexpr (STRICT == 3)
+                    {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            u[j] = fp_bits(fp_from_u64(u[j]));
+                            y[j] = fp_bits(fp_from_u64(y[j]));
+                            fp_butterfly_fwd(u[j], y[j], W1.x, fp_of(two_p), fp_of(neg_p));
+                        }
+                    }
+                    else
+                    {
+                        const u64 w[4] = {W1.x, W1.x, W1.x, W1.x}, ws[4] = {W1.y, W1.y, W1.y, W1.y};
+                        if (STRICT == 1)
+                        {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                u[j] = u[j] >= two_p ? u[j] - two_p : u[j];
+                        }
+                        if constexpr (kApx<STRICT> == 2)
+                            butterflies_fwd_apx2<true, 4>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p), zp.z);
+                        else
+                            butterflies_fwd_hs<true, 4, kApx<STRICT>>(u, y, w, ws, neg_p, fwd_addend<STRICT>(two_p, neg_p));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        x[s + j] = HALF ? y[j] : u[j];
+                        __hip_atomic_store(pub + Arr<T, 1>::slot_index(s + j), HALF ? u[j] : y[j], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the published words of this wave have left (a completed sc1 store is visible at agent scope); then the signal
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (explicit: a workgroup-scope release need not wait for stores)
+            if ((tid & 63) == 0)
+            {
+                if (signal)
+                    __hip_atomic_fetch_or(flagw, 1u << HALF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (((__hip_atomic_load(flagw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (1 - HALF)) & 1u) == 0)
+                {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > spin_limit)
+                    {
+                        // (never observed: do not hang the device; the launch is flagged as failed for every host-visible
+                        //  synchronisation point, like the hand-off of the other form)
+                        __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const u64 *got = rowp + (HALF << T) + jb;
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+            {
+                const int s = ((1 - HALF) << 4) | t;
+                x[s] = __hip_atomic_load(got + Arr<T, 1>::slot_index(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
         // XCD-aware block -> (row, half) map (speed only; any placement gives the same result). Blocks are dealt
         // round-robin over the 8 XCDs, each with its own 4 MB L2. Rows are enumerated prime-major
         // (v = position * npolys + poly, positions = the LIVE slots of a polynomial in slot order) and XCD x gets the
@@ -1360,6 +1494,20 @@ namespace sealhip
                     x[s + 1] = v.y;
                 }
             }
+            else if constexpr (SEALHIP_NTT_XCHG_TOP && REDUCE <= 3)
+            {
+                {
+                    // one flag word per (row, wave): bit h = "the wave of workgroup h has published"
+                    unsigned *flagw = tickets + (row << 4) + (static_cast<unsigned>(wave_base) >> 6);
+                    const bool signal = !(flags & kNttDebugNoSignal);
+                    if (half)
+                        h_load_top_xchg<T, STRICT, 1, REDUCE>(x, srcp, rowp, tw, fresh_tid(wave_base), two_p, neg_p, P.cr1, flagw,
+                                                              timeout_flag, spin_limit, signal);
+                    else
+                        h_load_top_xchg<T, STRICT, 0, REDUCE>(x, srcp, rowp, tw, fresh_tid(wave_base), two_p, neg_p, P.cr1, flagw,
+                                                              timeout_flag, spin_limit, signal);
+                }
+            }
             else if (half)
                 h_load_top<T, STRICT, 1, REDUCE>(x, srcp, tw, fresh_tid(wave_base), two_p, neg_p, P.cr1, src.aux_p, src.aux_cr1, src.aux_top);
             else
@@ -1388,7 +1536,8 @@ namespace sealhip
             __builtin_amdgcn_sched_barrier(0);
             if (!NTT_EXP(flags, 0x200))
                 h_exchange<T, 1, 2>(x, lds, fresh_tid(wave_base));
-            if (fresh_tid(wave_base) == 0 && tickets && !(flags & kNttDebugNoSignal))
+            constexpr bool xchg_top = SEALHIP_NTT_XCHG_TOP && REDUCE <= 3; // (its own hand-off, in the load phase)
+            if (!xchg_top && fresh_tid(wave_base) == 0 && tickets && !(flags & kNttDebugNoSignal))
                 __hip_atomic_fetch_add(&tickets[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if constexpr (kApx<STRICT> == 2)
                 zp.init();
@@ -1418,6 +1567,8 @@ namespace sealhip
             NTT_STAMP(2);
             // ---- wait until the sibling workgroup has read its inputs (normally true ~tens of microseconds ago)
             const auto wait_for_sibling = [&] {
+                if (xchg_top)
+                    return;
                 if ((fresh_tid(wave_base) & 63) == 0 && tickets) // one poll per wave, no workgroup barrier
                 {
                     unsigned spins = 0;
@@ -2507,8 +2658,14 @@ namespace sealhip
             bool all_gathered = src.base[0] != nullptr && !gather_ticket;
             for (int i = 0; all_gathered && i < live.n; i++)
                 all_gathered = src.code[live.slot[i]] != kSkipRow;
-            const bool no_handoff = no_ticket || top_done || all_gathered;
-            unsigned *tickets = no_handoff ? nullptr : e.ntt_tickets(nrows); // zeroed for this launch, stream-ordered
+            // SEALHIP_NTT_XCHG_TOP builds: the workgroups of a row share the top layer (h_load_top_xchg) wherever the load is a
+            // plain or single-prime mod-up one; a flag word per (row, wave) then
+            const int red0 = src.base[0] ? src.reduce_mode : 0;
+            const bool xchg = SEALHIP_NTT_XCHG_TOP && !top_done && red0 <= 2; // (every launch of the instances with REDUCE <= 3)
+            if (xchg)
+                flags |= kNttXchgTop;
+            const bool no_handoff = !xchg && (no_ticket || top_done || all_gathered);
+            unsigned *tickets = no_handoff ? nullptr : e.ntt_tickets(xchg ? nrows * 16 : nrows); // zeroed for this launch, stream-ordered
             if (e.ntt_suppress_signal)
                 flags |= kNttDebugNoSignal; // sealhip_debug_ntt_handoff: drive the time-out path
             {
