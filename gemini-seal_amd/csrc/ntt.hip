@@ -1824,8 +1824,11 @@ namespace sealhip
                 base += 1 << (f - 1 - W);
             }
         }
+#ifndef SEALHIP_NTT_INV_FIRST_APX2
+#define SEALHIP_NTT_INV_FIRST_APX2 1 // (level-2 quotient in the non-reducing layers of the first round too; 0: exact, as before)
+#endif
         template <int T, int G, int LZ>
-        __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp)
+        __device__ __forceinline__ void h_first_group_regs(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp, ZeroPairs &zp)
         {
             constexpr int f = T - 12;
             static_assert(LZ != 1 || f - 1 < bounds::inv_lazy_r1(T), "sparse schedule: the first layers are never the reducing ones");
@@ -1860,7 +1863,12 @@ namespace sealhip
                     else if (InvLazy<T, LZ>::mode(W) != 1) // (dense schedule at N = 2^16: its layer 2 is one of the first three)
                         tt = reduce_small_quot(tt, __uint_as_float(static_cast<unsigned>(rdp)), neg_p);
                     x[s] = tt;
-                    x[s | bit] = mulmod_lazy_hs<false>(u - v + addend, Wv.x, Wv.y, neg_p);
+                    // (W is a constant after unrolling: the branch folds)
+                    // (sparse schedule only: the dense plain instances spill four dwords with the pairs live here)
+                    if (SEALHIP_NTT_INV_FIRST_APX2 && LZ == 1 && kInvApx2 && InvLazy<T, 1>::mode(W) == 1)
+                        x[s | bit] = mulmod_lazy_apx2<false>(u - v + addend, Wv.x, Wv.y, neg_p, zp.z[(e >> (W + 1)) & 1]);
+                    else
+                        x[s | bit] = mulmod_lazy_hs<false>(u - v + addend, Wv.x, Wv.y, neg_p);
                 }
                 base += 1 << (f - 1 - W);
             }
@@ -1874,11 +1882,11 @@ namespace sealhip
                 if constexpr (I + 1 < FinalStage<T>::SG)
                     FirstStage<T, ST, LZ, I + 1>::load(tg, tw, jb, N);
             }
-            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp)
+            __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *tg, u64 neg_p, u64 two_p, u64 rdp, ZeroPairs &zp)
             {
-                h_first_group_regs<T, ST * FinalStage<T>::SG + I, LZ>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p, rdp);
+                h_first_group_regs<T, ST * FinalStage<T>::SG + I, LZ>(x, tg + I * FinalStage<T>::NTW, neg_p, two_p, rdp, zp);
                 if constexpr (I + 1 < FinalStage<T>::SG)
-                    FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p, rdp);
+                    FirstStage<T, ST, LZ, I + 1>::run(x, tg, neg_p, two_p, rdp, zp);
             }
         };
         // AHEAD: the next stage's twiddles are requested before this stage is computed (two stages of twiddles live: 48
@@ -1889,18 +1897,18 @@ namespace sealhip
         struct FirstPipe
         {
             __device__ static __forceinline__ void run(u64 (&x)[32], const u64x2 *cur, const u64 *__restrict__ tw, int jb,
-                                                       int N, u64 neg_p, u64 two_p, u64 rdp)
+                                                       int N, u64 neg_p, u64 two_p, u64 rdp, ZeroPairs &zp)
             {
                 u64x2 next[FinalStage<T>::SG * FinalStage<T>::NTW];
                 if constexpr (ST + 1 < FinalStage<T>::NS && AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 __builtin_amdgcn_sched_barrier(0);
-                FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p, rdp);
+                FirstStage<T, ST, LZ>::run(x, cur, neg_p, two_p, rdp, zp);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ST + 1 < FinalStage<T>::NS && !AHEAD)
                     FirstStage<T, ST + 1, LZ>::load(next, tw, jb, N);
                 if constexpr (ST + 1 < FinalStage<T>::NS)
-                    FirstPipe<T, ST + 1, LZ, AHEAD>::run(x, next, tw, jb, N, neg_p, two_p, rdp);
+                    FirstPipe<T, ST + 1, LZ, AHEAD>::run(x, next, tw, jb, N, neg_p, two_p, rdp, zp);
             }
         };
 
@@ -2203,8 +2211,11 @@ namespace sealhip
                     h_exchange<T, LA, 4>(x, lds, fresh_tid(wave_base));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                ZeroPairs zp1; // (devmath.hpp mulhi_apx2: the first round's own pairs, written here, dead after it)
+                if constexpr (SEALHIP_NTT_INV_FIRST_APX2 && LZ == 1 && kInvApx2)
+                    zp1.init();
                 FirstPipe<T, 0, LZ, FinalStage<T>::PIPE && !(DY && kLazy<LZ>) && !(WHOLE && LZ == 0)>::run(x, tg0, tw, gbase + jloc, N, neg_p,
-                                                                                                         two_p, rdp);
+                                                                                                         two_p, rdp, zp1);
             }
             const int jb3 = gbase + Arr<T, 3>::tid_index(fresh_tid(wave_base));
             u64 w0[kIL], ws0[kIL];

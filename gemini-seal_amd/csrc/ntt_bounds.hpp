@@ -48,9 +48,9 @@ namespace sealhip
         // Layer l reduces its sum with barrett_lazy (MODE 2, -> [0, 2p)) only for l == r1 and l == T - 1; elsewhere the sum
         // is left as it is (MODE 1). Values entering layer l are below 2^shift(l) * p; the difference operand gets exactly
         // that bound added so that it stays non-negative. The product is a Shoup product of a 64-bit word: below 2p with the
-        // exact quotient (the two reducing layers, and the first f = log n - 13 layers, which run at the register cap), below
-        // kInvLazyProductMult p = 4p with the level-2 quotient (section 2: quotient_shortfall) that every other MODE 1 layer
-        // uses since round 4. A MODE 1 layer's outputs are bounded by its unreduced sum, 2^(shift + 1) p >= 4p, so the
+        // exact quotient (the two reducing layers; in the dense schedule also the first f = log n - 13 layers, whose plain
+        // instances would spill with the zero-high pairs live), below kInvLazyProductMult p = 4p with the level-2 quotient
+        // (section 2: quotient_shortfall) that every other MODE 1 layer uses since round 4. A MODE 1 layer's outputs are bounded by its unreduced sum, 2^(shift + 1) p >= 4p, so the
         // recurrence below takes the maximum of the two and finds the schedule unchanged.
         constexpr int kInvLazyProductMult = 4;
         // Two schedules (`sched`):
