@@ -108,7 +108,7 @@ out += ["```", "", "Round-4 experiment records in this directory:",
         "against round 3's in the same library otherwise: forward 17.41 -> 17.10 ms, inverse + tensor 12.22 -> 12.04 ms, step 44.68 -> 44.17 ms (-1.1 %).",
         "- `step_ab_dense_inverse.txt`: the dense lazy schedule (LZ = 3) on the 60-bit Bsk rows of the inverse against the build before it: inverse + tensor "
         "11.94 -> 11.61 ms per 1024 pairs (-2.8 %).",
-        "- `fuzz_parity.txt`: `tools/fuzz_parity.py`, 4350 random cases (schemes, rings 2^3 .. 2^16, 25-59-bit primes, 1-3 special primes, batches up to 33, a quarter of the last 1350 in STRICT mode, the last 1150 on the wave-owned build, the last 1400 with the dense STRICT forward schedule; "
+        "- `fuzz_parity.txt`: `tools/fuzz_parity.py`, 4550 random cases (schemes, rings 2^3 .. 2^16, 25-59-bit primes, 1-3 special primes, batches up to 33, a quarter of the last 1350 in STRICT mode, the last 1150 on the wave-owned build, the last 1400 with the dense STRICT forward schedule; "
         "round 4: the four NTT entries on their documented operand ranges), all bit-exact against the oracle.",
         "- `inv_standalone_ab.txt`: standalone inverse at N = 2^15 (whole-row form): 0.319 -> 0.325 with the level-2 quotient in the lazy layers.",
         "- `bconv_mfma_ab.txt` (`tools/ubench_bconv_mfma.hip`, VERDICT r03 item 5): config 3's q -> Bsk base conversion as int8-MFMA byte-limb products, "
