@@ -86,6 +86,13 @@ def test_no_cpu_fallback_and_error_mapping(S):
         S.Evaluator(ctx).multiply(0x1000, 2, 0x2000, 2, 2, 1, 0x3000)
     with pytest.raises(S.LogicError):
         ctx.alloc(16)
+    # (pinning host memory for the *_host entries needs a device too; a null pointer is E_POINTER first)
+    buf = np.zeros(64, dtype=np.uint64)
+    with pytest.raises(S.LogicError):
+        S.Evaluator(ctx).host_register(buf)
+    with pytest.raises(S.LogicError):
+        S.Evaluator(ctx).host_unregister(buf)
+    assert (S.lib().sealhip_host_register(ctx.handle, None, 64) & 0xFFFFFFFF) == S.E_POINTER
     # E_POINTER before anything else, like the reference's IfNullRet
     with pytest.raises(TypeError):
         ctx.ntt_negacyclic_harvey(0, 1, 2)
